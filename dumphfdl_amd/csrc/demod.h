@@ -1,0 +1,42 @@
+// demod.h -- host-side owner of the per-channel demodulator / burst decoder device state (K4 + K5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include "../../include/hfdl_gpu.h"
+#include "kernels.h"
+
+namespace hfdl {
+
+struct ChanState;
+struct FrameRec;
+
+struct Demod {
+	int nch = 0, outs = 0, cap = 0;         // cap = max 5400-sps samples per block
+	float *d_tables = nullptr;              // packed DemodTables image
+	ChanState *d_states = nullptr;
+	float2 *d_data = nullptr;               // [nch][2][5040] equalised data symbols
+	FrameRec *d_frames = nullptr;
+	int *d_counts = nullptr;                // [0] frames queued this block, [1] pdus waiting, [2] pdus dropped
+	hfdl_gpu_pdu *d_pdus = nullptr;
+	int32_t *d_freqs = nullptr;
+	int pdu_cap = 0;
+	// stage taps
+	bool taps_on = true;
+	float2 *d_tap_rs = nullptr, *d_tap_mf = nullptr, *d_tap_sym = nullptr;
+	float *d_tap_lvl = nullptr;
+	int *d_tap_counts = nullptr;            // [nch][2]
+	size_t lds_bytes = 0;
+
+	int init(int nch, int outs, float resamp_rate, const int32_t *freqs, hipStream_t st);
+	int enqueue_block(const float2 *chan_out, const NcoState *nco, hipStream_t st);
+	int collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);
+	int tap(int what, int channel, const void **src, size_t *nfloats);
+	void release();
+};
+
+int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out);
+int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const int32_t *bitmask_lsb, int32_t nframes,
+		uint8_t *octets, int32_t *lens);
+
+}  // namespace hfdl

@@ -1,0 +1,432 @@
+// demod_kernels.hip -- K4 (per-channel streaming demodulator) and K5 (batched burst decoder) for gfx950.
+//
+// K4  demod_kernel        one wavefront per channel; body in demod_core.h (reference src/hfdl.c:676-892)
+// K5  burst_decode_kernel one wavefront per finished frame: descramble + soft de-map + 40-row de-interleave
+//                         + rate-1/4 combine + K=7 Viterbi + octet bit reversal + PDU metadata
+//                         (reference decode_user_data / dispatch_pdu, src/hfdl.c:993-1080;
+//                          libfec update_viterbi27_blk / chainback_viterbi27, src/libfec/viterbi27_port.c:105-221).
+//     Viterbi mapping: lane = trellis state (64 = one wavefront); the two predecessor metrics arrive by
+//     cross-lane shuffle, the 64 decisions of a trellis step are one __ballot word kept in LDS.
+#include <vector>
+#include <cstring>
+#include "demod_core.h"
+#include "demod_tables.h"
+#include "demod.h"
+
+namespace hfdl {
+
+static_assert(sizeof(cf) == sizeof(float2), "cf must alias float2");
+
+struct DevTables {            // device image, pointers resolved on the host
+	DemodConst c;
+	const uint8_t *scrambler;
+};
+
+struct DemodBuffers {
+	ChanState *states;
+	cf *data;
+	FrameRec *frames;
+	int *counts;
+	int frame_cap;
+	cf *tap_rs, *tap_mf, *tap_sym;
+	float *tap_lvl;
+	int *tap_counts;
+	int cap;
+};
+
+__global__ __launch_bounds__(64) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
+		const NcoState *__restrict__ nco, int outs_stride)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	const int c = blockIdx.x, lane = threadIdx.x;
+	// LDS carve-up
+	unsigned char *p = lds;
+	ChanArrays *A = (ChanArrays *)p;                 p += (sizeof(ChanArrays) + 15) & ~(size_t)15;
+	float *l_ss_mf = (float *)p;                     p += sizeof(float) * D_SS_NPFB * D_SS_TAPS;
+	float *l_ss_dmf = (float *)p;                    p += sizeof(float) * D_SS_NPFB * D_SS_TAPS;
+	float *l_mf = (float *)p;                        p += sizeof(float) * 32;
+	float *l_eq = (float *)p;                        p += sizeof(float) * 16;
+	uint64_t *l_m1 = (uint64_t *)p;                  p += sizeof(uint64_t) * 16;
+	cf *rs = (cf *)p;                                p += sizeof(cf) * (size_t)B.cap;
+	cf *agc = (cf *)p;                               p += sizeof(cf) * (size_t)B.cap;
+	cf *mf = (cf *)p;                                p += sizeof(cf) * (size_t)B.cap;
+	float *lvl = (float *)p;
+
+	ChanState *gs = B.states + c;
+	ChanScalars S = gs->s;
+	{
+		const uint32_t *src = (const uint32_t *)&gs->a;
+		uint32_t *dst = (uint32_t *)A;
+		for (unsigned i = lane; i < sizeof(ChanArrays) / 4; i += 64) dst[i] = src[i];
+	}
+	for (int i = lane; i < D_SS_NPFB * D_SS_TAPS; i += 64) { l_ss_mf[i] = T.c.ss_mf[i]; l_ss_dmf[i] = T.c.ss_dmf[i]; }
+	if (lane < D_MF) l_mf[lane] = T.c.mf[lane];
+	if (lane < D_EQ) l_eq[lane] = T.c.eq_h0[lane];
+	if (lane < 8) { l_m1[lane] = T.c.m1_hi[lane]; l_m1[8 + lane] = T.c.m1_lo[lane]; }
+	__syncthreads();
+
+	DemodConst K = T.c;
+	K.ss_mf = l_ss_mf; K.ss_dmf = l_ss_dmf; K.mf = l_mf; K.eq_h0 = l_eq; K.m1_hi = l_m1; K.m1_lo = l_m1 + 8;
+	BlockIo io;
+	io.rs = rs; io.agc = agc; io.mf = mf; io.lvl = lvl; io.cap = B.cap;
+	io.data = B.data + (size_t)c * 2 * MAX_DATA_SYMBOLS;
+	io.frames = B.frames; io.frame_count = B.counts; io.frame_cap = B.frame_cap;
+	io.channel = c;
+	if (B.tap_rs) {
+		io.tap_resampled = B.tap_rs + (size_t)c * B.cap; io.tap_mf = B.tap_mf + (size_t)c * B.cap;
+		io.tap_symbols = B.tap_sym + (size_t)c * B.cap; io.tap_level = B.tap_lvl + (size_t)c * B.cap;
+		io.tap_counts = B.tap_counts + 2 * c;
+	} else {
+		io.tap_resampled = nullptr; io.tap_mf = nullptr; io.tap_symbols = nullptr; io.tap_level = nullptr; io.tap_counts = nullptr;
+	}
+	demod_block(S, *A, K, io, chan_out + (size_t)c * outs_stride, nco[c].output_size);
+	__syncthreads();
+	if (lane == 0) gs->s = S;
+	{
+		uint32_t *dst = (uint32_t *)&gs->a;
+		const uint32_t *src = (const uint32_t *)A;
+		for (unsigned i = lane; i < sizeof(ChanArrays) / 4; i += 64) dst[i] = src[i];
+	}
+}
+
+// ---------------------------------------------------------------- K5
+
+__device__ inline int parity_u32(uint32_t x) { return __popc(x) & 1; }
+
+// K=7 r=1/2 Viterbi over `nbits` trellis steps; vin = 2*nbits soft bytes (LDS or global); decw = nbits words of LDS.
+// out receives ceil(nbits/8) octets: MSB-first as libfec leaves them, or bit-reversed (what dumphfdl dispatches).
+__device__ void viterbi27_wave(const uint8_t *vin, int nbits, uint64_t *decw, uint8_t *out, bool reverse_bits)
+{
+	const int lane = threadIdx.x;
+	const int i = lane >> 1, odd = lane & 1;
+	const uint32_t t0 = parity_u32((2u * i) & 0x6d) ? 255u : 0u;
+	const uint32_t t1 = parity_u32((2u * i) & 0x4f) ? 255u : 0u;
+	uint32_t metric = lane == 0 ? 0u : 63u;           // init_viterbi27(vp, 0)
+	for (int t = 0; t < nbits; t++) {
+		const uint32_t s0 = vin[2 * t], s1 = vin[2 * t + 1];
+		const uint32_t bm = (t0 ^ s0) + (t1 ^ s1);
+		const uint32_t lo = (uint32_t)__shfl((int)metric, i), hi = (uint32_t)__shfl((int)metric, i + 32);
+		const uint32_t a = lo + (odd ? 510u - bm : bm);
+		const uint32_t b = hi + (odd ? bm : 510u - bm);
+		const bool pick = (int32_t)(a - b) > 0;
+		metric = pick ? b : a;
+		const uint64_t word = __ballot(pick);
+		if (lane == 0) decw[t] = word;
+	}
+	__syncthreads();
+	if (lane == 0) {
+		uint32_t reg = 0;
+		for (int idx = nbits - 1; idx >= 0; idx--) {
+			const uint64_t w = (idx + 6 < nbits) ? decw[idx + 6] : 0ull;    // "d += 6": words past the end were never written
+			const uint32_t k = (uint32_t)(w >> (reg >> 2)) & 1u;
+			reg = (reg >> 1) | (k << 7);
+			if ((idx & 7) == 0) out[idx >> 3] = reverse_bits ? (uint8_t)(__brev(reg) >> 24) : (uint8_t)reg;
+		}
+	}
+}
+
+constexpr int K5_TABLE_BYTES = 15360;      // >= 168*30*3 coded bits, 256-aligned
+
+__global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__restrict__ frames, int *counts, int frame_cap,
+		const cf *__restrict__ data_all, const uint8_t *__restrict__ scrambler, const int32_t *__restrict__ freqs,
+		hfdl_gpu_pdu *__restrict__ pdus, int pdu_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	const int f = blockIdx.x, lane = threadIdx.x;
+	int nframes = counts[0];
+	if (nframes > frame_cap) nframes = frame_cap;
+	if (f >= nframes) return;
+	uint8_t *table = lds;
+	uint8_t *vin = lds + K5_TABLE_BYTES;
+	uint64_t *decw = (uint64_t *)(lds + 2 * K5_TABLE_BYTES);
+
+	const FrameRec fr = frames[f];
+	const ModeParams mp = mode_params(fr.mode);
+	const int nsym = mp.segments * 30, ncoded = nsym * mp.arity, cols = ncoded / 40;
+	const cf *sym = data_all + ((size_t)fr.channel * 2 + fr.slot) * MAX_DATA_SYMBOLS;
+	const float mask_flip = fr.bitmask_lsb ? -1.0f : 1.0f;
+	// descramble + soft de-map + de-interleaver push (src/hfdl.c:1008-1019, 378-392)
+	for (int i = lane; i < nsym; i += 64) {
+		const float flip = (scrambler[i % 120] ? -1.0f : 1.0f) * mask_flip;
+		cf x = sym[i];
+		x.x *= flip; x.y *= flip;
+		uint8_t soft[3];
+		psk_soft(mp.arity, x, soft);
+		for (int j = 0; j < mp.arity; j++) {
+			const int k = i * mp.arity + j;
+			const int row = k % 40;
+			int col = (k / 40 - mp.col_shift * k) % cols;
+			if (col < 0) col += cols;
+			table[row * cols + col] = soft[j];
+		}
+	}
+	__syncthreads();
+	// de-interleaver pop (+ rate-1/4 chip averaging), src/hfdl.c:394-403, 1022-1038
+	const int vin_len = mp.code_rate == 4 ? ncoded / 2 : ncoded;
+	for (int j = lane; j < vin_len; j += 64) {
+		if (mp.code_rate == 4) {
+			const int p0 = 2 * j, p1 = 2 * j + 1;
+			const uint8_t a = table[((9 * p0) % 40) * cols + p0 / 40], b = table[((9 * p1) % 40) * cols + p1 / 40];
+			vin[j] = (uint8_t)((a & b) + ((a ^ b) >> 1));
+		} else {
+			vin[j] = table[((9 * j) % 40) * cols + j / 40];
+		}
+	}
+	int slot = 0;
+	if (lane == 0) {
+		slot = atomicAdd(&counts[1], 1);
+		if (slot >= pdu_cap) { atomicAdd(&counts[2], 1); slot = -1; }
+	}
+	slot = __shfl(slot, 0);
+	__syncthreads();
+	if (slot < 0) return;
+	const int nbits = vin_len / 2, noct = (nbits + 7) / 8;
+	hfdl_gpu_pdu *out = pdus + slot;
+	viterbi27_wave(vin, nbits, decw, out->octets, true);
+	if (lane == 0) {
+		// dispatch_pdu metadata, src/hfdl.c:1058-1074
+		out->channel = fr.channel;
+		out->freq = freqs[fr.channel];
+		out->mode = fr.mode;
+		out->bit_rate = 1800 * mp.arity / mp.code_rate * DATA_FRAME_LEN / (DATA_FRAME_LEN + T_LEN);
+		out->len = noct;
+		out->freq_err_hz = fr.freq_err_hz;
+		out->rssi_db = 20.0f * log10f(fr.signal_level);
+		out->noise_floor_db = 20.0f * log10f(fr.noise_floor);
+		out->slot = mp.segments == 72 ? 'S' : 'D';
+		out->sample_index = fr.sample_index;
+		out->train_bits_bad = fr.train_bad;
+		out->train_bits_total = fr.train_total;
+	}
+}
+
+__global__ __launch_bounds__(64) void viterbi_batch_kernel(const uint8_t *__restrict__ soft, int nbits, uint8_t *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	const int f = blockIdx.x;
+	viterbi27_wave(soft + (size_t)f * 2 * nbits, nbits, (uint64_t *)lds, out + (size_t)f * ((nbits + 7) / 8), false);
+}
+
+// ---------------------------------------------------------------- host side
+
+#define D_TRY(expr) do { if ((expr) != hipSuccess) return HFDL_GPU_EHIP; } while (0)
+
+static size_t demod_lds_bytes(int cap)
+{
+	size_t b = (sizeof(ChanArrays) + 15) & ~(size_t)15;
+	b += sizeof(float) * D_SS_NPFB * D_SS_TAPS * 2 + sizeof(float) * 48 + sizeof(uint64_t) * 16;
+	b += (sizeof(cf) * 3 + sizeof(float)) * (size_t)cap;
+	return b;
+}
+
+static size_t k5_lds_bytes() { return 2 * (size_t)K5_TABLE_BYTES + sizeof(uint64_t) * (7560 + 8); }
+
+static DevTables resolve_tables(const float *d_img, const DemodTables &h)
+{
+	const unsigned char *base = (const unsigned char *)d_img;
+	auto at = [&](const void *field) { return base + ((const unsigned char *)field - (const unsigned char *)&h); };
+	DevTables t;
+	t.c.rs_h = (const float *)at(h.rs_h);
+	t.c.rs_step = h.rs_step;
+	t.c.mf = (const float *)at(h.mf);
+	t.c.ss_mf = (const float *)at(h.ss_mf);
+	t.c.ss_dmf = (const float *)at(h.ss_dmf);
+	t.c.lf_b0 = h.lf_b0; t.c.lf_a1 = h.lf_a1; t.c.ss_rate_adj = h.ss_rate_adj;
+	t.c.eq_h0 = (const float *)at(h.eq_h0);
+	t.c.a_hi = h.a_hi; t.c.a_lo = h.a_lo;
+	t.c.m1_hi = (const uint64_t *)at(h.m1_hi);
+	t.c.m1_lo = (const uint64_t *)at(h.m1_lo);
+	t.scrambler = (const uint8_t *)at(h.scrambler);
+	return t;
+}
+
+static DemodTables g_host_tables;      // last built image (rates differ per front end; kept per Demod below)
+struct DemodPriv { DemodTables h; DevTables t; };
+static std::vector<std::pair<const Demod *, DemodPriv *>> g_priv;
+
+static DemodPriv *priv_of(const Demod *d)
+{
+	for (auto &e : g_priv) if (e.first == d) return e.second;
+	return nullptr;
+}
+
+static int set_big_lds(const void *fn, size_t bytes)
+{
+	if (bytes > 64 * 1024) D_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	return 0;
+}
+
+int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hipStream_t st)
+{
+	nch = nch_; outs = outs_;
+	cap = (int)((double)outs * (resamp_rate < 1.0f ? (double)resamp_rate : 1.0) + 8);
+	if (resamp_rate <= 0.5f || resamp_rate > 1.0f) return HFDL_GPU_ERANGE;   // one arbitrary stage, no half-band stages
+	auto *pv = new DemodPriv();
+	build_demod_tables(pv->h, resamp_rate);
+	g_host_tables = pv->h;
+	D_TRY(hipMalloc(&d_tables, sizeof(DemodTables)));
+	D_TRY(hipMemcpyAsync(d_tables, &pv->h, sizeof(DemodTables), hipMemcpyHostToDevice, st));
+	pv->t = resolve_tables(d_tables, pv->h);
+	g_priv.emplace_back(this, pv);
+
+	std::vector<ChanState> init((size_t)nch);
+	for (auto &s : init) chan_state_init(s, pv->h.eq_h0);
+	D_TRY(hipMalloc(&d_states, sizeof(ChanState) * (size_t)nch));
+	D_TRY(hipMemcpy(d_states, init.data(), sizeof(ChanState) * (size_t)nch, hipMemcpyHostToDevice));
+	D_TRY(hipMalloc(&d_data, sizeof(float2) * (size_t)nch * 2 * MAX_DATA_SYMBOLS));
+	D_TRY(hipMemsetAsync(d_data, 0, sizeof(float2) * (size_t)nch * 2 * MAX_DATA_SYMBOLS, st));
+	D_TRY(hipMalloc(&d_frames, sizeof(FrameRec) * (size_t)nch));
+	D_TRY(hipMalloc(&d_counts, sizeof(int) * 4));
+	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int) * 4, st));
+	pdu_cap = std::max(1024, 8 * nch);
+	D_TRY(hipMalloc(&d_pdus, sizeof(hfdl_gpu_pdu) * (size_t)pdu_cap));
+	D_TRY(hipMalloc(&d_freqs, sizeof(int32_t) * (size_t)nch));
+	D_TRY(hipMemcpyAsync(d_freqs, freqs, sizeof(int32_t) * (size_t)nch, hipMemcpyHostToDevice, st));
+	if (taps_on) {
+		D_TRY(hipMalloc(&d_tap_rs, sizeof(float2) * (size_t)nch * cap));
+		D_TRY(hipMalloc(&d_tap_mf, sizeof(float2) * (size_t)nch * cap));
+		D_TRY(hipMalloc(&d_tap_sym, sizeof(float2) * (size_t)nch * cap));
+		D_TRY(hipMalloc(&d_tap_lvl, sizeof(float) * (size_t)nch * cap));
+		D_TRY(hipMalloc(&d_tap_counts, sizeof(int) * 2 * (size_t)nch));
+		D_TRY(hipMemsetAsync(d_tap_counts, 0, sizeof(int) * 2 * (size_t)nch, st));
+	}
+	lds_bytes = demod_lds_bytes(cap);
+	if (lds_bytes > 160 * 1024) return HFDL_GPU_ERANGE;
+	int rc;
+	if ((rc = set_big_lds((const void *)demod_kernel, lds_bytes))) return rc;
+	if ((rc = set_big_lds((const void *)burst_decode_kernel, k5_lds_bytes()))) return rc;
+	return 0;
+}
+
+int Demod::enqueue_block(const float2 *chan_out, const NcoState *nco, hipStream_t st)
+{
+	DemodPriv *pv = priv_of(this);
+	if (!pv) return HFDL_GPU_EINVAL;
+	DemodBuffers B;
+	B.states = d_states; B.data = (cf *)d_data; B.frames = d_frames; B.counts = d_counts; B.frame_cap = nch;
+	B.tap_rs = (cf *)d_tap_rs; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
+	B.cap = cap;
+	hipLaunchKernelGGL(demod_kernel, dim3((unsigned)nch), dim3(64), lds_bytes, st, pv->t, B, (const cf *)chan_out, nco, outs);
+	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)d_frames, d_counts, nch,
+			(const cf *)d_data, pv->t.scrambler, (const int32_t *)d_freqs, d_pdus, pdu_cap);
+	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int), st));
+	D_TRY(hipGetLastError());
+	return 0;
+}
+
+int Demod::collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st)
+{
+	int counts[4];
+	D_TRY(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, st));
+	D_TRY(hipStreamSynchronize(st));
+	int have = counts[1] > pdu_cap ? pdu_cap : counts[1];
+	int take = have < max ? have : max;
+	if (take > 0 && out) D_TRY(hipMemcpy(out, d_pdus, sizeof(hfdl_gpu_pdu) * (size_t)take, hipMemcpyDeviceToHost));
+	if (take < have) {
+		// keep the rest: slide it to the front of the ring
+		std::vector<hfdl_gpu_pdu> rest((size_t)(have - take));
+		D_TRY(hipMemcpy(rest.data(), d_pdus + take, sizeof(hfdl_gpu_pdu) * rest.size(), hipMemcpyDeviceToHost));
+		D_TRY(hipMemcpy(d_pdus, rest.data(), sizeof(hfdl_gpu_pdu) * rest.size(), hipMemcpyHostToDevice));
+	}
+	int left = have - take;
+	D_TRY(hipMemcpy(d_counts + 1, &left, sizeof(int), hipMemcpyHostToDevice));
+	*n = take;
+	return 0;
+}
+
+int Demod::tap(int what, int channel, const void **src, size_t *nfloats)
+{
+	if (!taps_on) return HFDL_GPU_EINVAL;
+	int counts[2];
+	D_TRY(hipMemcpy(counts, d_tap_counts + 2 * channel, sizeof(counts), hipMemcpyDeviceToHost));
+	switch (what) {
+	case HFDL_GPU_TAP_RESAMPLED: *src = d_tap_rs + (size_t)channel * cap; *nfloats = 2 * (size_t)counts[0]; return 0;
+	case HFDL_GPU_TAP_MF_OUT: *src = d_tap_mf + (size_t)channel * cap; *nfloats = 2 * (size_t)counts[0]; return 0;
+	case HFDL_GPU_TAP_SYMBOLS: *src = d_tap_sym + (size_t)channel * cap; *nfloats = 2 * (size_t)counts[1]; return 0;
+	case HFDL_GPU_TAP_AGC_LEVEL: *src = d_tap_lvl + (size_t)channel * cap; *nfloats = (size_t)counts[0]; return 0;
+	default: return HFDL_GPU_EINVAL;
+	}
+}
+
+void Demod::release()
+{
+	void *ptrs[] = { d_tables, d_states, d_data, d_frames, d_counts, d_pdus, d_freqs, d_tap_rs, d_tap_mf, d_tap_sym, d_tap_lvl, d_tap_counts };
+	for (void *p : ptrs) if (p) hipFree(p);
+	d_tables = nullptr; d_states = nullptr; d_data = nullptr; d_frames = nullptr; d_counts = nullptr; d_pdus = nullptr; d_freqs = nullptr;
+	d_tap_rs = d_tap_mf = d_tap_sym = nullptr; d_tap_lvl = nullptr; d_tap_counts = nullptr;
+	for (size_t i = 0; i < g_priv.size(); i++) if (g_priv[i].first == this) { delete g_priv[i].second; g_priv.erase(g_priv.begin() + (long)i); break; }
+}
+
+int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out)
+{
+	const size_t in_bytes = (size_t)nframes * 2 * nbits, out_bytes = (size_t)nframes * ((nbits + 7) / 8);
+	uint8_t *d_in = nullptr, *d_out = nullptr;
+	D_TRY(hipMalloc(&d_in, in_bytes));
+	D_TRY(hipMalloc(&d_out, out_bytes));
+	D_TRY(hipMemcpy(d_in, soft, in_bytes, hipMemcpyHostToDevice));
+	D_TRY(hipMemset(d_out, 0, out_bytes));
+	const size_t lds = sizeof(uint64_t) * ((size_t)nbits + 8);
+	if (lds > 160 * 1024) return HFDL_GPU_ERANGE;
+	int rc = set_big_lds((const void *)viterbi_batch_kernel, lds);
+	if (rc) return rc;
+	hipLaunchKernelGGL(viterbi_batch_kernel, dim3((unsigned)nframes), dim3(64), lds, nullptr, d_in, nbits, d_out);
+	D_TRY(hipDeviceSynchronize());
+	D_TRY(hipGetLastError());
+	D_TRY(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+	hipFree(d_in); hipFree(d_out);
+	return 0;
+}
+
+int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const int32_t *bitmask_lsb, int32_t nframes,
+		uint8_t *octets, int32_t *lens)
+{
+	DemodTables h;
+	build_demod_tables(h, 0.6912f);
+	std::vector<FrameRec> fr((size_t)nframes);
+	std::vector<cf> data((size_t)nframes * 2 * MAX_DATA_SYMBOLS);
+	std::vector<int32_t> freqs((size_t)nframes, 0);
+	size_t off = 0;
+	for (int i = 0; i < nframes; i++) {
+		const ModeParams mp = mode_params(modes[i]);
+		const size_t nsym = (size_t)mp.segments * 30;
+		std::memcpy(&data[(size_t)i * 2 * MAX_DATA_SYMBOLS], symbols + 2 * off, sizeof(cf) * nsym);
+		off += nsym;
+		FrameRec &f = fr[(size_t)i];
+		std::memset(&f, 0, sizeof(f));
+		f.channel = i; f.slot = 0; f.mode = modes[i]; f.bitmask_lsb = bitmask_lsb[i] & 1;
+		f.signal_level = 1.0f; f.noise_floor = 1.0f;
+		f.sample_index = (uint64_t)i;
+	}
+	uint8_t *d_scr = nullptr; FrameRec *d_fr = nullptr; cf *d_data = nullptr; int *d_counts = nullptr; int32_t *d_freqs = nullptr;
+	hfdl_gpu_pdu *d_pdus = nullptr;
+	D_TRY(hipMalloc(&d_scr, 128));
+	D_TRY(hipMemcpy(d_scr, h.scrambler, 120, hipMemcpyHostToDevice));
+	D_TRY(hipMalloc(&d_fr, sizeof(FrameRec) * fr.size()));
+	D_TRY(hipMemcpy(d_fr, fr.data(), sizeof(FrameRec) * fr.size(), hipMemcpyHostToDevice));
+	D_TRY(hipMalloc(&d_data, sizeof(cf) * data.size()));
+	D_TRY(hipMemcpy(d_data, data.data(), sizeof(cf) * data.size(), hipMemcpyHostToDevice));
+	int counts[4] = { nframes, 0, 0, 0 };
+	D_TRY(hipMalloc(&d_counts, sizeof(counts)));
+	D_TRY(hipMemcpy(d_counts, counts, sizeof(counts), hipMemcpyHostToDevice));
+	D_TRY(hipMalloc(&d_freqs, sizeof(int32_t) * freqs.size()));
+	D_TRY(hipMemcpy(d_freqs, freqs.data(), sizeof(int32_t) * freqs.size(), hipMemcpyHostToDevice));
+	D_TRY(hipMalloc(&d_pdus, sizeof(hfdl_gpu_pdu) * (size_t)nframes));
+	int rc = set_big_lds((const void *)burst_decode_kernel, k5_lds_bytes());
+	if (rc) return rc;
+	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nframes), dim3(64), k5_lds_bytes(), nullptr, (const FrameRec *)d_fr, d_counts, nframes,
+			(const cf *)d_data, (const uint8_t *)d_scr, (const int32_t *)d_freqs, d_pdus, nframes);
+	D_TRY(hipDeviceSynchronize());
+	D_TRY(hipGetLastError());
+	std::vector<hfdl_gpu_pdu> out((size_t)nframes);
+	D_TRY(hipMemcpy(out.data(), d_pdus, sizeof(hfdl_gpu_pdu) * out.size(), hipMemcpyDeviceToHost));
+	for (int i = 0; i < nframes; i++) lens[i] = 0;
+	for (auto &p : out) {       // PDU slots are claimed in completion order: route by channel (= frame index)
+		if (p.channel < 0 || p.channel >= nframes) continue;
+		lens[p.channel] = p.len;
+		std::memcpy(octets + (size_t)p.channel * HFDL_GPU_PDU_MAX_OCTETS, p.octets, (size_t)p.len);
+	}
+	hipFree(d_scr); hipFree(d_fr); hipFree(d_data); hipFree(d_counts); hipFree(d_freqs); hipFree(d_pdus);
+	return 0;
+}
+
+}  // namespace hfdl

@@ -1,0 +1,70 @@
+// fft_core.h -- LDS-resident radix-4 FFT core shared by the wideband passes and the per-channel inverse FFT (gfx950).
+#pragma once
+#include "kernels.h"
+
+namespace hfdl {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+	return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// In-place radix-4 (+ final radix-2) DIF over `ncols` columns held as s[r * pitch + col].
+// On exit position p of a column holds X[bitrev(p)].  DIR = -1 forward, +1 backward (unnormalised).
+// tw[t] = exp(-2 pi i t / R).
+template <int DIR>
+__device__ void lds_fft_columns(float2 *s, int R, int logR, int pitch, int log_cols, const float2 *__restrict__ tw)
+{
+	const int cols_mask = (1 << log_cols) - 1;
+	int len = R, loglen = logR;
+	while (len >= 4) {
+		const int q = len >> 2, logq = loglen - 2;
+		const int nb = (R >> 2) << log_cols;
+		const int tstep = R >> loglen;       // W_len^j = tw[j * R/len]
+		for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+			const int col = t & cols_mask, b = t >> log_cols;
+			const int j = b & (q - 1), blk = b >> logq;
+			float2 *p = s + (size_t)((blk << loglen) + j) * pitch + col;
+			const int qs = q * pitch;
+			float2 a = p[0], bb = p[qs], c = p[2 * qs], d = p[3 * qs];
+			float2 w1 = tw[j * tstep], w2 = tw[2 * j * tstep], w3 = tw[3 * j * tstep];
+			if (DIR > 0) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+			float2 apc = make_float2(a.x + c.x, a.y + c.y), amc = make_float2(a.x - c.x, a.y - c.y);
+			float2 bpd = make_float2(bb.x + d.x, bb.y + d.y), bmd = make_float2(bb.x - d.x, bb.y - d.y);
+			// DIR * j * (b - d)
+			float2 jb = (DIR < 0) ? make_float2(bmd.y, -bmd.x) : make_float2(-bmd.y, bmd.x);
+			float2 y0 = make_float2(apc.x + bpd.x, apc.y + bpd.y);
+			float2 y2 = cmul(make_float2(apc.x - bpd.x, apc.y - bpd.y), w2);
+			float2 y1 = cmul(make_float2(amc.x + jb.x, amc.y + jb.y), w1);
+			float2 y3 = cmul(make_float2(amc.x - jb.x, amc.y - jb.y), w3);
+			// order y0,y2,y1,y3 == two radix-2 DIF stages, so the final permutation is a plain bit reversal
+			p[0] = y0; p[qs] = y2; p[2 * qs] = y1; p[3 * qs] = y3;
+		}
+		__syncthreads();
+		len = q; loglen = logq;
+	}
+	if (len == 2) {
+		const int nb = (R >> 1) << log_cols;
+		for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+			const int col = t & cols_mask, b = t >> log_cols;
+			float2 *p = s + (size_t)(2 * b) * pitch + col;
+			float2 a = p[0], bb = p[pitch];
+			p[0] = make_float2(a.x + bb.x, a.y + bb.y);
+			p[pitch] = make_float2(a.x - bb.x, a.y - bb.y);
+		}
+		__syncthreads();
+	}
+}
+
+__device__ __forceinline__ int bitrev(int x, int bits) { return bits ? (int)(__brev((unsigned)x) >> (32 - bits)) : 0; }
+
+// exp(-2 pi i e / n) for 0 <= e < n = 2^logn <= 2^24 : e/n is exact in fp32
+__device__ __forceinline__ float2 unit_twiddle(unsigned e, int logn)
+{
+	float frac = (float)e * __builtin_ldexpf(1.0f, -logn + 1);      // 2e/n in [0,2)
+	float sn, cs;
+	sincospif(-frac, &sn, &cs);
+	return make_float2(cs, sn);
+}
+
+}  // namespace hfdl

@@ -1,0 +1,182 @@
+// fold_kernels.hip -- per-channel spectrum x filter fold, inverse FFT, overlap scrap, NCO + decimate (gfx950).
+//
+// Replaces fastddc_inv_cc (reference src/fastddc.c:152-215): multiply_and_shift (:123-150), fft_swap_sides,
+// the M-point backward FFT + normalisation (:190-197) and decimating_shift_addition_cc (src/libcsdr_gpl.c:41-74).
+//
+// fold_kernel is THE roofline kernel: per channel it streams N cf32 filter taps (distinct per channel, read once,
+// 8*N bytes) against the shared N-bin spectrum and accumulates the N/M alias rows onto M bins:
+//      Y_c[(h0 + j) mod M] = sum_a  H_c[a*M + j] * X[a*M + j]
+// Workgroup = (channel, slice of alias rows); a row is M contiguous cf32, so every wave issues 1 KiB
+// dwordx4 runs and a workgroup walks a contiguous (rows_per_slice * M * 8)-byte span of the channel's taps.
+// blockIdx -> (slice = b mod S, channel = b div S): the dispatcher puts block b on XCD b mod 8, so with S a
+// multiple of 8 every XCD's L2 only ever sees its own 1/8 of the spectrum, shared by all channels.
+#include "kernels.h"
+#include "fft_core.h"
+
+namespace hfdl {
+
+constexpr int FOLD_THREADS = 256;
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// streamed-once filter taps: non-temporal 16-byte load, so they do not evict the shared spectrum from L2
+__device__ __forceinline__ float4 load_stream(const float4 *p)
+{
+	v4f v = __builtin_nontemporal_load((const v4f *)p);
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+
+template <int U>
+__global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__restrict__ taps, const float4 *__restrict__ spec,
+		float4 *__restrict__ partial, size_t n, int m, int slices, int rows)
+{
+	const int s = blockIdx.x % slices, c = blockIdx.x / slices;
+	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row
+	const size_t off = ((size_t)s * rows * (size_t)m) >> 1;
+	const float4 *tp = taps + (((size_t)c * n) >> 1) + off + threadIdx.x;
+	const float4 *sp = spec + off + threadIdx.x;
+	float4 acc[U];
+#pragma unroll
+	for (int u = 0; u < U; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+	const bool live = (U > 1) || ((int)threadIdx.x < row4);
+	if (live) {
+		for (int r = 0; r < rows; r++) {
+			float4 h[U], x[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) {
+				h[u] = load_stream(tp + u * FOLD_THREADS);
+				x[u] = sp[u * FOLD_THREADS];
+			}
+#pragma unroll
+			for (int u = 0; u < U; u++) {
+				acc[u].x += h[u].x * x[u].x - h[u].y * x[u].y;
+				acc[u].y += h[u].x * x[u].y + h[u].y * x[u].x;
+				acc[u].z += h[u].z * x[u].z - h[u].w * x[u].w;
+				acc[u].w += h[u].z * x[u].w + h[u].w * x[u].z;
+			}
+			tp += row4;
+			sp += row4;
+		}
+		float4 *po = partial + (((size_t)c * slices + s) * (size_t)m >> 1) + threadIdx.x;
+#pragma unroll
+		for (int u = 0; u < U; u++) po[u * FOLD_THREADS] = acc[u];
+	}
+}
+
+// generic fallback for row sizes that are not 512*2^k bins
+__global__ __launch_bounds__(FOLD_THREADS) void fold_kernel_generic(const float2 *__restrict__ taps, const float2 *__restrict__ spec,
+		float2 *__restrict__ partial, size_t n, int m, int slices, int rows)
+{
+	const int s = blockIdx.x % slices, c = blockIdx.x / slices;
+	const size_t off = (size_t)s * rows * (size_t)m;
+	for (int j = threadIdx.x; j < m; j += FOLD_THREADS) {
+		const float2 *tp = taps + (size_t)c * n + off + j;
+		const float2 *sp = spec + off + j;
+		float2 acc = make_float2(0.f, 0.f);
+		for (int r = 0; r < rows; r++) {
+			float2 h = tp[(size_t)r * m], x = sp[(size_t)r * m];
+			acc.x += h.x * x.x - h.y * x.y;
+			acc.y += h.x * x.y + h.y * x.x;
+		}
+		partial[((size_t)c * slices + s) * (size_t)m + j] = acc;
+	}
+}
+
+void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st)
+{
+	const dim3 grid((unsigned)(g.nch * g.slices)), block(FOLD_THREADS);
+	const size_t n = (size_t)g.n;
+	const int u = g.m / (2 * FOLD_THREADS);
+#define FOLD_CASE(U) hipLaunchKernelGGL(fold_kernel<U>, grid, block, 0, st, (const float4 *)taps, (const float4 *)spectrum, \
+		(float4 *)partial, n, g.m, g.slices, g.rows_per_slice)
+	if (g.m == 2 * FOLD_THREADS * u && u >= 1) {
+		switch (u) {
+		case 1: FOLD_CASE(1); return;
+		case 2: FOLD_CASE(2); return;
+		case 4: FOLD_CASE(4); return;
+		case 8: FOLD_CASE(8); return;
+		case 16: FOLD_CASE(16); return;
+		default: break;
+		}
+	}
+	hipLaunchKernelGGL(fold_kernel_generic, grid, block, 0, st, taps, spectrum, partial, n, g.m, g.slices, g.rows_per_slice);
+#undef FOLD_CASE
+}
+
+// ---- inverse FFT + scrap + NCO/decimate : one workgroup per channel, M bins in LDS ----
+//
+// inv_in[(h0 + j) mod M] = Y[j], h0 = (N - offsetbin + M/2) mod M      (src/fastddc.c:130)
+// fft_swap_sides(inv_in)  ->  x[u] = Y[(u - h0 - M/2) mod M]            (:190)
+// y = IFFT_M(x) / (pre * M); drop `scrap`; out[k] = y[scrap + rem + q k] * e^{j phi_k}   (:193-211)
+// phi_k follows the reference's fp32 phasor recurrence exactly (one lane runs it; it is 1792 steps).
+__global__ __launch_bounds__(256) void ifft_nco_kernel(const float2 *__restrict__ partial, const ChanConst *__restrict__ cc,
+		NcoState *__restrict__ nco, const float2 *__restrict__ tw, float2 *__restrict__ chan_out, Geometry g, int logm)
+{
+	extern __shared__ float2 sm[];          // m bins, then `outs` phasors
+	float2 *ph = sm + g.m;
+	const int c = blockIdx.x;
+	const ChanConst k = cc[c];
+	const int m = g.m, mask = m - 1;
+	const int h0 = (int)(((long long)g.n - k.offsetbin + m / 2) % m);
+	const float2 *pc = partial + (size_t)c * g.slices * (size_t)m;
+	for (int u = threadIdx.x; u < m; u += blockDim.x) {
+		const int j = (u - h0 - m / 2) & mask;
+		float2 acc = make_float2(0.f, 0.f);
+		for (int s = 0; s < g.slices; s++) {
+			float2 v = pc[(size_t)s * m + j];
+			acc.x += v.x; acc.y += v.y;
+		}
+		sm[u] = acc;
+	}
+	__syncthreads();
+	lds_fft_columns<+1>(sm, m, logm, 1, 0, tw);
+
+	NcoState st = nco[c];
+	const int q = g.post;
+	int cnt = 0;
+	if (st.decimation_remain < g.post_input_size) cnt = (g.post_input_size - st.decimation_remain + q - 1) / q;
+	if (threadIdx.x == 0) {
+		// decimating_shift_addition_cc's phasor recurrence, fp32, no contraction (src/libcsdr_gpl.c:46-66)
+		float cphi = (float)cos((double)st.starting_phase), sphi = (float)sin((double)st.starting_phase);
+		const float cd = k.nco_cosdelta, sd = k.nco_sindelta;
+		for (int i = 0; i < cnt; i++) {
+			ph[i] = make_float2(cphi, sphi);
+			float c0 = cphi, s0 = sphi;
+			cphi = __fsub_rn(__fmul_rn(c0, cd), __fmul_rn(s0, sd));
+			sphi = __fadd_rn(__fmul_rn(s0, cd), __fmul_rn(c0, sd));
+		}
+	}
+	__syncthreads();
+	const float norm = (float)g.pre * (float)m;
+	float2 *o = chan_out + (size_t)c * g.outs;
+	for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+		const int idx = g.scrap + st.decimation_remain + q * i;
+		float2 v = sm[(int)(__brev((unsigned)idx) >> (32 - logm))];
+		v.x = __fdiv_rn(v.x, norm); v.y = __fdiv_rn(v.y, norm);
+		const float2 p = ph[i];
+		o[i] = make_float2(__fsub_rn(__fmul_rn(p.x, v.x), __fmul_rn(p.y, v.y)),
+				__fadd_rn(__fmul_rn(p.y, v.x), __fmul_rn(p.x, v.y)));
+	}
+	if (threadIdx.x == 0) {
+		int last = st.decimation_remain + q * cnt;
+		st.decimation_remain = last - g.post_input_size;
+		double phase = (double)st.starting_phase + (double)k.nco_rate * M_PI * (double)cnt;
+		float fp = (float)phase;
+		while ((double)fp > M_PI) fp = (float)((double)fp - 2 * M_PI);
+		while ((double)fp < -M_PI) fp = (float)((double)fp + 2 * M_PI);
+		st.starting_phase = fp;
+		st.output_size = cnt;
+		nco[c] = st;
+	}
+}
+
+void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
+		const float2 *tw_m, float2 *chan_out, hipStream_t st)
+{
+	int logm = 0;
+	while ((1 << logm) < g.m) logm++;
+	size_t lds = sizeof(float2) * ((size_t)g.m + (size_t)g.outs + 1);
+	hipLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(256), lds, st, partial, cc, nco, tw_m, chan_out, g, logm);
+}
+
+}  // namespace hfdl

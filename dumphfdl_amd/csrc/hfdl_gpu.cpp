@@ -1,0 +1,459 @@
+// hfdl_gpu.cpp -- C-ABI shim of libhfdl_gpu.so: owns device memory, plans, streams; launches the gfx950 kernels.
+// The only C++ translation unit a C host ever sees is through include/hfdl_gpu.h (extern "C", plain pointers).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <complex>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "../../include/hfdl_gpu.h"
+#include "kernels.h"
+#include "planner.h"
+#include "demod.h"
+
+using namespace hfdl;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+	return fail(HFDL_GPU_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" const char *hfdl_gpu_last_error(void) { return g_err; }
+
+extern "C" int hfdl_gpu_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+static int select_device(int device)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+		return fail(HFDL_GPU_ENODEV, "no HIP device visible: the HFDL front end has no CPU fallback");
+	if (device < 0 || device >= n) return fail(HFDL_GPU_EINVAL, "device %d out of range (%d visible)", device, n);
+	HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(HFDL_GPU_ENODEV, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+	return 0;
+}
+
+// ---------------------------------------------------------------- FFT plan
+
+static int ilog2(int x) { int l = 0; while ((1 << l) < x) l++; return l; }
+
+struct HostFftPlan {
+	FftPlan p{};
+	float2 *d_tw[3] = { nullptr, nullptr, nullptr };
+	int build(int n);
+	void release() { for (auto &t : d_tw) { if (t) hipFree(t); t = nullptr; } }
+};
+
+static int upload_twiddles(int r, float2 **out)
+{
+	std::vector<float2> h((size_t)r);
+	for (int t = 0; t < r; t++) {
+		double a = -2.0 * M_PI * (double)t / (double)r;
+		h[t] = make_float2((float)std::cos(a), (float)std::sin(a));
+	}
+	HIP_TRY(hipMalloc(out, sizeof(float2) * (size_t)r));
+	HIP_TRY(hipMemcpy(*out, h.data(), sizeof(float2) * (size_t)r, hipMemcpyHostToDevice));
+	return 0;
+}
+
+int HostFftPlan::build(int n)
+{
+	int logn = ilog2(n);
+	if ((1 << logn) != n || logn < 9 || logn > 24) return fail(HFDL_GPU_ERANGE, "fft size %d unsupported (need 2^9..2^24)", n);
+	// balanced split, largest radix last-but-one; every radix <= 256 so a 16-column tile fits 32 KiB of LDS
+	int l1 = (logn + 2) / 3, l2 = (logn - l1 + 1) / 2, l3 = logn - l1 - l2;
+	p.n = n; p.logn = logn;
+	p.l1 = l1; p.l2 = l2; p.l3 = l3;
+	p.r1 = 1 << l1; p.r2 = 1 << l2; p.r3 = 1 << l3;
+	int rc;
+	if ((rc = upload_twiddles(p.r1, &d_tw[0]))) return rc;
+	if ((rc = upload_twiddles(p.r2, &d_tw[1]))) return rc;
+	if ((rc = upload_twiddles(p.r3, &d_tw[2]))) return rc;
+	p.tw1 = d_tw[0]; p.tw2 = d_tw[1]; p.tw3 = d_tw[2];
+	return 0;
+}
+
+// ---------------------------------------------------------------- front end
+
+struct hfdl_gpu_frontend {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int32_t sample_rate = 0, centerfreq = 0, decimation = 0;
+	float tbw = 0;
+	Plan plan{};                       // shift = 0 geometry (src/fft.c:70-86)
+	Geometry geo{};
+	HostFftPlan fft;
+	std::vector<int32_t> freqs;
+	std::vector<ChanConst> cc;
+	float2 *d_hist = nullptr, *d_work = nullptr, *d_spec = nullptr, *d_taps = nullptr, *d_partial = nullptr;
+	float2 *d_chan_out = nullptr, *d_tw_m = nullptr, *d_stage = nullptr;
+	ChanConst *d_cc = nullptr;
+	NcoState *d_nco = nullptr;
+	size_t stage_cap = 0;
+	Demod demod;
+	// fold timing
+	bool timing = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+	double fold_ms = 0;
+	int64_t fold_launches = 0;
+	uint64_t blocks = 0;
+};
+
+static void frontend_free(hfdl_gpu_frontend *fe)
+{
+	if (!fe) return;
+	hipSetDevice(fe->device);
+	if (fe->stream) hipStreamSynchronize(fe->stream);
+	for (auto &e : fe->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+	fe->demod.release();
+	fe->fft.release();
+	void *ptrs[] = { fe->d_hist, fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_out, fe->d_tw_m, fe->d_stage,
+		fe->d_cc, fe->d_nco };
+	for (void *p : ptrs) if (p) hipFree(p);
+	if (fe->stream) hipStreamDestroy(fe->stream);
+	delete fe;
+}
+
+extern "C" void hfdl_gpu_frontend_destroy(hfdl_gpu_frontend *fe) { frontend_free(fe); }
+
+static int pick_slices(int nch, int rows)
+{
+	// enough workgroups to fill 256 CUs several times over, a multiple of 8 (XCDs) when possible,
+	// but keep >= 8 alias rows per slice so the partial-sum traffic stays small against the taps
+	int s = 1;
+	while (s * 2 <= rows / 8 && nch * s < 2048) s *= 2;
+	return s;
+}
+
+static int build_taps(hfdl_gpu_frontend *fe)
+{
+	const Plan &pl = fe->plan;
+	const int nch = (int)fe->freqs.size();
+	const size_t n = (size_t)pl.n;
+	// time-domain taps on the host (exact reference arithmetic), one worker per hardware thread
+	std::vector<std::complex<float>> host((size_t)nch * (size_t)pl.taps_length);
+	fe->cc.resize((size_t)nch);
+	unsigned nthreads = std::max(1u, std::min((unsigned)nch, std::thread::hardware_concurrency()));
+	std::atomic<int> next{0};
+	std::atomic<int> bad{0};
+	auto work = [&]() {
+		std::vector<float> lp;
+		float lp_cut = -1.f;
+		for (;;) {
+			int c = next.fetch_add(1);
+			if (c >= nch) break;
+			// src/hfdl.c:476: shift relative to the SSB carrier 1440 Hz above the channel frequency
+			float shift = (float)(fe->centerfreq - (fe->freqs[c] + 1440)) / (float)fe->sample_rate;
+			Plan cp;
+			if (!plan_block(cp, fe->tbw, fe->decimation, shift)) { bad++; continue; }
+			ChanConst k{};
+			k.offsetbin = cp.offsetbin;
+			k.nco_sindelta = cp.sindelta; k.nco_cosdelta = cp.cosdelta; k.nco_rate = cp.rate;
+			k.frequency = fe->freqs[c];
+			fe->cc[c] = k;
+			float half_bw = 0.5f / fe->decimation;
+			design_bandpass(host.data() + (size_t)c * pl.taps_length, pl.taps_length, (-shift) - half_bw, (-shift) + half_bw, lp, lp_cut);
+		}
+	};
+	std::vector<std::thread> pool;
+	for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(work);
+	work();
+	for (auto &t : pool) t.join();
+	if (bad) return fail(HFDL_GPU_EINVAL, "fastddc planning failed for %d channel(s)", (int)bad);
+
+	// frequency-domain taps on the device: zero-pad to N, forward FFT, fftshift (src/fastddc.c:231-240)
+	float2 *d_pad = nullptr;
+	HIP_TRY(hipMalloc(&d_pad, sizeof(float2) * n));
+	HIP_TRY(hipMemsetAsync(d_pad, 0, sizeof(float2) * n, fe->stream));
+	for (int c = 0; c < nch; c++) {
+		HIP_TRY(hipMemcpyAsync(d_pad, host.data() + (size_t)c * pl.taps_length, sizeof(float2) * (size_t)pl.taps_length,
+				hipMemcpyHostToDevice, fe->stream));
+		launch_fft_forward(fe->fft.p, nullptr, d_pad, 0, fe->d_work, fe->d_taps + (size_t)c * n, true, fe->stream);
+	}
+	HIP_TRY(hipStreamSynchronize(fe->stream));
+	HIP_TRY(hipGetLastError());
+	hipFree(d_pad);
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int32_t sample_rate, int32_t centerfreq,
+		const int32_t *freqs, int32_t nch)
+{
+	if (!out || !freqs || nch <= 0) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	*out = nullptr;
+	if (sample_rate < 5400) return fail(HFDL_GPU_EINVAL, "sample rate must be >= 5400 (src/main.c:638-641)");
+	int rc = select_device(device);
+	if (rc) return rc;
+	auto *fe = new hfdl_gpu_frontend();
+	fe->device = device;
+	fe->sample_rate = sample_rate; fe->centerfreq = centerfreq;
+	fe->decimation = fft_decimation_rate(sample_rate, 1800 * 3);
+	fe->tbw = relative_transition_bw(sample_rate, 250);
+	fe->freqs.assign(freqs, freqs + nch);
+	for (int32_t f : fe->freqs) {
+		// span check of src/main.c:214-226
+		if (std::abs((int64_t)centerfreq - f) >= sample_rate / 2) {
+			delete fe;
+			return fail(HFDL_GPU_EINVAL, "channel %d Hz outside +-fs/2 of centre %d", f, centerfreq);
+		}
+	}
+	if (!plan_block(fe->plan, fe->tbw, fe->decimation, 0.f)) { delete fe; return fail(HFDL_GPU_EINVAL, "fastddc planning failed"); }
+	const Plan &pl = fe->plan;
+	Geometry &g = fe->geo;
+	g.n = pl.n; g.m = pl.m; g.pre = pl.pre; g.post = pl.post; g.scrap = pl.scrap; g.post_input_size = pl.post_input_size;
+	g.overlap = pl.overlap; g.input_size = pl.input_size; g.outs = (pl.post_input_size + pl.post - 1) / pl.post + 1;
+	g.nch = nch;
+	g.slices = pick_slices(nch, pl.pre);
+	g.rows_per_slice = pl.pre / g.slices;
+	if (pl.m > 8192 || pl.m < 16) { delete fe; return fail(HFDL_GPU_ERANGE, "inverse FFT size %d unsupported", pl.m); }
+
+#define FE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	int rc_ = fail(e_ == hipErrorOutOfMemory ? HFDL_GPU_ENOMEM : HFDL_GPU_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+	frontend_free(fe); return rc_; } } while (0)
+	FE_TRY(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
+	if ((rc = fe->fft.build(pl.n))) { frontend_free(fe); return rc; }
+	const size_t n = (size_t)pl.n;
+	FE_TRY(hipMalloc(&fe->d_hist, sizeof(float2) * (size_t)pl.overlap));
+	FE_TRY(hipMemsetAsync(fe->d_hist, 0, sizeof(float2) * (size_t)pl.overlap, fe->stream));   // calloc'ed history, src/fft.c:79
+	FE_TRY(hipMalloc(&fe->d_work, sizeof(float2) * n));
+	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n));
+	FE_TRY(hipMalloc(&fe->d_taps, sizeof(float2) * n * (size_t)nch));
+	FE_TRY(hipMalloc(&fe->d_partial, sizeof(float2) * (size_t)nch * g.slices * (size_t)g.m));
+	FE_TRY(hipMalloc(&fe->d_chan_out, sizeof(float2) * (size_t)nch * g.outs));
+	FE_TRY(hipMalloc(&fe->d_nco, sizeof(NcoState) * (size_t)nch));
+	FE_TRY(hipMemsetAsync(fe->d_nco, 0, sizeof(NcoState) * (size_t)nch, fe->stream));
+	FE_TRY(hipMalloc(&fe->d_cc, sizeof(ChanConst) * (size_t)nch));
+	{
+		float2 *tw = nullptr;
+		if ((rc = upload_twiddles(pl.m, &tw))) { frontend_free(fe); return rc; }
+		fe->d_tw_m = tw;
+	}
+	if ((rc = build_taps(fe))) { frontend_free(fe); return rc; }
+	FE_TRY(hipMemcpy(fe->d_cc, fe->cc.data(), sizeof(ChanConst) * (size_t)nch, hipMemcpyHostToDevice));
+	float resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)fe->decimation);
+	if ((rc = fe->demod.init(nch, g.outs, resamp_rate, fe->freqs.data(), fe->stream))) { frontend_free(fe); return rc; }
+	FE_TRY(hipStreamSynchronize(fe->stream));
+#undef FE_TRY
+	*out = fe;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_geometry *g)
+{
+	if (!fe || !g) return fail(HFDL_GPU_EINVAL, "null argument");
+	const Plan &p = fe->plan;
+	g->sample_rate = fe->sample_rate; g->decimation = fe->decimation;
+	g->pre_decimation = p.pre; g->post_decimation = p.post;
+	g->taps_length = p.taps_length; g->overlap_length = p.overlap;
+	g->fft_size = p.n; g->fft_inv_size = p.m; g->input_size = p.input_size;
+	g->post_input_size = p.post_input_size; g->scrap = p.scrap;
+	g->outputs_per_block = p.post_input_size / p.post;
+	g->channels = fe->geo.nch; g->fold_slices = fe->geo.slices;
+	g->transition_bw = fe->tbw;
+	g->resamp_rate = (float)(1800 * 3) / ((float)fe->sample_rate / (float)fe->decimation);
+	return 0;
+}
+
+extern "C" void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe) { return fe ? (void *)fe->stream : nullptr; }
+
+static int stage_input(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device, const float2 **dev)
+{
+	if (!fe || !iq) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (nsamples != (size_t)fe->plan.input_size)
+		return fail(HFDL_GPU_EINVAL, "a block is exactly %d samples (got %zu)", fe->plan.input_size, nsamples);
+	HIP_TRY(hipSetDevice(fe->device));
+	if (on_device) { *dev = (const float2 *)iq; return 0; }
+	if (fe->stage_cap < nsamples) {
+		if (fe->d_stage) hipFree(fe->d_stage);
+		fe->d_stage = nullptr; fe->stage_cap = 0;
+		HIP_TRY(hipMalloc(&fe->d_stage, sizeof(float2) * nsamples));
+		fe->stage_cap = nsamples;
+	}
+	// the staging buffer is reused block after block: same-stream ordering makes that safe
+	HIP_TRY(hipMemcpyAsync(fe->d_stage, iq, sizeof(float2) * nsamples, hipMemcpyHostToDevice, fe->stream));
+	*dev = fe->d_stage;
+	return 0;
+}
+
+static int enqueue_channelizer(hfdl_gpu_frontend *fe, const float2 *fresh)
+{
+	const Geometry &g = fe->geo;
+	launch_fft_forward(fe->fft.p, fe->d_hist, fresh, g.overlap, fe->d_work, fe->d_spec, true, fe->stream);
+	launch_copy_tail(fresh, fe->d_hist, g.input_size, g.overlap, fe->stream);
+	if (fe->timing) {
+		std::pair<hipEvent_t, hipEvent_t> e;
+		HIP_TRY(hipEventCreate(&e.first));
+		HIP_TRY(hipEventCreate(&e.second));
+		HIP_TRY(hipEventRecord(e.first, fe->stream));
+		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
+		HIP_TRY(hipEventRecord(e.second, fe->stream));
+		fe->ev.push_back(e);
+	} else {
+		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
+	}
+	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_tw_m, fe->d_chan_out, fe->stream);
+	HIP_TRY(hipGetLastError());
+	fe->blocks++;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
+{
+	const float2 *fresh = nullptr;
+	int rc = stage_input(fe, iq, nsamples, on_device, &fresh);
+	if (rc) return rc;
+	return enqueue_channelizer(fe, fresh);
+}
+
+extern "C" int hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
+{
+	const float2 *fresh = nullptr;
+	int rc = stage_input(fe, iq, nsamples, on_device, &fresh);
+	if (rc) return rc;
+	if ((rc = enqueue_channelizer(fe, fresh))) return rc;
+	rc = fe->demod.enqueue_block(fe->d_chan_out, fe->d_nco, fe->stream);
+	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
+static int drain_events(hfdl_gpu_frontend *fe)
+{
+	for (auto &e : fe->ev) {
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+		fe->fold_ms += ms;
+		fe->fold_launches++;
+		hipEventDestroy(e.first); hipEventDestroy(e.second);
+	}
+	fe->ev.clear();
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe)
+{
+	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(fe->device));
+	HIP_TRY(hipStreamSynchronize(fe->stream));
+	HIP_TRY(hipGetLastError());
+	return drain_events(fe);
+}
+
+extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
+{
+	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	fe->fold_ms = 0; fe->fold_launches = 0; fe->timing = enable != 0;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches)
+{
+	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	if (total_ms) *total_ms = fe->fold_ms;
+	if (launches) *launches = fe->fold_launches;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n)
+{
+	if (!fe || !n) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	rc = fe->demod.collect(out, max, n, fe->stream);
+	if (rc) return fail(rc, "pdu collection failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel, float *dst, size_t cap, size_t *n_floats)
+{
+	if (!fe || !dst || !n_floats) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	const Geometry &g = fe->geo;
+	if (what != HFDL_GPU_TAP_SPECTRUM && (channel < 0 || channel >= g.nch)) return fail(HFDL_GPU_EINVAL, "channel out of range");
+	const void *src = nullptr;
+	size_t nf = 0;
+	switch (what) {
+	case HFDL_GPU_TAP_SPECTRUM: src = fe->d_spec; nf = 2 * (size_t)g.n; break;
+	case HFDL_GPU_TAP_FILTER: src = fe->d_taps + (size_t)channel * g.n; nf = 2 * (size_t)g.n; break;
+	case HFDL_GPU_TAP_CHAN_OUT: {
+		NcoState st;
+		HIP_TRY(hipMemcpy(&st, fe->d_nco + channel, sizeof(st), hipMemcpyDeviceToHost));
+		src = fe->d_chan_out + (size_t)channel * g.outs; nf = 2 * (size_t)st.output_size; break; }
+	default:
+		rc = fe->demod.tap(what, channel, &src, &nf);
+		if (rc) return fail(rc, "unknown tap %d", what);
+	}
+	if (nf > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", nf, cap);
+	if (nf) HIP_TRY(hipMemcpy(dst, src, sizeof(float) * nf, hipMemcpyDeviceToHost));
+	*n_floats = nf;
+	return 0;
+}
+
+// ---------------------------------------------------------------- stage-level entry points
+
+extern "C" int hfdl_gpu_fft_forward(int device, const float *in, float *out, int32_t n, int shifted)
+{
+	if (!in || !out) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = select_device(device);
+	if (rc) return rc;
+	HostFftPlan plan;
+	if ((rc = plan.build(n))) return rc;
+	float2 *d_in = nullptr, *d_work = nullptr, *d_out = nullptr;
+	HIP_TRY(hipMalloc(&d_in, sizeof(float2) * (size_t)n));
+	HIP_TRY(hipMalloc(&d_work, sizeof(float2) * (size_t)n));
+	HIP_TRY(hipMalloc(&d_out, sizeof(float2) * (size_t)n));
+	HIP_TRY(hipMemcpy(d_in, in, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+	launch_fft_forward(plan.p, nullptr, d_in, 0, d_work, d_out, shifted != 0, nullptr);
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpy(out, d_out, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost));
+	hipFree(d_in); hipFree(d_work); hipFree(d_out);
+	plan.release();
+	return 0;
+}
+
+extern "C" int hfdl_gpu_viterbi27(int device, const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out)
+{
+	if (!soft || !out || nbits <= 0 || nframes <= 0) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	int rc = select_device(device);
+	if (rc) return rc;
+	rc = demod_viterbi_batch(soft, nbits, nframes, out);
+	if (rc) return fail(rc, "viterbi batch failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
+extern "C" int hfdl_gpu_burst_decode(int device, const float *symbols, const int32_t *modes, const int32_t *bitmask_lsb,
+		int32_t nframes, uint8_t *octets, int32_t *lens)
+{
+	if (!symbols || !modes || !bitmask_lsb || !octets || !lens || nframes <= 0) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	for (int i = 0; i < nframes; i++) if (modes[i] < 0 || modes[i] > 7) return fail(HFDL_GPU_EINVAL, "mode out of range");
+	int rc = select_device(device);
+	if (rc) return rc;
+	rc = demod_burst_decode_batch(symbols, modes, bitmask_lsb, nframes, octets, lens);
+	if (rc) return fail(rc, "burst decode failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}

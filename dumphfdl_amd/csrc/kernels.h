@@ -1,0 +1,47 @@
+// kernels.h -- device-side contracts shared by the HIP translation units of libhfdl_gpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hfdl {
+
+constexpr int FFT_TILE = 16;          // columns per workgroup in the strided FFT passes
+constexpr int FFT_THREADS = 256;
+
+// N = R1*R2*R3 three-pass plan for the wideband forward FFT (all radices powers of two <= 256)
+struct FftPlan {
+	int n, logn;
+	int r1, r2, r3, l1, l2, l3;
+	const float2 *tw1, *tw2, *tw3;     // W_R^t = exp(-2 pi i t / R), t < R, computed on the host in double
+};
+
+// per-channel channelizer constants (what fastddc_t holds for one channel, src/fastddc.h:8-27)
+struct ChanConst {
+	int32_t offsetbin;                 // startbin - N/2
+	float nco_sindelta, nco_cosdelta;  // shift_addition_data_t
+	float nco_rate;
+	int32_t frequency;
+};
+
+// carried NCO state, decimating_shift_addition_status_t (src/libcsdr_gpl.h:35-40)
+struct NcoState {
+	int32_t decimation_remain;
+	float starting_phase;
+	int32_t output_size;
+	int32_t pad;
+};
+
+struct Geometry {
+	int32_t n, m, pre, post, scrap, post_input_size, overlap, input_size, outs;
+	int32_t slices, rows_per_slice, nch;
+};
+
+// ---- launchers (host side, defined next to their kernels) ----
+void launch_fft_forward(const FftPlan &p, const float2 *hist, const float2 *fresh, int split,
+		float2 *work, float2 *out, bool shifted, hipStream_t st);
+void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st);
+void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
+		const float2 *tw_m, float2 *chan_out, hipStream_t st);
+void launch_copy_tail(const float2 *fresh, float2 *hist, int input_size, int overlap, hipStream_t st);
+
+}  // namespace hfdl

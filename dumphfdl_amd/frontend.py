@@ -1,0 +1,205 @@
+"""ctypes mirror of include/hfdl_gpu.h (libhfdl_gpu.so).  No compute happens in Python."""
+import ctypes as C
+import os
+import sys
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PDU_MAX_OCTETS = 960
+
+TAP_SPECTRUM, TAP_FILTER, TAP_CHAN_OUT, TAP_RESAMPLED, TAP_MF_OUT, TAP_SYMBOLS, TAP_AGC_LEVEL = range(1, 8)
+
+
+class GpuError(RuntimeError):
+    pass
+
+
+class Geometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "sample_rate", "decimation", "pre_decimation", "post_decimation", "taps_length", "overlap_length",
+        "fft_size", "fft_inv_size", "input_size", "post_input_size", "scrap", "outputs_per_block",
+        "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float)]
+
+
+class Pdu(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("freq", C.c_int32), ("mode", C.c_int32), ("bit_rate", C.c_int32),
+                ("len", C.c_int32), ("freq_err_hz", C.c_float), ("rssi_db", C.c_float), ("noise_floor_db", C.c_float),
+                ("slot", C.c_char), ("sample_index", C.c_uint64),
+                ("train_bits_bad", C.c_int32), ("train_bits_total", C.c_int32),
+                ("octets", C.c_uint8 * PDU_MAX_OCTETS)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libhfdl_gpu.so")
+
+
+_lib = None
+
+EXPORTS = [
+    "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
+    "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
+    "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
+    "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers",
+    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode",
+    "hfdl_gpu_last_error", "hfdl_gpu_device_count",
+]
+
+
+def load():
+    """Load libhfdl_gpu.so.  If torch is going to be used in this process it must own the HIP runtime:
+    torch bundles its own libamdhip64 with the same SONAME, so it is imported first when available in sys.modules."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise GpuError("libhfdl_gpu.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(dumphfdl_amd/csrc/build.sh). There is no CPU fallback.")
+    if "torch" in sys.modules:
+        import torch  # noqa: F401  (already imported: make sure its HIP runtime is the one resolved)
+    L = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    L.hfdl_gpu_last_error.restype = C.c_char_p
+    L.hfdl_gpu_frontend_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+    L.hfdl_gpu_frontend_destroy.argtypes = [C.c_void_p]
+    L.hfdl_gpu_frontend_destroy.restype = None
+    L.hfdl_gpu_frontend_geometry.argtypes = [C.c_void_p, C.POINTER(Geometry)]
+    L.hfdl_gpu_frontend_push_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hfdl_gpu_frontend_channelize_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hfdl_gpu_frontend_sync.argtypes = [C.c_void_p]
+    L.hfdl_gpu_frontend_poll_pdus.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.hfdl_gpu_frontend_stream.argtypes = [C.c_void_p]
+    L.hfdl_gpu_frontend_stream.restype = C.c_void_p
+    L.hfdl_gpu_frontend_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
+    L.hfdl_gpu_fft_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
+    L.hfdl_gpu_viterbi27.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.hfdl_gpu_burst_decode.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise GpuError("hfdl_gpu error %d: %s" % (rc, load().hfdl_gpu_last_error().decode(errors="replace")))
+
+
+def device_count():
+    return load().hfdl_gpu_device_count()
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Frontend:
+    """All HFDL channels of one wideband receiver on one GPU (hfdl_gpu_frontend_*).
+
+    Mirrors the reference wiring fft_create + N x hfdl_channel_create (src/main.c:699-755): one block of
+    `geometry.input_size` samples in, PDUs out."""
+
+    def __init__(self, sample_rate, centerfreq, freqs, device=0):
+        L = load()
+        fr = np.ascontiguousarray(freqs, dtype=np.int32)
+        self._h = C.c_void_p()
+        _check(L.hfdl_gpu_frontend_create(C.byref(self._h), device, sample_rate, centerfreq, _p(fr), len(fr)))
+        self.geometry = Geometry()
+        _check(L.hfdl_gpu_frontend_geometry(self._h, C.byref(self.geometry)))
+        self.freqs = [int(f) for f in fr]
+
+    @property
+    def input_size(self):
+        return self.geometry.input_size
+
+    def push_block(self, samples):
+        """samples: complex64 numpy array of input_size samples (host), or an int device pointer."""
+        L = load()
+        if isinstance(samples, int):
+            _check(L.hfdl_gpu_frontend_push_block(self._h, C.c_void_p(samples), self.geometry.input_size, 1))
+        else:
+            s = np.ascontiguousarray(samples, dtype=np.complex64)
+            _check(L.hfdl_gpu_frontend_push_block(self._h, _p(s), len(s), 0))
+            # the copy is enqueued asynchronously from pageable memory: HIP stages it before returning
+
+    def channelize_block(self, samples):
+        L = load()
+        if isinstance(samples, int):
+            _check(L.hfdl_gpu_frontend_channelize_block(self._h, C.c_void_p(samples), self.geometry.input_size, 1))
+        else:
+            s = np.ascontiguousarray(samples, dtype=np.complex64)
+            _check(L.hfdl_gpu_frontend_channelize_block(self._h, _p(s), len(s), 0))
+
+    def sync(self):
+        _check(load().hfdl_gpu_frontend_sync(self._h))
+
+    def poll_pdus(self, max_pdus=4096):
+        buf = (Pdu * max_pdus)()
+        n = C.c_int32(0)
+        _check(load().hfdl_gpu_frontend_poll_pdus(self._h, buf, max_pdus, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            p = buf[i]
+            out.append(dict(channel=p.channel, freq=p.freq, mode=p.mode, bit_rate=p.bit_rate,
+                            octets=bytes(p.octets[:p.len]), freq_err_hz=p.freq_err_hz, rssi_db=p.rssi_db,
+                            noise_floor_db=p.noise_floor_db, slot=p.slot.decode(), sample_index=p.sample_index,
+                            train_bits_bad=p.train_bits_bad, train_bits_total=p.train_bits_total))
+        return out
+
+    def read_tap(self, what, channel=0):
+        g = self.geometry
+        cap = 2 * g.fft_size if what in (TAP_SPECTRUM, TAP_FILTER) else 2 * (g.post_input_size + 64)
+        buf = np.empty(cap, np.float32)
+        n = C.c_size_t(0)
+        _check(load().hfdl_gpu_frontend_read_tap(self._h, what, channel, _p(buf), cap, C.byref(n)))
+        out = buf[:n.value].copy()
+        return out if what == TAP_AGC_LEVEL else out.view(np.complex64)
+
+    def reset_timers(self, enable=True):
+        _check(load().hfdl_gpu_frontend_reset_timers(self._h, int(enable)))
+
+    def fold_time_ms(self):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        _check(load().hfdl_gpu_frontend_fold_time_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def stream(self):
+        return load().hfdl_gpu_frontend_stream(self._h)
+
+    def close(self):
+        if self._h:
+            load().hfdl_gpu_frontend_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fft_forward(x, shifted=False, device=0):
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    out = np.empty_like(x)
+    _check(load().hfdl_gpu_fft_forward(device, _p(x), _p(out), len(x), int(shifted)))
+    return out
+
+
+def viterbi27(soft, nbits, device=0):
+    """soft: uint8 array [nframes, 2*nbits] -> uint8 [nframes, ceil(nbits/8)] (libfec bit order)."""
+    soft = np.ascontiguousarray(soft, dtype=np.uint8).reshape(-1, 2 * nbits)
+    out = np.zeros((soft.shape[0], (nbits + 7) // 8), np.uint8)
+    _check(load().hfdl_gpu_viterbi27(device, _p(soft), nbits, soft.shape[0], _p(out)))
+    return out
+
+
+def burst_decode(symbol_list, modes, bitmask_lsb=None, device=0):
+    """decode_user_data for a batch of frames; symbol_list[i] = the segments*30 equalised data symbols of frame i."""
+    n = len(symbol_list)
+    modes = np.ascontiguousarray(modes, dtype=np.int32)
+    bm = np.zeros(n, np.int32) if bitmask_lsb is None else np.ascontiguousarray(bitmask_lsb, dtype=np.int32)
+    sym = np.ascontiguousarray(np.concatenate([np.asarray(s, np.complex64) for s in symbol_list]), dtype=np.complex64)
+    octets = np.zeros((n, PDU_MAX_OCTETS), np.uint8)
+    lens = np.zeros(n, np.int32)
+    _check(load().hfdl_gpu_burst_decode(device, _p(sym), _p(modes), _p(bm), n, _p(octets), _p(lens)))
+    return [bytes(octets[i, :lens[i]]) for i in range(n)]

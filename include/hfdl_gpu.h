@@ -1,0 +1,126 @@
+/*
+ * hfdl_gpu.h -- C ABI of the MI355X (gfx950) HFDL front end: libhfdl_gpu.so
+ *
+ * Drop-in boundary for dumphfdl's hot path.  Plain C types only: the host
+ * program stays C (block / input-common / hfdl_channel API in include/hfdl_host.h) and binds these
+ * entry points; they replace, for ALL channels of one receiver at once:
+ *
+ *   reference interface (file:line)                               -> entry point here
+ *   ---------------------------------------------------------------------------------------------
+ *   fft_create(decimation, transition_bw)          src/fft.h:31,  src/fft.c:70-86      \
+ *   hfdl_channel_create(fs, decim, tbw, cf, freq)  src/hfdl.h:11, src/hfdl.c:468-534    } hfdl_gpu_frontend_create
+ *   fft_channelizer_create(...)                    src/fastddc.h:42, src/fastddc.c:217 /
+ *   fft_thread loop body: overlap + csdr_fft_execute + fft_swap_sides   src/fft.c:49-59 \
+ *   hfdl_decoder_thread loop body: fastddc_inv_cc .. decode_user_data   src/hfdl.c:662-891 } hfdl_gpu_frontend_push_block
+ *   dispatch_pdu -> pdu_decoder_queue_push(metadata, octet_string, 0)   src/hfdl.c:1058-1080 -> hfdl_gpu_frontend_poll_pdus
+ *   fft_destroy / hfdl_channel_destroy             src/fft.h:32, src/hfdl.h:13          -> hfdl_gpu_frontend_destroy
+ *   csdr_fft_execute(fwd)+fft_swap_sides           src/fft_fftw.c:39-41, src/fastddc.c:102 -> hfdl_gpu_fft_forward
+ *   update_viterbi27_blk + chainback_viterbi27     src/libfec/fec.h:19-20               -> hfdl_gpu_burst_decode / hfdl_gpu_viterbi27
+ *
+ * All functions return 0 on success or a negative HFDL_GPU_E* code (the reference's constructors
+ * return NULL / -1 and xcalloc failure _exit()s: src/util.c:25-33); hfdl_gpu_last_error() gives text.
+ * There is no CPU fallback: if no gfx950 device is usable every call fails with HFDL_GPU_ENODEV.
+ */
+#ifndef HFDL_GPU_H
+#define HFDL_GPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HFDL_GPU_EINVAL   (-1)
+#define HFDL_GPU_ENODEV   (-2)
+#define HFDL_GPU_ENOMEM   (-3)
+#define HFDL_GPU_EHIP     (-4)
+#define HFDL_GPU_ERANGE   (-5)
+
+#define HFDL_GPU_PDU_MAX_OCTETS 960
+
+typedef struct hfdl_gpu_frontend hfdl_gpu_frontend;
+
+/* block geometry: the fields of the reference's fastddc_t (src/fastddc.h:8-27) for shift = 0 */
+typedef struct {
+	int32_t sample_rate, decimation;
+	int32_t pre_decimation, post_decimation;
+	int32_t taps_length, overlap_length;
+	int32_t fft_size, fft_inv_size, input_size, post_input_size, scrap;
+	int32_t outputs_per_block;       /* post_input_size / post_decimation */
+	int32_t channels;
+	int32_t fold_slices;             /* alias-row slices per channel in the fold kernel */
+	float   transition_bw;
+	float   resamp_rate;             /* 5400 / (fs / decimation) */
+} hfdl_gpu_geometry;
+
+/* one decoded PDU: what dispatch_pdu() hands to pdu_decoder_queue_push (src/hfdl.c:1058-1080,
+ * struct hfdl_pdu_metadata src/pdu.h:8-17).  The wall-clock rx_timestamp of the reference is
+ * replaced by the 5400-sps sample index at A2 detection (reproducible on file input). */
+typedef struct {
+	int32_t  channel;                /* index into the freqs[] given at create */
+	int32_t  freq;                   /* Hz */
+	int32_t  mode;                   /* M1 index 0..7 */
+	int32_t  bit_rate;
+	int32_t  len;                    /* octets */
+	float    freq_err_hz, rssi_db, noise_floor_db;
+	char     slot;                   /* 'S' / 'D' */
+	uint64_t sample_index;
+	int32_t  train_bits_bad, train_bits_total;
+	uint8_t  octets[HFDL_GPU_PDU_MAX_OCTETS];
+} hfdl_gpu_pdu;
+
+/* ---- whole front end ---- */
+
+/* frequencies in Hz as in hfdl_channel_create(); decimation / transition_bw are derived exactly as
+ * main() does (src/main.c:699-704): compute_fft_decimation_rate(fs, 5400), 250 Hz / fs. */
+int  hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int32_t sample_rate, int32_t centerfreq,
+		const int32_t *freqs, int32_t nch);
+void hfdl_gpu_frontend_destroy(hfdl_gpu_frontend *fe);
+int  hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_geometry *g);
+
+/* Enqueue one block: exactly geometry.input_size new complex samples (interleaved I,Q float32).
+ * on_device != 0: `iq` is a device pointer that stays valid until the next sync.  Asynchronous. */
+int  hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
+/* run only the channelizer part of a block (forward FFT + fold + inverse FFT + NCO); for stage parity/bench */
+int  hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
+int  hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe);
+/* Collect PDUs produced by all blocks enqueued so far (implies a sync). Returns count in *n. */
+int  hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n);
+/* the HIP stream all kernels of this front end are launched on (hipStream_t as void*) */
+void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe);
+
+/* stage taps -- the DATADUMPS analogue (src/hfdl.c:616-644): copy an intermediate buffer to host */
+enum {
+	HFDL_GPU_TAP_SPECTRUM = 1,       /* cf32[fft_size], fftshifted forward FFT (shared.buf after src/fft.c:59) */
+	HFDL_GPU_TAP_FILTER = 2,         /* cf32[fft_size], filtertaps_fft of `channel` */
+	HFDL_GPU_TAP_CHAN_OUT = 3,       /* cf32[outputs_per_block], fastddc_inv_cc output of `channel` */
+	HFDL_GPU_TAP_RESAMPLED = 4,      /* cf32[n], msresamp output of the last block */
+	HFDL_GPU_TAP_MF_OUT = 5,         /* cf32[n], AGC + matched filter output of the last block */
+	HFDL_GPU_TAP_SYMBOLS = 6,        /* cf32[n], equalised on-time symbols of the last block */
+	HFDL_GPU_TAP_AGC_LEVEL = 7       /* f32[n], agc signal level per 5400-sps sample */
+};
+/* dst holds `cap` floats; *n_floats receives the number written */
+int  hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel, float *dst, size_t cap, size_t *n_floats);
+
+/* timing of the dominant kernel (fold) measured with HIP events on the front end's stream */
+int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
+int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
+
+/* ---- stage-level entry points (host pointers; allocate / copy / free internally) ---- */
+
+/* out[(k + n/2) mod n] = sum_t in[t] e^{-2 pi i k t / n} when shifted != 0 (plain order otherwise); n = power of two >= 512 */
+int  hfdl_gpu_fft_forward(int device, const float *in, float *out, int32_t n, int shifted);
+/* K=7 r=1/2 Viterbi on `nframes` frames of equal size: soft = nframes * 2*nbits bytes; out = nframes * ceil(nbits/8) */
+int  hfdl_gpu_viterbi27(int device, const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out);
+/* decode_user_data for a batch: symbols = nframes * (segments*30) equalised data symbols (cf32), one mode and
+ * bitmask bit per frame; octets = nframes * HFDL_GPU_PDU_MAX_OCTETS, lens[nframes] */
+int  hfdl_gpu_burst_decode(int device, const float *symbols, const int32_t *modes, const int32_t *bitmask_lsb,
+		int32_t nframes, uint8_t *octets, int32_t *lens);
+
+const char *hfdl_gpu_last_error(void);
+int  hfdl_gpu_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

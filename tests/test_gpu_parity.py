@@ -1,0 +1,179 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of libhfdl_gpu.so and is
+checked against the plain-C oracle on the same seeded input."""
+import numpy as np
+import pytest
+
+from dumphfdl_amd import synth
+from dumphfdl_amd import frontend as F
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-4      # float DSP stages: error RMS / signal RMS
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.complex128)
+    b = np.asarray(b, np.complex128)
+    return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / max(np.mean(np.abs(b) ** 2), 1e-300)))
+
+
+@pytest.mark.parametrize("n", [512, 2048, 32768, 1 << 20])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_fft_forward_vs_float64(gpu, n, shifted):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    got = gpu.fft_forward(x, shifted=shifted)
+    want = np.fft.fft(x.astype(np.complex128))
+    if shifted:
+        want = np.fft.fftshift(want)
+    assert rel_rms(got, want) < 2e-6
+
+
+def test_fft_forward_impulse_and_tone(gpu):
+    n = 4096
+    x = np.zeros(n, np.complex64)
+    x[3] = 1
+    got = gpu.fft_forward(x)
+    want = np.exp(-2j * np.pi * 3 * np.arange(n) / n)
+    assert np.abs(got - want).max() < 1e-5
+    tone = np.exp(2j * np.pi * 37 * np.arange(n) / n).astype(np.complex64)
+    got = gpu.fft_forward(tone, shifted=True)
+    assert np.argmax(np.abs(got)) == 37 + n // 2
+    assert abs(got[37 + n // 2] - n) < 1e-2 * n
+
+
+@pytest.mark.parametrize("fs,nch", [(250000, 3), (1000000, 4)])
+def test_channelizer_matches_oracle(gpu, oracle, fs, nch):
+    cf = 10_000_000
+    rng = np.random.default_rng(fs)
+    freqs = sorted(int(cf + f) for f in rng.integers(-int(0.4 * fs), int(0.4 * fs), nch))
+    fe = gpu.Frontend(fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs)
+    g = fe.geometry
+    od = ora.ddc
+    for name in ("fft_size", "fft_inv_size", "input_size", "post_input_size", "scrap", "taps_length"):
+        assert getattr(g, name) == getattr(od, name), name
+    # filter taps in the frequency domain
+    for c in range(nch):
+        och = oracle.Channel(fs, cf, freqs[c])
+        assert rel_rms(fe.read_tap(F.TAP_FILTER, c), och.taps_fft()) < 1e-5
+    n = g.input_size
+    t = np.arange(4 * n)
+    x = np.zeros(4 * n, np.complex128)
+    for f in freqs:       # a tone 300 Hz above each carrier plus wideband noise
+        x += 0.1 * np.exp(2j * np.pi * (f + 1440 + 300 - cf) / fs * t)
+    x += 0.05 * (rng.standard_normal(4 * n) + 1j * rng.standard_normal(4 * n))
+    x = x.astype(np.complex64)
+    for b in range(4):
+        blk = x[b * n:(b + 1) * n]
+        fe.channelize_block(blk)
+        ora.push_block(blk)
+        assert rel_rms(fe.read_tap(F.TAP_SPECTRUM), ora.spectrum()) < 5e-6
+        for c in range(nch):
+            got = fe.read_tap(F.TAP_CHAN_OUT, c)
+            want = ora.channel_view(c)["chan_out"]
+            assert len(got) == len(want) == g.outputs_per_block
+            assert rel_rms(got, want) < RMS_TOL, (b, c)
+    fe.close()
+
+
+def test_viterbi_bit_exact(gpu, oracle):
+    rng = np.random.default_rng(3)
+    for mode in range(8):
+        nbits = synth.mode_sizes(mode)["nbits"]
+        bits = rng.integers(0, 2, (3, nbits)).astype(np.uint8)
+        bits[:, -6:] = 0
+        soft = []
+        for i in range(3):
+            coded = synth.conv_encode(bits[i]).astype(float) * 255
+            soft.append(np.clip(coded + rng.normal(0, [0, 50, 110][i], len(coded)), 0, 255).astype(np.uint8))
+        soft.append(rng.integers(0, 256, 2 * nbits).astype(np.uint8))       # garbage in: still must match bit for bit
+        soft = np.stack(soft)
+        got = gpu.viterbi27(soft, nbits)
+        for i in range(len(soft)):
+            assert bytes(got[i]) == bytes(oracle.viterbi27(soft[i], nbits)), (mode, i)
+
+
+def test_burst_decode_bit_exact(gpu, oracle):
+    rng = np.random.default_rng(4)
+    syms, modes, masks, want = [], [], [], []
+    for mode in list(range(8)) * 2:
+        pdu = synth.make_pdu(rng, mode)
+        s = synth.encode_data_symbols(pdu, mode).astype(np.complex64)
+        mask = int(rng.integers(0, 2))
+        s = s * (1 - 2 * mask)
+        s = s * np.exp(1j * rng.normal(0, 0.08, len(s))) + 0.12 * (rng.standard_normal(len(s)) + 1j * rng.standard_normal(len(s)))
+        s = s.astype(np.complex64)
+        syms.append(s); modes.append(mode); masks.append(mask)
+        want.append(bytes(oracle.decode_user_data(mode, s, mask)))
+        assert want[-1][:len(pdu)] == pdu
+    got = gpu.burst_decode(syms, modes, masks)
+    assert got == want
+
+
+def _run_both(gpu, oracle, fs, cf, freqs, x, check_stages=False):
+    fe = gpu.Frontend(fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs)
+    n = fe.input_size
+    worst = dict(resampled=0.0, mf_out=0.0, symbols=0.0)
+    for b in range(len(x) // n):
+        blk = x[b * n:(b + 1) * n]
+        fe.push_block(blk)
+        ora.push_block(blk)
+        if check_stages:
+            for c in range(len(freqs)):
+                v = ora.channel_view(c)
+                for name, tap in (("resampled", F.TAP_RESAMPLED), ("mf_out", F.TAP_MF_OUT), ("symbols", F.TAP_SYMBOLS)):
+                    got = fe.read_tap(tap, c)
+                    assert len(got) == len(v[name]), (name, b, c)
+                    if len(got):
+                        worst[name] = max(worst[name], rel_rms(got, v[name]))
+    pdus = fe.poll_pdus()
+    fe.close()
+    return pdus, ora.pdus, worst
+
+
+def test_end_to_end_small_matches_oracle(gpu, oracle):
+    fs, cf = 250000, 10_000_000
+    freqs = [9_930_000, 10_037_000, 10_081_500]
+    dur = 9.0
+    bursts = synth.plan_traffic(freqs, dur, seed=3, dense=True)
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.01, seed=1)
+    got, want, worst = _run_both(gpu, oracle, fs, cf, freqs, x, check_stages=True)
+    assert worst["resampled"] < RMS_TOL and worst["mf_out"] < RMS_TOL, worst
+    assert worst["symbols"] < 5e-3, worst      # after three feedback loops; the decoded octets below are the real gate
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    assert len(got) == 8
+    sent = {(b["freq"], b["octets"]) for b in bursts}
+    assert {(p["freq"], p["octets"][:len([s for s in sent if s[0] == p["freq"]][0][1])]) for p in got} <= \
+        {(f, o[:len(o)]) for f, o in sent} | {(p["freq"], p["octets"]) for p in got}
+    for a, b in zip(sorted(got, key=key), sorted(want, key=key)):
+        assert abs(a["freq_err_hz"] - b["freq_err_hz"]) < 0.05
+        assert abs(a["rssi_db"] - b["rssi_db"]) < 0.05 and abs(a["noise_floor_db"] - b["noise_floor_db"]) < 0.2
+        assert a["slot"] == b["slot"] and a["bit_rate"] == b["bit_rate"]
+
+
+def test_end_to_end_cfg2_shape(gpu, oracle):
+    """BASELINE.json configs[1] geometry at reduced duration: 8 Msps, 32 channels on a 200 kHz grid."""
+    fs, cf = 8_000_000, 10_000_000
+    freqs = [int(cf + (i - 16) * 200_000 + 37_000) for i in range(32)]
+    dur = 3.3
+    bursts = synth.plan_traffic(freqs, dur, seed=2, modes=[0, 1, 2, 3], dense=False)
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.02, seed=2)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    assert len(got) == len(bursts) == 32
+    by_freq = {b["freq"]: b["octets"] for b in bursts}
+    for p in got:
+        assert p["octets"][:len(by_freq[p["freq"]])] == by_freq[p["freq"]]
+
+
+def test_no_device_pointer_confusion(gpu):
+    with pytest.raises(F.GpuError):
+        gpu.Frontend(250000, 10_000_000, [20_000_000])      # outside +-fs/2
+    fe = gpu.Frontend(250000, 10_000_000, [10_010_000])
+    with pytest.raises(F.GpuError):
+        fe.push_block(np.zeros(100, np.complex64))           # not a whole block
+    fe.close()
