@@ -18,6 +18,10 @@ class Ddc(C.Structure):
         [(n, C.c_float) for n in ("pre_shift", "post_shift", "nco_sindelta", "nco_cosdelta", "nco_rate")]
 
 
+class Cf(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
 class NcoState(C.Structure):
     _fields_ = [("decimation_remain", C.c_int32), ("starting_phase", C.c_float), ("output_size", C.c_int32)]
 
@@ -86,7 +90,7 @@ def lib():
         L.orc_decode_user_data.restype = C.c_int32
         L.orc_deinterleave_maps.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.orc_scrambler_bits.argtypes = [C.c_void_p, C.c_int32]
-        L.orc_modem_demod_soft.argtypes = [C.c_int, C.c_float * 2, C.c_void_p]
+        L.orc_modem_demod_soft.argtypes = [C.c_int, Cf, C.c_void_p]
         L.orc_channel_create.restype = C.c_void_p
         L.orc_channel_create.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int]
         L.orc_channel_destroy.argtypes = [C.c_void_p]

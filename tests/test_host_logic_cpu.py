@@ -1,0 +1,181 @@
+"""CPU tests of the product's host-side logic: the C ABI exports, the planner / tap design in the shim, and the
+demodulator control logic (dumphfdl_amd/csrc/demod_core.h compiled for the host by tests/hostsim -- test harness only)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+
+from dumphfdl_amd import synth
+import dumphfdl_amd as hf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sim():
+    d = os.path.join(ROOT, "tests", "hostsim")
+    so = os.path.join(d, "libhostsim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so,
+                           os.path.join(d, "hostsim.cpp")])
+    H = C.CDLL(so)
+    H.sim_create.restype = C.c_void_p
+    H.sim_create.argtypes = [C.c_float, C.c_int]
+    H.sim_destroy.argtypes = [C.c_void_p]
+    H.sim_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    H.sim_taps.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    H.sim_plan.argtypes = [C.c_float, C.c_int, C.c_float, C.c_void_p]
+    H.sim_transition_bw.restype = C.c_float
+    H.sim_bandpass.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+    H.sim_psk_soft.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p]
+    H.sim_sizeof_framerec.restype = C.c_size_t
+    return H
+
+
+class FrameRec(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("slot", C.c_int32), ("mode", C.c_int32), ("bitmask_lsb", C.c_int32),
+                ("freq_err_hz", C.c_float), ("signal_level", C.c_float), ("noise_floor", C.c_float),
+                ("train_bad", C.c_int32), ("train_total", C.c_int32), ("pad", C.c_int32), ("sample_index", C.c_uint64)]
+
+
+class Plan(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("pre", "post", "taps_min_length", "taps_length", "overlap", "n", "m", "input_size",
+                                         "post_input_size", "scrap", "v", "startbin", "offsetbin")] + \
+        [(n, C.c_float) for n in ("pre_shift", "post_shift", "sindelta", "cosdelta", "rate")]
+
+
+def test_abi_exports_match_header():
+    """libhfdl_gpu.so loads without a GPU and exports every symbol include/hfdl_gpu.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "hfdl_gpu.h")).read()
+    declared = set(re.findall(r"\b(hfdl_gpu_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("hfdl_gpu_frontend")
+    L = hf.load()
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert set(hf.frontend.EXPORTS) == declared
+
+
+def test_no_cpu_fallback_without_device():
+    if hf.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hf.GpuError, match="no HIP device|no CPU fallback"):
+        hf.Frontend(250000, 10_000_000, [10_010_000])
+    with pytest.raises(hf.GpuError):
+        hf.fft_forward(np.zeros(1024, np.complex64))
+    with pytest.raises(hf.GpuError):
+        hf.viterbi27(np.zeros((1, 1080), np.uint8), 540)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped package must never import, link or dlopen anything under oracle/ (or fall back to a CPU path)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dumphfdl_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".c", ".sh")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in txt and "liboracle" not in txt and "hfdl_oracle.h" not in txt, f
+                assert not re.search(r"(from|import)\s+oracle\b", txt), f
+    out = subprocess.run(["ldd", hf.lib_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+@pytest.mark.parametrize("fs,off", [(250000, 37000), (250000, -101500), (1000000, 412345), (8000000, -3163000), (40000000, 19081440)])
+def test_planner_matches_oracle(sim, oracle, fs, off):
+    dec, tbw, _ = oracle.geometry(fs)
+    assert sim.sim_fft_decimation_rate(fs, 5400) == dec
+    assert np.float32(sim.sim_transition_bw(fs, 250)) == np.float32(tbw)
+    shift = float(np.float32(-(off + 1440)) / np.float32(fs))
+    p = Plan()
+    assert sim.sim_plan(tbw, dec, shift, C.byref(p)) == 0
+    d = oracle.fastddc_init(tbw, dec, shift)
+    assert (p.pre, p.post, p.taps_length, p.n, p.m, p.input_size, p.post_input_size, p.scrap, p.v, p.startbin, p.offsetbin) == \
+        (d.pre_decimation, d.post_decimation, d.taps_length, d.fft_size, d.fft_inv_size, d.input_size, d.post_input_size,
+         d.scrap, d.v, d.startbin, d.offsetbin)
+    for a, b in ((p.post_shift, d.post_shift), (p.sindelta, d.nco_sindelta), (p.cosdelta, d.nco_cosdelta), (p.rate, d.nco_rate)):
+        assert np.float32(a) == np.float32(b)
+
+
+def test_tap_design_matches_oracle_bit_for_bit(sim, oracle):
+    n = 4097
+    a = np.zeros(n, np.complex64); b = np.zeros(n, np.complex64)
+    lo, hi = np.float32(0.1234 - 1 / 64), np.float32(0.1234 + 1 / 64)
+    sim.sim_bandpass(a.ctypes.data, n, float(lo), float(hi))
+    oracle.lib().orc_firdes_bandpass_c(b.ctypes.data, n, float(lo), float(hi))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert abs(np.abs(np.sum(a * np.exp(-2j * np.pi * 0.1234 * np.arange(n)))) - 1.0) < 1e-4     # unity gain at band centre
+
+
+def test_demod_tables_match_oracle(sim, oracle):
+    class T(C.Structure):
+        _fields_ = [("rs_h", C.c_float * (256 * 14)), ("rs_step", C.c_uint32), ("mf", C.c_float * 19),
+                    ("ss_mf", C.c_float * 288), ("ss_dmf", C.c_float * 288), ("lf_b0", C.c_float), ("lf_a1", C.c_float),
+                    ("ss_rate_adj", C.c_float), ("eq_h0", C.c_float * 15), ("a_hi", C.c_uint64), ("a_lo", C.c_uint64),
+                    ("m1_hi", C.c_uint64 * 8), ("m1_lo", C.c_uint64 * 8), ("scrambler", C.c_uint8 * 120)]
+    sim.sim_sizeof_tables.restype = C.c_size_t
+    assert sim.sim_sizeof_tables() == C.sizeof(T)
+    for rate in (0.6912, 0.55296):
+        t = T()
+        sim.sim_tables.argtypes = [C.c_float, C.c_void_p]
+        sim.sim_tables(rate, C.byref(t))
+        h = np.zeros(256 * 14, np.float32); step = C.c_uint32(0)
+        oracle.lib().orc_resamp_filter(rate, h.ctypes.data, C.byref(step))
+        assert step.value == t.rs_step and np.array_equal(np.frombuffer(t.rs_h, np.float32), h)
+        assert abs(h.reshape(256, 14).sum(axis=1) - 1).max() < 2e-3        # every polyphase branch ~ unity DC gain
+    mf = np.zeros(288, np.float32); dmf = np.zeros(288, np.float32)
+    oracle.lib().orc_symsync_filters(mf.ctypes.data, dmf.ctypes.data)
+    assert np.array_equal(np.frombuffer(t.ss_mf, np.float32), mf) and np.array_equal(np.frombuffer(t.ss_dmf, np.float32), dmf)
+    w = np.zeros(15, np.float32)
+    oracle.lib().orc_eq_initial_taps(w.ctypes.data)
+    assert np.array_equal(np.frombuffer(t.eq_h0, np.float32), w)
+    sb = np.zeros(120, np.uint8)
+    oracle.lib().orc_scrambler_bits(sb.ctypes.data, 120)
+    assert bytes(t.scrambler) == bytes(sb)
+
+
+def test_psk_soft_matches_oracle(sim, oracle):
+    rng = np.random.default_rng(8)
+    f2 = oracle.Cf
+    for arity in (1, 2, 3):
+        for _ in range(400):
+            x = complex(rng.normal(0, 0.8), rng.normal(0, 0.8))
+            a = np.zeros(3, np.uint8); b = np.zeros(3, np.uint8)
+            sim.sim_psk_soft(arity, x.real, x.imag, a.ctypes.data)
+            oracle.lib().orc_modem_demod_soft(arity, f2(x.real, x.imag), b.ctypes.data)
+            assert np.array_equal(a[:arity], b[:arity])
+
+
+def test_demod_core_matches_oracle_bit_for_bit(sim, oracle):
+    """Same plain-C arithmetic, same order, no FMA contraction on either side: every stage must agree exactly."""
+    assert sim.sim_sizeof_framerec() == C.sizeof(FrameRec)
+    rng = np.random.default_rng(7)
+    ch = oracle.Channel(250000, 10_000_000, 10_030_000, want_channelizer=False)
+    rate = 7812.5
+    s = sim.sim_create(np.float32(5400) / np.float32(rate), 1024)
+    t, bursts = 0.2, []
+    for mode in (3, 0, 6, 5):
+        bursts.append(dict(mode=mode, octets=synth.make_pdu(rng, mode), t0=t, amp=0.08, cfo=-11.0))
+        t += synth.burst_symbols_len(mode) / 1800 + 0.3
+    x = synth.synth_channel_baseband(rate, int((t + 0.3) * rate), bursts, noise_sigma=0.004, seed=2)
+    frames = (FrameRec * 16)()
+    syms = np.zeros((16, 5040), np.complex64)
+    got = []
+    for i in range(0, len(x) - 896, 896):
+        blk = np.ascontiguousarray(x[i:i + 896])
+        ch.process_baseband(blk)
+        v = ch.view()
+        nf = sim.sim_block(s, blk.ctypes.data, len(blk), frames, syms.ctypes.data)
+        rs = np.zeros(1024, np.complex64); mf = np.zeros(1024, np.complex64); sy = np.zeros(1024, np.complex64)
+        lv = np.zeros(1024, np.float32); cnt = (C.c_int * 2)()
+        sim.sim_taps(s, rs.ctypes.data, mf.ctypes.data, sy.ctypes.data, lv.ctypes.data, cnt)
+        assert cnt[0] == len(v["resampled"]) and cnt[1] == len(v["symbols"])
+        assert np.array_equal(rs[:cnt[0]], v["resampled"]) and np.array_equal(mf[:cnt[0]], v["mf_out"])
+        assert np.array_equal(lv[:cnt[0]], v["agc_level"]) and np.array_equal(sy[:cnt[1]], v["symbols"])
+        for k in range(nf):
+            f = frames[k]
+            octets = oracle.decode_user_data(f.mode, syms[k][:synth.mode_sizes(f.mode)["nsym"]], f.bitmask_lsb)
+            got.append((f.mode, bytes(octets), f.sample_index, f.train_bad, f.train_total, np.float32(f.freq_err_hz)))
+    sim.sim_destroy(s)
+    want = [(p["mode"], p["octets"], p["sample_index"], p["train_bits_bad"], p["train_bits_total"], np.float32(p["freq_err_hz"]))
+            for p in ch.pdus]
+    assert got == want and len(got) == 4
