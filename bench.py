@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- wideband I/Q Msamples/s (+ HFDL frames/s) of the MI355X HFDL front end at a fixed channel count.
+
+  python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2]
+
+One "step" = one block of `input_size` wideband cf32 samples through the WHOLE hot path: overlap assembly, forward
+FFT, per-channel fold + inverse FFT + NCO (fastddc), per-channel demodulator, burst decoder, PDU read-back.
+The synthetic input is resident in HBM before the timed region.  For N > 1 the driver launches one rank per GPU;
+every rank owns an independent wideband stream with the same channel count (BASELINE.json config 5, channels /
+streams sharded, no data-path collective); `value` is the whole-job aggregate.
+
+The JSON line carries, next to the driver's contract fields:
+  roofline      the fold kernel (spectrum x per-channel filter, >99% of the block's algorithmic bytes), timed with
+                HIP events on the front end's own stream; bytes = SURVEY.md section 8(d) canonical model
+  cpu_baseline  the plain-C oracle (a restatement -- FFTW / liquid-dsp are not installable here) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: 40 Msps synthetic cf32, 256 channels on a 150 kHz grid, 1 MI355X
+    "cfg3": dict(fs=40_000_000, centerfreq=15_000_000, nch=256, grid=150_000, blocks=16, seed=3, noise=0.05,
+                 name="40 Msps cf32, 256 HFDL channels (BASELINE.json configs[2]; per rank at N>1 = configs[4])"),
+    # BASELINE.json configs[1]: 8 Msps, 32 channels on a 200 kHz grid
+    "cfg2": dict(fs=8_000_000, centerfreq=10_000_000, nch=32, grid=200_000, blocks=26, seed=2, noise=0.02,
+                 name="8 Msps cf32, 32 HFDL channels (BASELINE.json configs[1])"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def channel_plan(w):
+    nch, grid, cf = w["nch"], w["grid"], w["centerfreq"]
+    return [int(cf + (i - nch // 2) * grid + grid // 2 - 1440) for i in range(nch)]
+
+
+def make_input(w, geom_input_size, rank, world):
+    """Seeded synthetic wideband stream: one single-slot burst per channel (modes cycle 300/600/1200/1800 bps) + AWGN."""
+    from dumphfdl_amd import synth
+    seed = w["seed"] if world == 1 else 5 + rank        # cfg5 = independent streams, seeds 5..12
+    nsamp = w["blocks"] * geom_input_size
+    cache = "/tmp/hfdl_bench_%s_seed%d_%d.npy" % (w["fs"], seed, nsamp)
+    freqs = channel_plan(w)
+    dur = nsamp / w["fs"]
+    rng = np.random.default_rng(seed)
+    bursts = []
+    for i, f in enumerate(freqs):
+        mode = i % 4
+        t0 = float(rng.uniform(0.02, max(0.03, dur - synth.burst_symbols_len(mode) / 1800 - 0.05)))
+        bursts.append(dict(freq=f, mode=mode, octets=synth.make_pdu(rng, mode), t0=t0,
+                           amp=float(rng.uniform(0.03, 0.06)) if w["nch"] > 64 else float(rng.uniform(0.05, 0.15)),
+                           cfo=float(rng.uniform(-15, 15))))
+    if os.path.exists(cache):
+        x = np.load(cache, mmap_mode="r")
+        if x.shape == (nsamp,):
+            return np.ascontiguousarray(x), bursts
+    x = synth.synth_wideband(w["fs"], w["centerfreq"], nsamp, bursts, noise_sigma=w["noise"], seed=seed)
+    try:
+        np.save(cache, x)
+    except OSError:
+        pass
+    return x, bursts
+
+
+def cpu_baseline(w, x, input_size, target_seconds=20.0):
+    """Time the oracle (plain-C restatement of the reference path, one worker thread per channel like the reference)
+    on this host: C_s channels of the same geometry, a few blocks; scale the per-channel part to the full channel count."""
+    from oracle import pyoracle
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    freqs = channel_plan(w)
+    cs = min(len(freqs), cores)
+    sel = freqs[:: max(1, len(freqs) // cs)][:cs]
+    t0 = time.time()
+    fe = pyoracle.Frontend(w["fs"], w["centerfreq"], sel, nthreads=cores)
+    t_init = time.time() - t0
+    # one untimed block (page-in, twiddle tables), then timed blocks
+    fe.push_block(x[:input_size], nthreads=cores)
+    nblk, t_all, t_fft = 0, 0.0, 0.0
+    L = pyoracle.lib()
+    import ctypes as C
+    spec = np.empty(fe.ddc.fft_size, np.complex64)
+    buf = np.zeros(fe.ddc.fft_size, np.complex64)
+    while nblk < 2 or (t_all < target_seconds / 2 and nblk < w["blocks"] - 1):
+        blk = np.ascontiguousarray(x[(nblk + 1) * input_size:(nblk + 2) * input_size])
+        t1 = time.time()
+        fe.push_block(blk, nthreads=cores)
+        t_all += time.time() - t1
+        t1 = time.time()            # the shared forward FFT alone (1 thread, like --fft-threads 1)
+        L.orc_forward_block(buf.ctypes.data_as(C.c_void_p), blk.ctypes.data_as(C.c_void_p), C.byref(fe.ddc), spec.ctypes.data_as(C.c_void_p))
+        t_fft += time.time() - t1
+        nblk += 1
+    per_blk, fft_blk = t_all / nblk, t_fft / nblk
+    chan_blk = max(per_blk - fft_blk, 1e-9)          # cs channels on `cores` threads
+    full = fft_blk + chan_blk * (len(freqs) / cs)
+    frames = len(fe.pdus)
+    fe.close()
+    return dict(value=input_size / full / 1e6, unit="Msamples/s", cores=cores, kind="port",
+                sample="oracle (C restatement; FFTW/liquid-dsp binaries unavailable): %d of %d channels x %d blocks of %d samples on %d "
+                       "threads, %.2f s/block measured (forward FFT %.2f s), channel part scaled x%.1f to %d channels; init %.1f s untimed; %d PDUs"
+                       % (cs, len(freqs), nblk, input_size, cores, per_blk, fft_blk, len(freqs) / cs, len(freqs), t_init, frames))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+
+    import torch            # plumbing only: device memory for the resident input, barrier / max-reduce across ranks
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HFDL front end has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import dumphfdl_amd as hf
+
+    freqs = channel_plan(w)
+    t0 = time.time()
+    fe = hf.Frontend(w["fs"], w["centerfreq"], freqs, device=local_rank)
+    g = fe.geometry
+    t_create = time.time() - t0
+    t0 = time.time()
+    x, bursts = make_input(w, g.input_size, rank, world)
+    t_gen = time.time() - t0
+    nblocks = len(x) // g.input_size
+    dev = torch.from_numpy(x.view(np.float32)).cuda()          # resident in HBM before the timed region
+    ptrs = [dev.data_ptr() + 8 * b * g.input_size for b in range(nblocks)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        fe.push_block(ptrs[step % nblocks]); step += 1
+    fe.poll_pdus()
+    fe.reset_timers(True)
+    barrier()
+    t0 = time.perf_counter()
+    npdus = 0
+    for _ in range(args.steps):
+        fe.push_block(ptrs[step % nblocks]); step += 1
+    pdus = fe.poll_pdus()           # sync + device->host of every PDU produced by the timed blocks
+    npdus = len(pdus)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fold_ms, fold_n = fe.fold_time_ms()
+    barrier()
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    cnt = torch.tensor([float(npdus)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed_max = float(tt.item())
+    total_pdus = int(cnt.item())
+
+    if rank == 0:
+        good = sum(1 for p in pdus if any(p["octets"][:len(b["octets"])] == b["octets"] for b in bursts if b["freq"] == p["freq"]))
+        samples = world * args.steps * g.input_size
+        # B = 8*input_size + C*8*N + C*8*(post_input_size/post_decimation) algorithmic bytes per block
+        alg_bytes = 8 * g.input_size + g.channels * 8 * g.fft_size + g.channels * 8 * (g.post_input_size // g.post_decimation)
+        fold_avg_ms = fold_ms / max(fold_n, 1)
+        achieved = alg_bytes / (fold_avg_ms * 1e-3) / 1e9 if fold_n else None
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "fold_traffic_%s.json" % args.workload)
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "wideband I/Q Msamples/s (cf32 ingest -> decoded HFDL PDUs) at fixed channel count",
+            "value": samples / elapsed_max / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["name"], "sample_rate": w["fs"], "channels": g.channels, "fft_size": g.fft_size,
+                       "fft_inv_size": g.fft_inv_size, "block_samples": g.input_size, "resident_blocks": nblocks,
+                       "parallelism": "1 independent %d-channel stream per GPU, no collectives" % g.channels},
+            "frames_per_s": total_pdus / elapsed_max, "pdus_in_timed_region": total_pdus,
+            "pdus_rank0_matching_sent_payload": good,
+            "roofline": {"bound": "hbm", "kernel": "fold_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n},
+            "setup_s": {"frontend_create": round(t_create, 2), "input_synthesis": round(t_gen, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            fe.close()
+            del dev
+            out["cpu_baseline"] = cpu_baseline(w, x, g.input_size)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

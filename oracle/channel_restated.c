@@ -710,7 +710,17 @@ struct orc_frontend {
 	orc_channel **ch;
 };
 
-orc_frontend *orc_frontend_create(int32_t sample_rate, int32_t centerfreq, const int32_t *freqs, int32_t nch)
+struct creator { orc_frontend *f; int32_t sample_rate, centerfreq, decim; float tbw; const int32_t *freqs; int first, step; };
+
+static void *creator_main(void *arg)
+{
+	struct creator *w = arg;
+	for (int32_t i = w->first; i < w->f->nch; i += w->step)
+		w->f->ch[i] = orc_channel_create(w->sample_rate, w->decim, w->tbw, w->centerfreq, w->freqs[i], 1);
+	return NULL;
+}
+
+orc_frontend *orc_frontend_create_mt(int32_t sample_rate, int32_t centerfreq, const int32_t *freqs, int32_t nch, int nthreads)
 {
 	orc_frontend *f = calloc(1, sizeof(*f));
 	int32_t decim = orc_compute_fft_decimation_rate(sample_rate, 1800 * 3);
@@ -720,8 +730,22 @@ orc_frontend *orc_frontend_create(int32_t sample_rate, int32_t centerfreq, const
 	f->spectrum = calloc((size_t)f->ddc.fft_size, sizeof(orc_cf));
 	f->nch = nch;
 	f->ch = calloc((size_t)nch, sizeof(*f->ch));
-	for (int32_t i = 0; i < nch; i++) f->ch[i] = orc_channel_create(sample_rate, decim, tbw, centerfreq, freqs[i], 1);
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > nch) nthreads = nch;
+	struct creator *w = calloc((size_t)nthreads, sizeof(*w));
+	pthread_t *th = calloc((size_t)nthreads, sizeof(*th));
+	for (int t = 0; t < nthreads; t++) {
+		w[t] = (struct creator){ f, sample_rate, centerfreq, decim, tbw, freqs, t, nthreads };
+		if (nthreads == 1) creator_main(&w[t]); else pthread_create(&th[t], NULL, creator_main, &w[t]);
+	}
+	for (int t = 0; t < nthreads && nthreads > 1; t++) pthread_join(th[t], NULL);
+	free(w); free(th);
 	return f;
+}
+
+orc_frontend *orc_frontend_create(int32_t sample_rate, int32_t centerfreq, const int32_t *freqs, int32_t nch)
+{
+	return orc_frontend_create_mt(sample_rate, centerfreq, freqs, nch, 1);
 }
 
 void orc_frontend_destroy(orc_frontend *f)

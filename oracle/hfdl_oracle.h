@@ -142,6 +142,7 @@ void orc_eq_initial_taps(float *w15);
 /* ---------------- whole front end (src/main.c:699-774 wiring) ---------------- */
 typedef struct orc_frontend orc_frontend;
 orc_frontend *orc_frontend_create(int32_t sample_rate, int32_t centerfreq, const int32_t *freqs, int32_t nch);
+orc_frontend *orc_frontend_create_mt(int32_t sample_rate, int32_t centerfreq, const int32_t *freqs, int32_t nch, int nthreads);
 void orc_frontend_destroy(orc_frontend *f);
 const orc_ddc *orc_frontend_ddc(const orc_frontend *f);
 /* push exactly input_size new samples; nthreads worker threads over channels (reference: 1 thread/channel) */

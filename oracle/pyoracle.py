@@ -108,6 +108,8 @@ def lib():
         L.orc_eq_initial_taps.argtypes = [C.c_void_p]
         L.orc_frontend_create.restype = C.c_void_p
         L.orc_frontend_create.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        L.orc_frontend_create_mt.restype = C.c_void_p
+        L.orc_frontend_create_mt.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int]
         L.orc_frontend_destroy.argtypes = [C.c_void_p]
         L.orc_frontend_ddc.restype = C.POINTER(Ddc)
         L.orc_frontend_ddc.argtypes = [C.c_void_p]
@@ -272,9 +274,9 @@ class Channel:
 class Frontend:
     """orc_frontend: forward FFT block + N channels, the reference's main.c wiring."""
 
-    def __init__(self, sample_rate, centerfreq, freqs):
+    def __init__(self, sample_rate, centerfreq, freqs, nthreads=1):
         fr = np.ascontiguousarray(freqs, dtype=np.int32)
-        self.h = lib().orc_frontend_create(sample_rate, centerfreq, _p(fr), len(fr))
+        self.h = lib().orc_frontend_create_mt(sample_rate, centerfreq, _p(fr), len(fr), nthreads)
         assert self.h
         self.nch = len(fr)
         self.ddc = lib().orc_frontend_ddc(self.h).contents

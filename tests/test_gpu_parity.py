@@ -164,7 +164,8 @@ def test_end_to_end_cfg2_shape(gpu, oracle):
     freqs = [int(cf + (i - 16) * 200_000 + 37_000) for i in range(32)]
     dur = 3.3
     bursts = synth.plan_traffic(freqs, dur, seed=2, modes=[0, 1, 2, 3], dense=False)
-    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.02, seed=2)
+    # pad the stream so the last burst has left the channelizer / demodulator pipeline before the input ends
+    x = synth.synth_wideband(fs, cf, int((dur + 0.35) * fs), bursts, noise_sigma=0.02, seed=2)
     got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
     key = lambda p: (p["freq"], p["mode"], p["octets"])
     assert sorted(map(key, got)) == sorted(map(key, want))
