@@ -56,7 +56,7 @@ def make_input(w, geom_input_size, rank, world):
         mode = i % 4
         t0 = float(rng.uniform(0.02, max(0.03, dur - synth.burst_symbols_len(mode) / 1800 - 0.05)))
         bursts.append(dict(freq=f, mode=mode, octets=synth.make_pdu(rng, mode), t0=t0,
-                           amp=float(rng.uniform(0.03, 0.06)) if w["nch"] > 64 else float(rng.uniform(0.05, 0.15)),
+                           amp=float(rng.uniform(0.01, 0.03)),        # ~19..29 dB in-channel SNR
                            cfo=float(rng.uniform(-15, 15))))
     if os.path.exists(cache):
         x = np.load(cache, mmap_mode="r")

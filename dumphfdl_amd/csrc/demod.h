@@ -29,7 +29,7 @@ struct Demod {
 	size_t lds_bytes = 0;
 
 	int init(int nch, int outs, float resamp_rate, const int32_t *freqs, hipStream_t st);
-	int enqueue_block(const float2 *chan_out, const NcoState *nco, hipStream_t st);
+	int enqueue_block(const float2 *chan_out, const int *out_count, hipStream_t st);
 	int collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);
 	int tap(int what, int channel, const void **src, size_t *nfloats);
 	void release();

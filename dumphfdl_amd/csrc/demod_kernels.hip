@@ -35,7 +35,7 @@ struct DemodBuffers {
 };
 
 __global__ __launch_bounds__(64) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
-		const NcoState *__restrict__ nco, int outs_stride)
+		const int *__restrict__ n_in, int outs_stride)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const int c = blockIdx.x, lane = threadIdx.x;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void demod_kernel(DevTables T, DemodBuffers B, 
 	} else {
 		io.tap_resampled = nullptr; io.tap_mf = nullptr; io.tap_symbols = nullptr; io.tap_level = nullptr; io.tap_counts = nullptr;
 	}
-	demod_block(S, *A, K, io, chan_out + (size_t)c * outs_stride, nco[c].output_size);
+	demod_block(S, *A, K, io, chan_out + (size_t)c * outs_stride, n_in[c]);
 	__syncthreads();
 	if (lane == 0) gs->s = S;
 	{
@@ -298,7 +298,7 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	return 0;
 }
 
-int Demod::enqueue_block(const float2 *chan_out, const NcoState *nco, hipStream_t st)
+int Demod::enqueue_block(const float2 *chan_out, const int *out_count, hipStream_t st)
 {
 	DemodPriv *pv = priv_of(this);
 	if (!pv) return HFDL_GPU_EINVAL;
@@ -306,7 +306,7 @@ int Demod::enqueue_block(const float2 *chan_out, const NcoState *nco, hipStream_
 	B.states = d_states; B.data = (cf *)d_data; B.frames = d_frames; B.counts = d_counts; B.frame_cap = nch;
 	B.tap_rs = (cf *)d_tap_rs; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
 	B.cap = cap;
-	hipLaunchKernelGGL(demod_kernel, dim3((unsigned)nch), dim3(64), lds_bytes, st, pv->t, B, (const cf *)chan_out, nco, outs);
+	hipLaunchKernelGGL(demod_kernel, dim3((unsigned)nch), dim3(64), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
 	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)d_frames, d_counts, nch,
 			(const cf *)d_data, pv->t.scrambler, (const int32_t *)d_freqs, d_pdus, pdu_cap);
 	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int), st));
@@ -351,7 +351,7 @@ int Demod::tap(int what, int channel, const void **src, size_t *nfloats)
 void Demod::release()
 {
 	void *ptrs[] = { d_tables, d_states, d_data, d_frames, d_counts, d_pdus, d_freqs, d_tap_rs, d_tap_mf, d_tap_sym, d_tap_lvl, d_tap_counts };
-	for (void *p : ptrs) if (p) hipFree(p);
+	for (void *p : ptrs) if (p) (void)hipFree(p);
 	d_tables = nullptr; d_states = nullptr; d_data = nullptr; d_frames = nullptr; d_counts = nullptr; d_pdus = nullptr; d_freqs = nullptr;
 	d_tap_rs = d_tap_mf = d_tap_sym = nullptr; d_tap_lvl = nullptr; d_tap_counts = nullptr;
 	for (size_t i = 0; i < g_priv.size(); i++) if (g_priv[i].first == this) { delete g_priv[i].second; g_priv.erase(g_priv.begin() + (long)i); break; }
@@ -373,7 +373,7 @@ int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uin
 	D_TRY(hipDeviceSynchronize());
 	D_TRY(hipGetLastError());
 	D_TRY(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
-	hipFree(d_in); hipFree(d_out);
+	(void)hipFree(d_in); (void)hipFree(d_out);
 	return 0;
 }
 
@@ -425,7 +425,7 @@ int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const i
 		lens[p.channel] = p.len;
 		std::memcpy(octets + (size_t)p.channel * HFDL_GPU_PDU_MAX_OCTETS, p.octets, (size_t)p.len);
 	}
-	hipFree(d_scr); hipFree(d_fr); hipFree(d_data); hipFree(d_counts); hipFree(d_freqs); hipFree(d_pdus);
+	(void)hipFree(d_scr); (void)hipFree(d_fr); (void)hipFree(d_data); (void)hipFree(d_counts); (void)hipFree(d_freqs); (void)hipFree(d_pdus);
 	return 0;
 }
 

@@ -110,7 +110,8 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 // y = IFFT_M(x) / (pre * M); drop `scrap`; out[k] = y[scrap + rem + q k] * e^{j phi_k}   (:193-211)
 // phi_k follows the reference's fp32 phasor recurrence exactly (one lane runs it; it is 1792 steps).
 __global__ __launch_bounds__(256) void ifft_nco_kernel(const float2 *__restrict__ partial, const ChanConst *__restrict__ cc,
-		NcoState *__restrict__ nco, const float2 *__restrict__ tw, float2 *__restrict__ chan_out, Geometry g, int logm)
+		NcoState *__restrict__ nco, const float2 *__restrict__ tw, float2 *__restrict__ chan_out, int *__restrict__ out_count,
+		Geometry g, int logm)
 {
 	extern __shared__ float2 sm[];          // m bins, then `outs` phasors
 	float2 *ph = sm + g.m;
@@ -167,16 +168,17 @@ __global__ __launch_bounds__(256) void ifft_nco_kernel(const float2 *__restrict_
 		st.starting_phase = fp;
 		st.output_size = cnt;
 		nco[c] = st;
+		out_count[c] = cnt;      // per-buffer copy: the demodulator of this block may run while the next block updates nco[]
 	}
 }
 
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
-		const float2 *tw_m, float2 *chan_out, hipStream_t st)
+		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st)
 {
 	int logm = 0;
 	while ((1 << logm) < g.m) logm++;
 	size_t lds = sizeof(float2) * ((size_t)g.m + (size_t)g.outs + 1);
-	hipLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(256), lds, st, partial, cc, nco, tw_m, chan_out, g, logm);
+	hipLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(256), lds, st, partial, cc, nco, tw_m, chan_out, out_count, g, logm);
 }
 
 }  // namespace hfdl

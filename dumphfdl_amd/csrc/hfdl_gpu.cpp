@@ -61,7 +61,7 @@ struct HostFftPlan {
 	FftPlan p{};
 	float2 *d_tw[3] = { nullptr, nullptr, nullptr };
 	int build(int n);
-	void release() { for (auto &t : d_tw) { if (t) hipFree(t); t = nullptr; } }
+	void release() { for (auto &t : d_tw) { if (t) (void)hipFree(t); t = nullptr; } }
 };
 
 static int upload_twiddles(int r, float2 **out)
@@ -97,7 +97,10 @@ int HostFftPlan::build(int n)
 
 struct hfdl_gpu_frontend {
 	int device = 0;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;       // A: ingest + forward FFT + fold + inverse FFT/NCO of block k
+	hipStream_t stream_b = nullptr;     // B: demodulator + burst decoder of block k-1, concurrent with A
+	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
+	int last_buf = 0;
 	int32_t sample_rate = 0, centerfreq = 0, decimation = 0;
 	float tbw = 0;
 	Plan plan{};                       // shift = 0 geometry (src/fft.c:70-86)
@@ -106,7 +109,8 @@ struct hfdl_gpu_frontend {
 	std::vector<int32_t> freqs;
 	std::vector<ChanConst> cc;
 	float2 *d_hist = nullptr, *d_work = nullptr, *d_spec = nullptr, *d_taps = nullptr, *d_partial = nullptr;
-	float2 *d_chan_out = nullptr, *d_tw_m = nullptr, *d_stage = nullptr;
+	float2 *d_chan_out[2] = { nullptr, nullptr }, *d_tw_m = nullptr, *d_stage = nullptr;
+	int *d_out_count[2] = { nullptr, nullptr };
 	ChanConst *d_cc = nullptr;
 	NcoState *d_nco = nullptr;
 	size_t stage_cap = 0;
@@ -123,14 +127,17 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 {
 	if (!fe) return;
 	hipSetDevice(fe->device);
-	if (fe->stream) hipStreamSynchronize(fe->stream);
-	for (auto &e : fe->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+	if (fe->stream) (void)hipStreamSynchronize(fe->stream);
+	if (fe->stream_b) (void)hipStreamSynchronize(fe->stream_b);
+	for (int i = 0; i < 2; i++) { if (fe->ev_chan[i]) (void)hipEventDestroy(fe->ev_chan[i]); if (fe->ev_demod[i]) (void)hipEventDestroy(fe->ev_demod[i]); }
+	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	fe->demod.release();
 	fe->fft.release();
-	void *ptrs[] = { fe->d_hist, fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_out, fe->d_tw_m, fe->d_stage,
-		fe->d_cc, fe->d_nco };
-	for (void *p : ptrs) if (p) hipFree(p);
-	if (fe->stream) hipStreamDestroy(fe->stream);
+	void *ptrs[] = { fe->d_hist, fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_out[0], fe->d_chan_out[1], fe->d_tw_m,
+		fe->d_stage, fe->d_cc, fe->d_nco, fe->d_out_count[0], fe->d_out_count[1] };
+	for (void *p : ptrs) if (p) (void)hipFree(p);
+	if (fe->stream) (void)hipStreamDestroy(fe->stream);
+	if (fe->stream_b) (void)hipStreamDestroy(fe->stream_b);
 	delete fe;
 }
 
@@ -192,7 +199,7 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	}
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipGetLastError());
-	hipFree(d_pad);
+	(void)hipFree(d_pad);
 	return 0;
 }
 
@@ -231,6 +238,11 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	int rc_ = fail(e_ == hipErrorOutOfMemory ? HFDL_GPU_ENOMEM : HFDL_GPU_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
 	frontend_free(fe); return rc_; } } while (0)
 	FE_TRY(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
+	FE_TRY(hipStreamCreateWithFlags(&fe->stream_b, hipStreamNonBlocking));
+	for (int i = 0; i < 2; i++) {
+		FE_TRY(hipEventCreateWithFlags(&fe->ev_chan[i], hipEventDisableTiming));
+		FE_TRY(hipEventCreateWithFlags(&fe->ev_demod[i], hipEventDisableTiming));
+	}
 	if ((rc = fe->fft.build(pl.n))) { frontend_free(fe); return rc; }
 	const size_t n = (size_t)pl.n;
 	FE_TRY(hipMalloc(&fe->d_hist, sizeof(float2) * (size_t)pl.overlap));
@@ -239,7 +251,11 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n));
 	FE_TRY(hipMalloc(&fe->d_taps, sizeof(float2) * n * (size_t)nch));
 	FE_TRY(hipMalloc(&fe->d_partial, sizeof(float2) * (size_t)nch * g.slices * (size_t)g.m));
-	FE_TRY(hipMalloc(&fe->d_chan_out, sizeof(float2) * (size_t)nch * g.outs));
+	for (int i = 0; i < 2; i++) {
+		FE_TRY(hipMalloc(&fe->d_chan_out[i], sizeof(float2) * (size_t)nch * g.outs));
+		FE_TRY(hipMalloc(&fe->d_out_count[i], sizeof(int) * (size_t)nch));
+		FE_TRY(hipMemsetAsync(fe->d_out_count[i], 0, sizeof(int) * (size_t)nch, fe->stream));
+	}
 	FE_TRY(hipMalloc(&fe->d_nco, sizeof(NcoState) * (size_t)nch));
 	FE_TRY(hipMemsetAsync(fe->d_nco, 0, sizeof(NcoState) * (size_t)nch, fe->stream));
 	FE_TRY(hipMalloc(&fe->d_cc, sizeof(ChanConst) * (size_t)nch));
@@ -284,7 +300,7 @@ static int stage_input(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, 
 	HIP_TRY(hipSetDevice(fe->device));
 	if (on_device) { *dev = (const float2 *)iq; return 0; }
 	if (fe->stage_cap < nsamples) {
-		if (fe->d_stage) hipFree(fe->d_stage);
+		if (fe->d_stage) (void)hipFree(fe->d_stage);
 		fe->d_stage = nullptr; fe->stage_cap = 0;
 		HIP_TRY(hipMalloc(&fe->d_stage, sizeof(float2) * nsamples));
 		fe->stage_cap = nsamples;
@@ -295,9 +311,13 @@ static int stage_input(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, 
 	return 0;
 }
 
-static int enqueue_channelizer(hfdl_gpu_frontend *fe, const float2 *fresh)
+// Stream A runs the channelizer of block k into buffer k&1; stream B demodulates it.  A may not overwrite a buffer
+// before B has finished with it (two blocks ago); B may not start before A has filled it.
+static int enqueue_channelizer(hfdl_gpu_frontend *fe, const float2 *fresh, int *buf_out)
 {
 	const Geometry &g = fe->geo;
+	const int buf = (int)(fe->blocks & 1);
+	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_demod[buf], 0));
 	launch_fft_forward(fe->fft.p, fe->d_hist, fresh, g.overlap, fe->d_work, fe->d_spec, true, fe->stream);
 	launch_copy_tail(fresh, fe->d_hist, g.input_size, g.overlap, fe->stream);
 	if (fe->timing) {
@@ -311,9 +331,12 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const float2 *fresh)
 	} else {
 		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
 	}
-	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_tw_m, fe->d_chan_out, fe->stream);
+	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_tw_m, fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream);
 	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(fe->ev_chan[buf], fe->stream));
 	fe->blocks++;
+	fe->last_buf = buf;
+	if (buf_out) *buf_out = buf;
 	return 0;
 }
 
@@ -322,17 +345,20 @@ extern "C" int hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const f
 	const float2 *fresh = nullptr;
 	int rc = stage_input(fe, iq, nsamples, on_device, &fresh);
 	if (rc) return rc;
-	return enqueue_channelizer(fe, fresh);
+	return enqueue_channelizer(fe, fresh, nullptr);
 }
 
 extern "C" int hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
 {
 	const float2 *fresh = nullptr;
+	int buf = 0;
 	int rc = stage_input(fe, iq, nsamples, on_device, &fresh);
 	if (rc) return rc;
-	if ((rc = enqueue_channelizer(fe, fresh))) return rc;
-	rc = fe->demod.enqueue_block(fe->d_chan_out, fe->d_nco, fe->stream);
+	if ((rc = enqueue_channelizer(fe, fresh, &buf))) return rc;
+	HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
+	rc = fe->demod.enqueue_block(fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream_b);
 	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
+	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_b));
 	return 0;
 }
 
@@ -343,7 +369,7 @@ static int drain_events(hfdl_gpu_frontend *fe)
 		HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
 		fe->fold_ms += ms;
 		fe->fold_launches++;
-		hipEventDestroy(e.first); hipEventDestroy(e.second);
+		(void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
 	}
 	fe->ev.clear();
 	return 0;
@@ -354,6 +380,7 @@ extern "C" int hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe)
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	HIP_TRY(hipSetDevice(fe->device));
 	HIP_TRY(hipStreamSynchronize(fe->stream));
+	HIP_TRY(hipStreamSynchronize(fe->stream_b));
 	HIP_TRY(hipGetLastError());
 	return drain_events(fe);
 }
@@ -382,7 +409,7 @@ extern "C" int hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *
 	if (!fe || !n) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
-	rc = fe->demod.collect(out, max, n, fe->stream);
+	rc = fe->demod.collect(out, max, n, fe->stream_b);
 	if (rc) return fail(rc, "pdu collection failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;
 }
@@ -400,9 +427,9 @@ extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32
 	case HFDL_GPU_TAP_SPECTRUM: src = fe->d_spec; nf = 2 * (size_t)g.n; break;
 	case HFDL_GPU_TAP_FILTER: src = fe->d_taps + (size_t)channel * g.n; nf = 2 * (size_t)g.n; break;
 	case HFDL_GPU_TAP_CHAN_OUT: {
-		NcoState st;
-		HIP_TRY(hipMemcpy(&st, fe->d_nco + channel, sizeof(st), hipMemcpyDeviceToHost));
-		src = fe->d_chan_out + (size_t)channel * g.outs; nf = 2 * (size_t)st.output_size; break; }
+		int cnt = 0;
+		HIP_TRY(hipMemcpy(&cnt, fe->d_out_count[fe->last_buf] + channel, sizeof(cnt), hipMemcpyDeviceToHost));
+		src = fe->d_chan_out[fe->last_buf] + (size_t)channel * g.outs; nf = 2 * (size_t)cnt; break; }
 	default:
 		rc = fe->demod.tap(what, channel, &src, &nf);
 		if (rc) return fail(rc, "unknown tap %d", what);
@@ -431,7 +458,7 @@ extern "C" int hfdl_gpu_fft_forward(int device, const float *in, float *out, int
 	HIP_TRY(hipDeviceSynchronize());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpy(out, d_out, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost));
-	hipFree(d_in); hipFree(d_work); hipFree(d_out);
+	(void)hipFree(d_in); (void)hipFree(d_work); (void)hipFree(d_out);
 	plan.release();
 	return 0;
 }

@@ -163,7 +163,7 @@ def test_end_to_end_cfg2_shape(gpu, oracle):
     fs, cf = 8_000_000, 10_000_000
     freqs = [int(cf + (i - 16) * 200_000 + 37_000) for i in range(32)]
     dur = 3.3
-    bursts = synth.plan_traffic(freqs, dur, seed=2, modes=[0, 1, 2, 3], dense=False)
+    bursts = synth.plan_traffic(freqs, dur, seed=2, modes=[0, 1, 2, 3], dense=False, amp=(0.008, 0.03))   # 19..30 dB in-channel SNR
     # pad the stream so the last burst has left the channelizer / demodulator pipeline before the input ends
     x = synth.synth_wideband(fs, cf, int((dur + 0.35) * fs), bursts, noise_sigma=0.02, seed=2)
     got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
