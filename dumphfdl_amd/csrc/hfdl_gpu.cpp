@@ -290,6 +290,31 @@ extern "C" int hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_
 	return 0;
 }
 
+extern "C" int hfdl_gpu_plan_geometry(int32_t decimation, float transition_bw, hfdl_gpu_geometry *g)
+{
+	if (!g || decimation < 1 || !(transition_bw > 0.f)) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	Plan p;
+	if (!plan_block(p, transition_bw, decimation, 0.f)) return fail(HFDL_GPU_EINVAL, "fastddc planning failed");
+	memset(g, 0, sizeof(*g));
+	g->decimation = decimation;
+	g->pre_decimation = p.pre; g->post_decimation = p.post;
+	g->taps_length = p.taps_length; g->overlap_length = p.overlap;
+	g->fft_size = p.n; g->fft_inv_size = p.m; g->input_size = p.input_size;
+	g->post_input_size = p.post_input_size; g->scrap = p.scrap;
+	g->outputs_per_block = p.post_input_size / p.post;
+	g->transition_bw = transition_bw;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_host_alloc(void **ptr, size_t bytes)
+{
+	if (!ptr || !bytes) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+	return 0;
+}
+
+extern "C" void hfdl_gpu_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
+
 extern "C" void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe) { return fe ? (void *)fe->stream : nullptr; }
 
 static int stage_input(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device, const float2 **dev)

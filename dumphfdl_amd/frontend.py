@@ -36,6 +36,7 @@ def lib_path():
 _lib = None
 
 EXPORTS = [
+    "hfdl_gpu_plan_geometry", "hfdl_gpu_host_alloc", "hfdl_gpu_host_free",
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
@@ -61,6 +62,10 @@ def load():
     L.hfdl_gpu_last_error.restype = C.c_char_p
     L.hfdl_gpu_frontend_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
     L.hfdl_gpu_frontend_destroy.argtypes = [C.c_void_p]
+    L.hfdl_gpu_plan_geometry.argtypes = [C.c_int32, C.c_float, C.POINTER(Geometry)]
+    L.hfdl_gpu_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.hfdl_gpu_host_free.argtypes = [C.c_void_p]
+    L.hfdl_gpu_host_free.restype = None
     L.hfdl_gpu_frontend_destroy.restype = None
     L.hfdl_gpu_frontend_geometry.argtypes = [C.c_void_p, C.POINTER(Geometry)]
     L.hfdl_gpu_frontend_push_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -82,6 +87,12 @@ def load():
 def _check(rc):
     if rc != 0:
         raise GpuError("hfdl_gpu error %d: %s" % (rc, load().hfdl_gpu_last_error().decode(errors="replace")))
+
+
+def plan_geometry(decimation, transition_bw):
+    g = Geometry()
+    _check(load().hfdl_gpu_plan_geometry(decimation, transition_bw, C.byref(g)))
+    return g
 
 
 def device_count():

@@ -1,0 +1,64 @@
+/* hfdl_replay.c -- minimal host program over libhfdl_host.so: the wiring of dumphfdl's main() (src/main.c:687-802) for a raw
+ * I/Q file, with the protocol parsers replaced by the library's printing pdu_decoder_queue_push().
+ *
+ *   hfdl_replay --iq-file FILE --sample-rate HZ --sample-format CF32|CS16|CU8 --centerfreq KHZ [--device N] FREQ_KHZ...
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "hfdl_host.h"
+
+int main(int argc, char **argv)
+{
+	struct input_cfg *cfg = input_cfg_create();
+	cfg->type = INPUT_TYPE_FILE;
+	double centerfreq_khz = -1;
+	int32_t freqs[4096];
+	int nfreq = 0;
+	for (int i = 1; i < argc; i++) {
+		if (!strcmp(argv[i], "--iq-file") && i + 1 < argc) cfg->source = argv[++i];
+		else if (!strcmp(argv[i], "--sample-rate") && i + 1 < argc) cfg->sample_rate = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--sample-format") && i + 1 < argc) cfg->sfmt = sample_format_from_string(argv[++i]);
+		else if (!strcmp(argv[i], "--centerfreq") && i + 1 < argc) centerfreq_khz = atof(argv[++i]);
+		else if (!strcmp(argv[i], "--read-buffer-size") && i + 1 < argc) cfg->read_buffer_size = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--device") && i + 1 < argc) hfdl_frontend_set_device(atoi(argv[++i]));
+		else if (argv[i][0] != '-' && nfreq < 4096) freqs[nfreq++] = (int32_t)(1e3 * atof(argv[i]));     /* kHz -> Hz, src/main.c:197-212 */
+		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
+	}
+	if (!cfg->source || cfg->sample_rate < HFDL_SYMBOL_RATE * SPS || cfg->sfmt == SFMT_UNDEF || nfreq == 0) {
+		fprintf(stderr, "usage: %s --iq-file F --sample-rate HZ --sample-format FMT [--centerfreq KHZ] freq_khz...\n", argv[0]);
+		return 1;
+	}
+	if (centerfreq_khz < 0) {        /* midpoint of the outermost channels, src/main.c:228-239 */
+		int32_t lo = freqs[0], hi = freqs[0];
+		for (int i = 1; i < nfreq; i++) { if (freqs[i] < lo) lo = freqs[i]; if (freqs[i] > hi) hi = freqs[i]; }
+		cfg->centerfreq = lo + (hi - lo) / 2;
+	} else {
+		cfg->centerfreq = (int32_t)(1e3 * centerfreq_khz);
+	}
+	struct block *input = input_create(cfg);
+	if (input == NULL || input_init(input) < 0) { fprintf(stderr, "Unable to initialize input\n"); return 1; }
+	int32_t decimation = compute_fft_decimation_rate(cfg->sample_rate, HFDL_SYMBOL_RATE * SPS);
+	float tbw = compute_filter_relative_transition_bw(cfg->sample_rate, HFDL_CHANNEL_TRANSITION_BW_HZ);
+	struct block *fft = fft_create(decimation, tbw);
+	if (fft == NULL) return 1;
+	hfdl_init_globals();
+	struct block **channels = calloc((size_t)nfreq, sizeof(*channels));
+	for (int i = 0; i < nfreq; i++) {
+		channels[i] = hfdl_channel_create(cfg->sample_rate, decimation, tbw, cfg->centerfreq, freqs[i]);
+		if (channels[i] == NULL) { fprintf(stderr, "Failed to initialize channel %d\n", freqs[i]); return 1; }
+	}
+	if (block_connect_one2one(input, fft) != 1 || block_connect_one2many(fft, (size_t)nfreq, channels) != nfreq) return 1;
+	/* start order: channels, fft, input (src/main.c:770-774) */
+	if (block_set_start((size_t)nfreq, channels) != nfreq || block_start(fft) != 1 || block_start(input) != 1) return 1;
+	while (block_is_running(input) || block_is_running(fft) || block_set_is_any_running((size_t)nfreq, channels)) usleep(20000);
+	block_disconnect_one2many(fft, (size_t)nfreq, channels);
+	block_disconnect_one2one(input, fft);
+	for (int i = 0; i < nfreq; i++) hfdl_channel_destroy(channels[i]);
+	fft_destroy(fft);
+	input_destroy(input);
+	input_cfg_destroy(cfg);
+	free(channels);
+	return 0;
+}

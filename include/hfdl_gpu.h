@@ -69,6 +69,16 @@ typedef struct {
 	uint8_t  octets[HFDL_GPU_PDU_MAX_OCTETS];
 } hfdl_gpu_pdu;
 
+/* ---- planning (host only, no device needed) ---- */
+
+/* fastddc_init(.., shift = 0) as fft_create() runs it (src/fft.c:70-86, src/fastddc.c:46-80): block geometry for a
+ * decimation / relative transition bandwidth pair.  channels / fold_slices / sample_rate / resamp_rate are left 0. */
+int  hfdl_gpu_plan_geometry(int32_t decimation, float transition_bw, hfdl_gpu_geometry *g);
+
+/* page-locked host memory for block staging (the role of the reference's ring read pointer, src/fft.c:50-53) */
+int  hfdl_gpu_host_alloc(void **ptr, size_t bytes);
+void hfdl_gpu_host_free(void *ptr);
+
 /* ---- whole front end ---- */
 
 /* frequencies in Hz as in hfdl_channel_create(); decimation / transition_bw are derived exactly as

@@ -1,0 +1,119 @@
+/* host_check.c -- TEST PROGRAM: drives libhfdl_host.so's block / input API the way dumphfdl's main() does, without a GPU.
+ *   host_check ring                       ring wrap-around / overrun behaviour
+ *   host_check file PATH FMT BUFSIZE OUT  file input -> ring -> this consumer; converted cf32 samples written to OUT
+ *   host_check graph                      connect/return-value contract of the block graph and channel slots */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "hfdl_host.h"
+
+static int check_ring(void)
+{
+	struct hfdl_ring *r = hfdl_ring_create(8);
+	float complex a[16], b[16];
+	for (int i = 0; i < 16; i++) a[i] = i + 1 + (float)i * I;
+	if (hfdl_ring_write(r, a, 5) != 5 || hfdl_ring_size(r) != 5 || hfdl_ring_space_available(r) != 3) return 1;
+	if (hfdl_ring_read(r, b, 3) != 3 || crealf(b[0]) != 1 || crealf(b[2]) != 3) return 2;
+	if (hfdl_ring_write(r, a + 5, 6) != 6 || hfdl_ring_size(r) != 8) return 3;          /* wraps */
+	if (hfdl_ring_write(r, a, 4) != 0) return 4;                                          /* full */
+	if (hfdl_ring_read(r, b, 16) != 8) return 5;
+	for (int i = 0; i < 8; i++) if (crealf(b[i]) != i + 4 || cimagf(b[i]) != i + 3) return 6;
+	hfdl_ring_destroy(r);
+	/* complex_samples_produce drops what does not fit and keeps the rest (src/input-helpers.c:80-92) */
+	struct block src = { .producer = { .type = PRODUCER_SINGLE, .max_tu = 1 } }, dst = { .consumer = { .type = CONSUMER_SINGLE, .min_ru = 2 } };
+	if (block_connect_one2one(&src, &dst) != 1) return 7;
+	struct circ_buffer *cb = &src.producer.out->circ_buffer;           /* capacity max(8*1, 2*2) = 8 */
+	complex_samples_produce(cb, a, 6);
+	complex_samples_produce(cb, a + 6, 6);
+	if (hfdl_ring_size(cb->buf) != 8) return 8;
+	hfdl_ring_read(cb->buf, b, 8);
+	if (crealf(b[7]) != 8) return 9;
+	block_disconnect_one2one(&src, &dst);
+	if (src.producer.out != NULL || dst.consumer.in != NULL) return 10;
+	printf("ring ok\n");
+	return 0;
+}
+
+static int check_file(const char *path, const char *fmt, int bufsize, const char *out_path)
+{
+	struct input_cfg *cfg = input_cfg_create();
+	cfg->type = INPUT_TYPE_FILE;
+	cfg->source = (char *)path;
+	cfg->sfmt = sample_format_from_string(fmt);
+	cfg->read_buffer_size = bufsize;
+	cfg->sample_rate = 250000;
+	struct block *in = input_create(cfg);
+	if (in == NULL) return 1;
+	if (input_init(in) < 0) return 2;
+	struct block sink = { .consumer = { .type = CONSUMER_SINGLE, .min_ru = 1000 } };
+	if (block_connect_one2one(in, &sink) != 1) return 3;
+	struct circ_buffer *cb = &sink.consumer.in->circ_buffer;
+	FILE *out = fopen(out_path, "wb");
+	if (block_start(in) != 1) return 4;
+	float complex tmp[4096];
+	size_t total = 0;
+	for (;;) {
+		pthread_mutex_lock(cb->mutex);
+		while (hfdl_ring_size(cb->buf) == 0 && !block_connection_is_shutdown_signaled(sink.consumer.in)) pthread_cond_wait(cb->cond, cb->mutex);
+		size_t n = hfdl_ring_read(cb->buf, tmp, 4096);
+		int done = n == 0 && block_connection_is_shutdown_signaled(sink.consumer.in);
+		pthread_mutex_unlock(cb->mutex);
+		if (done) break;
+		fwrite(tmp, sizeof(float complex), n, out);
+		total += n;
+	}
+	fclose(out);
+	while (block_is_running(in)) usleep(1000);
+	struct input *ip = (struct input *)in;
+	printf("samples %zu max_tu %zu bytes_per_sample %d full_scale %.3f\n", total, in->producer.max_tu, ip->bytes_per_sample, ip->full_scale);
+	return 0;
+}
+
+static int check_graph(void)
+{
+	int32_t dec = compute_fft_decimation_rate(250000, HFDL_SYMBOL_RATE * SPS);
+	float tbw = compute_filter_relative_transition_bw(250000, HFDL_CHANNEL_TRANSITION_BW_HZ);
+	if (dec != 32) return 1;
+	if (compute_fft_decimation_rate(8000000, 5400) != 1024 || compute_fft_decimation_rate(40000000, 5400) != 4096) return 2;
+	struct block *fft = fft_create(dec, tbw);
+	if (fft == NULL) return 3;
+	if (fft->producer.type != PRODUCER_MULTI || fft->consumer.type != CONSUMER_SINGLE || fft->producer.max_tu != 32768 || fft->consumer.min_ru != 32768) return 4;
+	hfdl_init_globals();
+	struct block *ch[3];
+	for (int i = 0; i < 3; i++) {
+		ch[i] = hfdl_channel_create(250000, dec, tbw, 10000000, 10010000 + 20000 * i);
+		if (ch[i] == NULL || ch[i]->consumer.type != CONSUMER_MULTI || ch[i]->producer.type != PRODUCER_NONE) return 5;
+	}
+	if (hfdl_channel_create(0, dec, tbw, 1, 2) != NULL) return 6;
+	if (block_connect_one2many(fft, 3, ch) != 3) return 7;
+	for (int i = 0; i < 3; i++) if (ch[i]->consumer.in != fft->producer.out) return 8;
+	struct block bad = { .producer = { .type = PRODUCER_SINGLE, .max_tu = 4 } };
+	if (block_connect_one2many(&bad, 3, ch) != 0) return 9;                 /* wrong producer type */
+	if (block_is_running(fft) || block_set_is_any_running(3, ch)) return 10;
+	block_disconnect_one2many(fft, 3, ch);
+	for (int i = 0; i < 3; i++) { if (ch[i]->consumer.in != NULL) return 11; hfdl_channel_destroy(ch[i]); }
+	fft_destroy(fft);
+	if (sample_format_from_string("cs16") != SFMT_CS16 || sample_format_from_string("CF32") != SFMT_CF32 ||
+			sample_format_from_string("nope") != SFMT_UNDEF) return 12;
+	if (get_sample_size(SFMT_CU8) != 2 || get_sample_size(SFMT_CS16) != 4 || get_sample_size(SFMT_CF32) != 8) return 13;
+	struct octet_string *o = octet_string_new(malloc(4), 4);
+	struct metadata *m = hfdl_pdu_metadata_create();
+	if (o->len != 4 || m->vtable == NULL) return 14;
+	struct metadata *c = m->vtable->copy(m);
+	m->vtable->destroy(m);
+	c->vtable->destroy(c);
+	octet_string_destroy(o);
+	printf("graph ok\n");
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	int rc = 99;
+	if (argc >= 2 && !strcmp(argv[1], "ring")) rc = check_ring();
+	else if (argc >= 6 && !strcmp(argv[1], "file")) rc = check_file(argv[2], argv[3], atoi(argv[4]), argv[5]);
+	else if (argc >= 2 && !strcmp(argv[1], "graph")) rc = check_graph();
+	if (rc) fprintf(stderr, "host_check %s failed at step %d\n", argc > 1 ? argv[1] : "?", rc);
+	return rc;
+}

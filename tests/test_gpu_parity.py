@@ -182,3 +182,44 @@ def test_no_device_pointer_confusion(gpu):
     with pytest.raises(F.GpuError):
         fe.push_block(np.zeros(100, np.complex64))           # not a whole block
     fe.close()
+
+
+def _replay(tmp_path, x_raw, fmt, fs, cf, freqs):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "dumphfdl_amd", "hfdl_replay")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "dumphfdl_amd", "host")])
+    path = tmp_path / ("iq." + fmt.lower())
+    x_raw.tofile(path)
+    out = subprocess.run([exe, "--iq-file", str(path), "--sample-rate", str(fs), "--sample-format", fmt, "--centerfreq", str(cf / 1e3)]
+                         + ["%.3f" % (f / 1e3) for f in freqs], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    pdus = []
+    for line in out.stdout.splitlines():
+        if line.startswith("PDU "):
+            kv = dict(t.split("=") for t in line.split()[1:-1])
+            pdus.append((int(kv["freq"]), int(kv["bit_rate"]), kv["slot"], bytes.fromhex(line.split()[-1])))
+    return pdus
+
+
+@pytest.mark.parametrize("fmt", ["CF32", "CS16"])
+def test_host_c_program_end_to_end(gpu, oracle, tmp_path, fmt):
+    """The C host path: file input -> block ring -> GPU front-end block -> pdu_decoder_queue_push (printing default)."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_930_000, 10_037_000, 10_081_500]
+    bursts = synth.plan_traffic(freqs, 6.0, seed=3, dense=True)
+    x = synth.synth_wideband(fs, cf, int(6.0 * fs), bursts, noise_sigma=0.01, seed=1)
+    if fmt == "CS16":
+        raw = np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16)
+        x_in = (raw.astype(np.float32) / np.float32(32767.5)).view(np.complex64)       # what convert_cs16 produces
+    else:
+        raw, x_in = x.view(np.float32), x
+    got = _replay(tmp_path, raw, fmt, fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs)
+    n = ora.ddc.input_size
+    for b in range(len(x_in) // n):
+        ora.push_block(x_in[b * n:(b + 1) * n])
+    want = [(p["freq"], p["bit_rate"], p["slot"], p["octets"]) for p in ora.pdus]
+    assert sorted(got) == sorted(want) and len(got) == len(bursts)

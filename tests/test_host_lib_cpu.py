@@ -1,0 +1,70 @@
+"""CPU tests of libhfdl_host.so (plain-C block runtime / inputs keeping the reference's interface), driven from a small C
+program the way dumphfdl's main() drives the reference.  No GPU work: the front-end thread is never started here."""
+import os
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "dumphfdl_amd")
+
+
+@pytest.fixture(scope="module")
+def host_check(tmp_path_factory):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "host")])
+    exe = str(tmp_path_factory.mktemp("hc") / "host_check")
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "hostsim", "host_check.c"), "-o", exe,
+                           "-L", PKG, "-lhfdl_host", "-lhfdl_gpu", "-Wl,-rpath," + PKG, "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-lm"])
+    return exe
+
+
+def test_ring_and_overrun(host_check):
+    out = subprocess.run([host_check, "ring"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "Sample buffer overrun (4/6 samples lost)" in out.stderr       # the reference's message, src/input-helpers.c:85
+    assert "ring ok" in out.stdout
+
+
+def test_block_graph_contract(host_check):
+    out = subprocess.run([host_check, "graph"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
+@pytest.mark.parametrize("fmt,bufsize", [("CF32", 320000), ("CS16", 4096), ("CU8", 1000), ("CF32", 8)])
+def test_file_input_conversion(host_check, tmp_path, fmt, bufsize):
+    rng = np.random.default_rng(3)
+    n = 30011
+    if fmt == "CF32":
+        raw = rng.standard_normal(2 * n).astype(np.float32)
+        want = raw.view(np.complex64)
+    elif fmt == "CS16":
+        raw = rng.integers(-32768, 32768, 2 * n).astype(np.int16)
+        want = (raw.astype(np.float32) / np.float32(32767.5)).view(np.complex64)      # src/input-helpers.c:116
+    else:
+        raw = rng.integers(0, 256, 2 * n).astype(np.uint8)
+        want = ((raw.astype(np.float32) - np.float32(63.5)) / np.float32(127.0)).view(np.complex64)   # :108-113, :71
+    src, dst = tmp_path / "in.bin", tmp_path / "out.cf32"
+    raw.tofile(src)
+    out = subprocess.run([host_check, "file", str(src), fmt, str(bufsize), str(dst)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    got = np.fromfile(dst, np.complex64)
+    assert len(got) == n and np.array_equal(got, want)
+    assert ("max_tu %d " % (bufsize // {"CF32": 8, "CS16": 4, "CU8": 2}[fmt])) in out.stdout
+
+
+def test_file_input_rejects_bad_config(host_check, tmp_path):
+    src = tmp_path / "x.bin"
+    np.zeros(16, np.float32).tofile(src)
+    assert subprocess.run([host_check, "file", str(src), "CF32", "12", str(tmp_path / "o")], capture_output=True).returncode == 2
+    assert subprocess.run([host_check, "file", str(tmp_path / "missing"), "CF32", "80", str(tmp_path / "o")], capture_output=True).returncode == 2
+    assert subprocess.run([host_check, "file", str(src), "XX", "80", str(tmp_path / "o")], capture_output=True).returncode == 2
+
+
+def test_planner_abi_without_device():
+    import dumphfdl_amd as hf
+    g = hf.plan_geometry(4096, 250 / 40e6)
+    assert (g.fft_size, g.fft_inv_size, g.input_size, g.post_input_size, g.scrap, g.outputs_per_block) == \
+        (8388608, 4096, 7340032, 3584, 512, 1792)
+    with pytest.raises(hf.GpuError):
+        hf.plan_geometry(0, 0.001)
