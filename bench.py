@@ -45,7 +45,8 @@ def channel_plan(w):
 def make_input(w, geom_input_size, rank, world):
     """Seeded synthetic wideband stream: one single-slot burst per channel (modes cycle 300/600/1200/1800 bps) + AWGN."""
     from dumphfdl_amd import synth
-    seed = w["seed"] if world == 1 else 5 + rank        # SURVEY.md 8(d): cfg5 = independent streams, seeds 5..12
+    from dumphfdl_amd import shard
+    seed = shard.stream_seed(w["seed"], rank, world)
     nsamp = w["blocks"] * geom_input_size
     cache = "/tmp/hfdl_bench_%s_seed%d_%d.npy" % (w["fs"], seed, nsamp)
     freqs = channel_plan(w)
@@ -164,17 +165,12 @@ def main():
     elapsed = time.perf_counter() - t0
     fold_ms, fold_n = fe.fold_time_ms()
     barrier()
-    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([float(npdus)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    elapsed_max = float(tt.item())
-    total_pdus = int(cnt.item())
+    from dumphfdl_amd import shard
+    elapsed_max, total_samples, total_pdus = shard.reduce_job(elapsed, args.steps * g.input_size, npdus, dist, device="cuda")
 
     if rank == 0:
         good = sum(1 for p in pdus if any(p["octets"][:len(b["octets"])] == b["octets"] for b in bursts if b["freq"] == p["freq"]))
-        samples = world * args.steps * g.input_size
+        samples = total_samples
         # B = 8*input_size + C*8*N + C*8*(post_input_size/post_decimation) algorithmic bytes per block
         alg_bytes = 8 * g.input_size + g.channels * 8 * g.fft_size + g.channels * 8 * (g.post_input_size // g.post_decimation)
         fold_avg_ms = fold_ms / max(fold_n, 1)

@@ -1,0 +1,59 @@
+"""The N>1 path on CPU: two gloo ranks shard streams / channels with no data-path collective and reduce the job totals."""
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from dumphfdl_amd import shard
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r, lr, w = shard.env_rank()
+    freqs = bench.channel_plan(bench.WORKLOADS["cfg2"])
+    mine = shard.shard_channels(freqs, r, w)
+    seed = shard.stream_seed(3, r, w)
+    # every rank "processes" 10 blocks of its own stream; rank 1 is slower
+    elapsed, samples, pdus = shard.reduce_job(0.5 + 0.25 * r, 10 * 917504, 7 + r, dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((r, w, mine, seed, elapsed, samples, pdus))
+
+
+def test_two_rank_sharding_and_reduction():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    import bench
+    freqs = bench.channel_plan(bench.WORKLOADS["cfg2"])
+    a, b = res
+    assert sorted(a[2] + b[2]) == sorted(freqs) and not set(a[2]) & set(b[2])         # partition, no overlap
+    assert (a[3], b[3]) == (5, 6)                                                     # independent stream seeds
+    for r in res:
+        assert r[4] == pytest.approx(0.75) and r[5] == 2 * 10 * 917504 and r[6] == 15  # max time, summed work
+
+
+def test_single_rank_is_passthrough():
+    sys.path.insert(0, ROOT)
+    from dumphfdl_amd import shard
+    assert shard.reduce_job(1.5, 100, 3) == (1.5, 100, 3)
+    assert shard.stream_seed(3, 0, 1) == 3
+    assert shard.shard_channels([1, 2, 3], 0, 1) == [1, 2, 3]
