@@ -222,9 +222,36 @@ HFDL_FN void psk_soft(int arity, cf x, uint8_t *soft)
 
 // ---------------- helpers of the sequential stage ----------------
 
+#if HFDL_LANES > 1
+// Sum of v over lanes 0..15, returned wave-uniform.  Four DPP row_shr steps build an inclusive scan inside the
+// 16-lane row (lanes shifted in from outside the row read 0), lane 15 then holds the total.
+HFDL_FN float row16_sum(float v)
+{
+	int x = __float_as_int(v);
+	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true)));
+	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true)));
+	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true)));
+	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));
+	return __int_as_float(__builtin_amdgcn_readlane(x, 15));
+}
+#endif
+
 // sum_t h[t] * win[(head - t) mod 18] : polyphase branch output, newest sample first
 HFDL_FN cf bank_dot(const float *h, const cf *win, int head)
 {
+#if HFDL_LANES > 1
+	// lanes 0..15 take taps t and t+16 (18 taps), then one row reduction per component
+	const int t = HFDL_LANE & 15;
+	int i0 = head - t; if (i0 < 0) i0 += D_SS_TAPS;
+	float pr = h[t] * win[i0].x, pi = h[t] * win[i0].y;
+	if (t + 16 < D_SS_TAPS) {
+		int i1 = head - t - 16; if (i1 < 0) i1 += D_SS_TAPS;
+		pr += h[t + 16] * win[i1].x; pi += h[t + 16] * win[i1].y;
+	}
+	if (HFDL_LANE >= 16) { pr = 0.f; pi = 0.f; }
+	cf r; r.x = row16_sum(pr); r.y = row16_sum(pi);
+	return r;
+#else
 	float ar = 0, ai = 0;
 	int idx = head;
 	for (int t = 0; t < D_SS_TAPS; t++) {
@@ -234,6 +261,7 @@ HFDL_FN cf bank_dot(const float *h, const cf *win, int head)
 	}
 	cf y; y.x = ar; y.y = ai;
 	return y;
+#endif
 }
 
 HFDL_FN void symsync_reset(ChanScalars &s, ChanArrays &a)
@@ -568,7 +596,12 @@ HFDL_FN int demod_block(ChanScalars &s, ChanArrays &a, const DemodConst &T, cons
 			s.phi += s.dphi;
 			if (s.phi > (float)M_PI) s.phi -= (float)(2.0 * M_PI);
 			else if (s.phi < -(float)M_PI) s.phi += (float)(2.0 * M_PI);
+#if HFDL_LANES > 1
+			float sp, cp;
+			sincosf(s.phi, &sp, &cp);            // one shared range reduction
+#else
 			const float cp = cosf(s.phi), sp = sinf(s.phi);
+#endif
 			cf r;
 			r.x = out[i].x * cp + out[i].y * sp;
 			r.y = out[i].y * cp - out[i].x * sp;
@@ -588,6 +621,19 @@ HFDL_FN int demod_block(ChanScalars &s, ChanArrays &a, const DemodConst &T, cons
 			if (!(s.symsync_out_idx & 1u)) continue;
 			// eqlms_cccf_execute: sum conj(w_i) x_i, x_0 oldest
 			cf y; y.x = 0.f; y.y = 0.f;
+#if HFDL_LANES > 1
+			{   // lane t < 15 owns tap t
+				const int t = lane & 15;
+				int idx = s.eq_head + t; if (idx >= D_EQ) idx -= D_EQ;
+				float pr = 0.f, pi = 0.f;
+				if (lane < D_EQ) {
+					const cf w = a.eq_w[t], x = a.eq_buf[idx];
+					pr = w.x * x.x + w.y * x.y;
+					pi = w.x * x.y - w.y * x.x;
+				}
+				y.x = row16_sum(pr); y.y = row16_sum(pi);
+			}
+#else
 			{
 				int idx = s.eq_head;
 				for (int t = 0; t < D_EQ; t++) {
@@ -597,6 +643,7 @@ HFDL_FN int demod_block(ChanScalars &s, ChanArrays &a, const DemodConst &T, cons
 					idx = idx + 1 == D_EQ ? 0 : idx + 1;
 				}
 			}
+#endif
 			if (s.fr_state == FR_EQ_TRAIN) {
 				// eqlms_cccf_step(d = known T symbol, d_hat = y)
 				bool run = true;
@@ -604,6 +651,15 @@ HFDL_FN int demod_block(ChanScalars &s, ChanArrays &a, const DemodConst &T, cons
 				if (run) {
 					const float tv = t_symbol(s.T_idx) * ((s.bitmask & 1u) ? -1.0f : 1.0f);
 					const float er = tv - y.x, ei = -(0.0f - y.y);
+#if HFDL_LANES > 1
+					if (lane < D_EQ) {
+						int idx = s.eq_head + lane; if (idx >= D_EQ) idx -= D_EQ;
+						const cf x = a.eq_buf[idx];
+						const float pr = er * x.x - ei * x.y, pi = er * x.y + ei * x.x;
+						a.eq_w[lane].x = a.eq_w[lane].x + 0.1f * pr / s.eq_x2sum;
+						a.eq_w[lane].y = a.eq_w[lane].y + 0.1f * pi / s.eq_x2sum;
+					}
+#else
 					int idx = s.eq_head;
 					for (int t = 0; t < D_EQ; t++) {
 						const cf x = a.eq_buf[idx];
@@ -612,6 +668,7 @@ HFDL_FN int demod_block(ChanScalars &s, ChanArrays &a, const DemodConst &T, cons
 						a.eq_w[t].y = a.eq_w[t].y + 0.1f * pi / s.eq_x2sum;
 						idx = idx + 1 == D_EQ ? 0 : idx + 1;
 					}
+#endif
 				}
 				s.T_idx++;
 			}

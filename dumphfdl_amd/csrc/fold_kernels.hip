@@ -26,38 +26,48 @@ __device__ __forceinline__ float4 load_stream(const float4 *p)
 	return make_float4(v.x, v.y, v.z, v.w);
 }
 
-template <int U>
+// U float4 (= 2U bins) per thread per alias row; NT = non-temporal tap loads; R = alias rows per loop trip;
+// CS = column split: a workgroup covers 1/CS of a row (more, lighter workgroups -> more waves per SIMD)
+template <int U, bool NT, int R, int CS>
 __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__restrict__ taps, const float4 *__restrict__ spec,
 		float4 *__restrict__ partial, size_t n, int m, int slices, int rows)
 {
-	const int s = blockIdx.x % slices, c = blockIdx.x / slices;
+	const int cpart = blockIdx.x % CS;
+	const int bs = blockIdx.x / CS;
+	const int s = bs % slices, c = bs / slices;
 	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row
-	const size_t off = ((size_t)s * rows * (size_t)m) >> 1;
+	const size_t off = (((size_t)s * rows * (size_t)m) >> 1) + (size_t)cpart * U * FOLD_THREADS;
 	const float4 *tp = taps + (((size_t)c * n) >> 1) + off + threadIdx.x;
 	const float4 *sp = spec + off + threadIdx.x;
 	float4 acc[U];
 #pragma unroll
 	for (int u = 0; u < U; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-	const bool live = (U > 1) || ((int)threadIdx.x < row4);
+	const bool live = (U * CS > 1) || ((int)threadIdx.x < row4);
 	if (live) {
-		for (int r = 0; r < rows; r++) {
-			float4 h[U], x[U];
+		for (int r = 0; r < rows; r += R) {
+			float4 h[R][U], x[R][U];
 #pragma unroll
-			for (int u = 0; u < U; u++) {
-				h[u] = load_stream(tp + u * FOLD_THREADS);
-				x[u] = sp[u * FOLD_THREADS];
+			for (int q = 0; q < R; q++) {
+#pragma unroll
+				for (int u = 0; u < U; u++) {
+					h[q][u] = NT ? load_stream(tp + (size_t)q * row4 + u * FOLD_THREADS) : tp[(size_t)q * row4 + u * FOLD_THREADS];
+					x[q][u] = sp[(size_t)q * row4 + u * FOLD_THREADS];
+				}
 			}
 #pragma unroll
-			for (int u = 0; u < U; u++) {
-				acc[u].x += h[u].x * x[u].x - h[u].y * x[u].y;
-				acc[u].y += h[u].x * x[u].y + h[u].y * x[u].x;
-				acc[u].z += h[u].z * x[u].z - h[u].w * x[u].w;
-				acc[u].w += h[u].z * x[u].w + h[u].w * x[u].z;
+			for (int q = 0; q < R; q++) {
+#pragma unroll
+				for (int u = 0; u < U; u++) {
+					acc[u].x += h[q][u].x * x[q][u].x - h[q][u].y * x[q][u].y;
+					acc[u].y += h[q][u].x * x[q][u].y + h[q][u].y * x[q][u].x;
+					acc[u].z += h[q][u].z * x[q][u].z - h[q][u].w * x[q][u].w;
+					acc[u].w += h[q][u].z * x[q][u].w + h[q][u].w * x[q][u].z;
+				}
 			}
-			tp += row4;
-			sp += row4;
+			tp += (size_t)R * row4;
+			sp += (size_t)R * row4;
 		}
-		float4 *po = partial + (((size_t)c * slices + s) * (size_t)m >> 1) + threadIdx.x;
+		float4 *po = partial + (((size_t)c * slices + s) * (size_t)m >> 1) + (size_t)cpart * U * FOLD_THREADS + threadIdx.x;
 #pragma unroll
 		for (int u = 0; u < U; u++) po[u * FOLD_THREADS] = acc[u];
 	}
@@ -84,23 +94,26 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel_generic(const float2
 
 void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st)
 {
-	const dim3 grid((unsigned)(g.nch * g.slices)), block(FOLD_THREADS);
+	const dim3 block(FOLD_THREADS);
 	const size_t n = (size_t)g.n;
 	const int u = g.m / (2 * FOLD_THREADS);
-#define FOLD_CASE(U) hipLaunchKernelGGL(fold_kernel<U>, grid, block, 0, st, (const float4 *)taps, (const float4 *)spectrum, \
-		(float4 *)partial, n, g.m, g.slices, g.rows_per_slice)
+#define FOLD_LAUNCH(U, NT, R, CS) hipLaunchKernelGGL((fold_kernel<U, NT, R, CS>), dim3((unsigned)(g.nch * g.slices * CS)), block, 0, st, \
+		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, n, g.m, g.slices, g.rows_per_slice)
+	// variants measured on cfg3 (profiles/r01_experiments.md): non-temporal taps +7 %, two rows per trip +0.5 %,
+	// column-split (lighter, more numerous workgroups) -1..-8 %, S = 4..16 slices flat, S >= 32 slower
 	if (g.m == 2 * FOLD_THREADS * u && u >= 1) {
+		if (u == 8 && (g.rows_per_slice % 2) == 0) { FOLD_LAUNCH(8, true, 2, 1); return; }
 		switch (u) {
-		case 1: FOLD_CASE(1); return;
-		case 2: FOLD_CASE(2); return;
-		case 4: FOLD_CASE(4); return;
-		case 8: FOLD_CASE(8); return;
-		case 16: FOLD_CASE(16); return;
+		case 1: FOLD_LAUNCH(1, true, 1, 1); return;
+		case 2: FOLD_LAUNCH(2, true, 1, 1); return;
+		case 4: FOLD_LAUNCH(4, true, 1, 1); return;
+		case 8: FOLD_LAUNCH(8, true, 1, 1); return;
+		case 16: FOLD_LAUNCH(16, true, 1, 1); return;
 		default: break;
 		}
 	}
-	hipLaunchKernelGGL(fold_kernel_generic, grid, block, 0, st, taps, spectrum, partial, n, g.m, g.slices, g.rows_per_slice);
-#undef FOLD_CASE
+	hipLaunchKernelGGL(fold_kernel_generic, dim3((unsigned)(g.nch * g.slices)), block, 0, st, taps, spectrum, partial, n, g.m, g.slices, g.rows_per_slice);
+#undef FOLD_LAUNCH
 }
 
 // ---- inverse FFT + scrap + NCO/decimate : one workgroup per channel, M bins in LDS ----

@@ -238,7 +238,11 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	int rc_ = fail(e_ == hipErrorOutOfMemory ? HFDL_GPU_ENOMEM : HFDL_GPU_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
 	frontend_free(fe); return rc_; } } while (0)
 	FE_TRY(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
-	FE_TRY(hipStreamCreateWithFlags(&fe->stream_b, hipStreamNonBlocking));
+	{
+		// measured on MI355X: stream priority (hi/lo) and CU-masking of this stream change nothing beyond run-to-run
+		// noise (profiles/r01_experiments.md), so a plain non-blocking stream is used
+		FE_TRY(hipStreamCreateWithFlags(&fe->stream_b, hipStreamNonBlocking));
+	}
 	for (int i = 0; i < 2; i++) {
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_chan[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_demod[i], hipEventDisableTiming));

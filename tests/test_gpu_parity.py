@@ -223,3 +223,60 @@ def test_host_c_program_end_to_end(gpu, oracle, tmp_path, fmt):
         ora.push_block(x_in[b * n:(b + 1) * n])
     want = [(p["freq"], p["bit_rate"], p["slot"], p["octets"]) for p in ora.pdus]
     assert sorted(got) == sorted(want) and len(got) == len(bursts)
+
+
+def test_burst_dense_all_modes_cfg4_shape(gpu, oracle):
+    """BASELINE.json configs[3] in miniature: every channel carries back-to-back bursts cycling all 8 modes
+    (300/600/1200/1800 bps, single + double slot).  PDU multiset must equal the oracle's, payloads what was sent."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000]
+    dur = 31.0
+    bursts = synth.plan_traffic(freqs, dur, seed=4, dense=True, gap_s=0.12, amp=(0.03, 0.12))
+    assert {b["mode"] for b in bursts} == set(range(8))
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.01, seed=4)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["slot"], p["bit_rate"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    assert len(got) >= len(bursts) - 1
+    for p in got:
+        assert any(p["octets"][:len(b["octets"])] == b["octets"] and p["mode"] == b["mode"] for b in bursts if b["freq"] == p["freq"])
+        assert len(p["octets"]) == synth.mode_sizes(p["mode"])["octets"]
+
+
+def test_degenerate_inputs(gpu, oracle):
+    """All-zero input, a single channel at the band edge, full-scale noise: no PDUs, no NaNs, stages still match the oracle."""
+    fs, cf = 250000, 10_000_000
+    freqs = [cf + 110_000]                              # 0.44 fs from centre
+    fe = gpu.Frontend(fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs)
+    n = fe.input_size
+    rng = np.random.default_rng(0)
+    blocks = [np.zeros(n, np.complex64), np.zeros(n, np.complex64),
+              (0.7 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64),
+              np.zeros(n, np.complex64)]
+    for blk in blocks:
+        fe.push_block(blk)
+        ora.push_block(blk)
+        got = fe.read_tap(F.TAP_CHAN_OUT, 0)
+        want = ora.channel_view(0)["chan_out"]
+        assert np.isfinite(got.view(np.float32)).all()
+        assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-12) + 1e-12
+        lv, lw = fe.read_tap(F.TAP_AGC_LEVEL, 0), ora.channel_view(0)["agc_level"]
+        assert len(lv) == len(lw) and np.isfinite(lv).all()
+        assert np.allclose(lv, lw, rtol=2e-3, atol=1e-12)
+    assert fe.poll_pdus() == [] and ora.pdus == []
+    fe.close()
+
+
+def test_many_frames_in_one_block(gpu, oracle):
+    """64 channels whose bursts end inside the same block: the burst-decoder queue takes them all at once."""
+    fs, cf = 1_000_000, 10_000_000
+    freqs = [int(cf + (i - 32) * 14_000 + 3_000) for i in range(64)]
+    rng = np.random.default_rng(12)
+    bursts = [dict(freq=f, mode=int(i % 4), octets=synth.make_pdu(rng, int(i % 4)), t0=0.3, amp=0.02, cfo=float(rng.uniform(-8, 8)))
+              for i, f in enumerate(freqs)]
+    x = synth.synth_wideband(fs, cf, int(3.1 * fs), bursts, noise_sigma=0.004, seed=6)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    assert len(got) >= 60
