@@ -194,6 +194,7 @@ def main():
                        "parallelism": "1 independent %d-channel stream per GPU, no collectives" % g.channels},
             "frames_per_s": total_pdus / elapsed_max, "pdus_in_timed_region": total_pdus,
             "pdus_rank0_matching_sent_payload": good,
+            "pdus_rank0_fcs_good_on_device": sum(1 for p in pdus if p["fcs_status"] == 0),
             "roofline": {"bound": "hbm", "kernel": "fold_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n},

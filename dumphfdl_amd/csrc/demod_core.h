@@ -220,6 +220,46 @@ HFDL_FN void psk_soft(int arity, cf x, uint8_t *soft)
 	for (int k = 0; k < arity; k++) soft[k] = soft_clamp(((d0[k] - d1[k]) * gamma) * 16);
 }
 
+// ---------------- PDU header triage: FCS = CRC-16/X-25 over the header, stored low octet first ----------------
+// hfdl_pdu_fcs_check (src/pdu.c:68-79), header length rules of mpdu_parse (src/mpdu.c:56-79) and spdu_parse (src/spdu.c:12,55-62)
+
+HFDL_FN uint16_t crc16_x25(const uint8_t *p, uint32_t len)
+{
+	uint32_t crc = 0xFFFFu;
+	for (uint32_t i = 0; i < len; i++) {
+		crc ^= p[i];
+		for (int b = 0; b < 8; b++) crc = (crc & 1u) ? (crc >> 1) ^ 0x8408u : crc >> 1;
+	}
+	return (uint16_t)(crc ^ 0xFFFFu);
+}
+
+// returns fcs status (0 good, 1 bad, 2 too short); kind: 0 SPDU, 1 MPDU downlink, 2 MPDU uplink
+HFDL_FN int pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hdr_len_out)
+{
+	uint32_t hdr_len;
+	if ((buf[0] & 1u) == 0) {
+		*kind = 0;
+		hdr_len = 64;
+		*hdr_len_out = hdr_len;
+		if (len < 66) return 2;
+	} else if (buf[0] & 0x2u) {
+		*kind = 1;
+		hdr_len = 6 + ((buf[0] >> 2) & 0xFu);
+	} else {
+		*kind = 2;
+		const uint32_t aircraft_cnt = ((buf[0] & 0x70u) >> 4) + 1;
+		hdr_len = 2;
+		for (uint32_t i = 0; i < aircraft_cnt; i++) {
+			if (len < hdr_len + 2) { *hdr_len_out = hdr_len; return 2; }
+			hdr_len += 2 + (buf[hdr_len + 1] >> 4);
+		}
+	}
+	*hdr_len_out = hdr_len;
+	if (len < hdr_len + 2) return 2;
+	const uint16_t rx = (uint16_t)(buf[hdr_len] | (buf[hdr_len + 1] << 8));
+	return rx == crc16_x25(buf, hdr_len) ? 0 : 1;
+}
+
 // ---------------- helpers of the sequential stage ----------------
 
 #if HFDL_LANES > 1

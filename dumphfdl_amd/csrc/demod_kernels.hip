@@ -197,6 +197,11 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 		out->sample_index = fr.sample_index;
 		out->train_bits_bad = fr.train_bad;
 		out->train_bits_total = fr.train_total;
+		int kind = 0;
+		uint32_t hdr_len = 0;
+		out->fcs_status = (uint8_t)pdu_triage(out->octets, (uint32_t)noct, &kind, &hdr_len);   // same lane wrote the octets
+		out->pdu_kind = (uint8_t)kind;
+		out->hdr_len = (uint16_t)hdr_len;
 	}
 }
 

@@ -12,9 +12,25 @@
 
 namespace hfdl {
 
+// raw sample -> float complex with the reference's scaling: convert_cf32 / convert_cs16 / convert_cu8
+// (src/input-helpers.c:10-78; full scale 1.0 / 32767.5 / 127, cu8 offset = full_scale / 2 as written there)
+template <int FMT>
+__device__ __forceinline__ float2 load_sample(const void *__restrict__ raw, int i)
+{
+	if (FMT == SFMT_CS16) {
+		const short2 v = ((const short2 *)raw)[i];
+		return make_float2((float)v.x / 32767.5f, (float)v.y / 32767.5f);
+	} else if (FMT == SFMT_CU8) {
+		const uchar2 v = ((const uchar2 *)raw)[i];
+		return make_float2(((float)v.x - 63.5f) / 127.0f, ((float)v.y - 63.5f) / 127.0f);
+	}
+	return ((const float2 *)raw)[i];
+}
+
 // pass 1: columns c = n2*R3+n3 (stride R2*R3 between the R1 samples of a column).  Input is the
 // virtual concatenation [hist(split) , fresh(n-split)] -- the overlap assembly of src/fft.c:49-54.
-__global__ __launch_bounds__(FFT_THREADS) void fft_pass1(const float2 *__restrict__ hist, const float2 *__restrict__ fresh,
+template <int FMT>
+__global__ __launch_bounds__(FFT_THREADS) void fft_pass1(const float2 *__restrict__ hist, const void *__restrict__ fresh,
 		int split, float2 *__restrict__ out, FftPlan p)
 {
 	extern __shared__ float2 sm[];
@@ -27,7 +43,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass1(const float2 *__restric
 		float2 v = make_float2(0.f, 0.f);
 		if (c < cs) {
 			const int idx = r * cs + c;
-			v = idx < split ? hist[idx] : fresh[idx - split];
+			v = idx < split ? hist[idx] : load_sample<FMT>(fresh, idx - split);
 		}
 		sm[e] = v;
 	}
@@ -109,27 +125,39 @@ __global__ void copy_tail_kernel(const float4 *__restrict__ src, float4 *__restr
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-void launch_fft_forward(const FftPlan &p, const float2 *hist, const float2 *fresh, int split,
+void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split,
 		float2 *work, float2 *out, bool shifted, hipStream_t st)
 {
 	const int c1 = (p.n >> p.l1), c2 = p.r1 * p.r3, c3 = p.r1 * p.r2;
-	hipLaunchKernelGGL(fft_pass1, dim3((c1 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), p.r1 * FFT_TILE * sizeof(float2), st,
-			hist, fresh, split, work, p);
+	const dim3 g1((c1 + FFT_TILE - 1) / FFT_TILE), blk(FFT_THREADS);
+	const size_t l1 = p.r1 * FFT_TILE * sizeof(float2);
+	if (fmt == SFMT_CS16) hipLaunchKernelGGL(fft_pass1<SFMT_CS16>, g1, blk, l1, st, hist, fresh, split, work, p);
+	else if (fmt == SFMT_CU8) hipLaunchKernelGGL(fft_pass1<SFMT_CU8>, g1, blk, l1, st, hist, fresh, split, work, p);
+	else hipLaunchKernelGGL(fft_pass1<SFMT_CF32>, g1, blk, l1, st, hist, fresh, split, work, p);
 	hipLaunchKernelGGL(fft_pass2, dim3((c2 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), p.r2 * FFT_TILE * sizeof(float2), st,
 			work, p);
 	hipLaunchKernelGGL(fft_pass3, dim3((c3 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), p.r3 * FFT_TILE * sizeof(float2), st,
 			(const float2 *)work, out, p, shifted ? 1 : 0);
 }
 
-// hist <- last `overlap` samples of this block's input (input_size >= overlap always: N >= 4*taps_length)
-void launch_copy_tail(const float2 *fresh, float2 *hist, int input_size, int overlap, hipStream_t st)
+template <int FMT>
+__global__ void convert_tail_kernel(const void *__restrict__ raw, float2 *__restrict__ dst, int first, int n)
 {
-	const float2 *src = fresh + (input_size - overlap);
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = load_sample<FMT>(raw, first + i);
+}
+
+// hist <- last `overlap` samples of this block's input (input_size >= overlap always: N >= 4*taps_length)
+void launch_copy_tail(const void *fresh, int fmt, float2 *hist, int input_size, int overlap, hipStream_t st)
+{
+	const int first = input_size - overlap;
+	if (fmt == SFMT_CS16) { hipLaunchKernelGGL(convert_tail_kernel<SFMT_CS16>, dim3(512), dim3(256), 0, st, fresh, hist, first, overlap); return; }
+	if (fmt == SFMT_CU8) { hipLaunchKernelGGL(convert_tail_kernel<SFMT_CU8>, dim3(512), dim3(256), 0, st, fresh, hist, first, overlap); return; }
+	const float2 *src = (const float2 *)fresh + first;
 	if ((((uintptr_t)src | (uintptr_t)hist) & 15) == 0 && (overlap & 1) == 0) {
 		size_t n4 = (size_t)overlap / 2;
 		hipLaunchKernelGGL(copy_tail_kernel, dim3(512), dim3(256), 0, st, (const float4 *)src, (float4 *)hist, n4);
 	} else {
-		hipMemcpyAsync(hist, src, sizeof(float2) * (size_t)overlap, hipMemcpyDeviceToDevice, st);
+		(void)hipMemcpyAsync(hist, src, sizeof(float2) * (size_t)overlap, hipMemcpyDeviceToDevice, st);
 	}
 }
 

@@ -195,7 +195,7 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	for (int c = 0; c < nch; c++) {
 		HIP_TRY(hipMemcpyAsync(d_pad, host.data() + (size_t)c * pl.taps_length, sizeof(float2) * (size_t)pl.taps_length,
 				hipMemcpyHostToDevice, fe->stream));
-		launch_fft_forward(fe->fft.p, nullptr, d_pad, 0, fe->d_work, fe->d_taps + (size_t)c * n, true, fe->stream);
+		launch_fft_forward(fe->fft.p, nullptr, d_pad, SFMT_CF32, 0, fe->d_work, fe->d_taps + (size_t)c * n, true, fe->stream);
 	}
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipGetLastError());
@@ -321,13 +321,16 @@ extern "C" void hfdl_gpu_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr);
 
 extern "C" void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe) { return fe ? (void *)fe->stream : nullptr; }
 
-static int stage_input(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device, const float2 **dev)
+static size_t sample_bytes(int fmt) { return fmt == SFMT_CS16 ? 4 : fmt == SFMT_CU8 ? 2 : 8; }
+
+static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, int fmt, int on_device, const void **dev)
 {
 	if (!fe || !iq) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (fmt != SFMT_CF32 && fmt != SFMT_CS16 && fmt != SFMT_CU8) return fail(HFDL_GPU_EINVAL, "unknown sample format %d", fmt);
 	if (nsamples != (size_t)fe->plan.input_size)
 		return fail(HFDL_GPU_EINVAL, "a block is exactly %d samples (got %zu)", fe->plan.input_size, nsamples);
 	HIP_TRY(hipSetDevice(fe->device));
-	if (on_device) { *dev = (const float2 *)iq; return 0; }
+	if (on_device) { *dev = iq; return 0; }
 	if (fe->stage_cap < nsamples) {
 		if (fe->d_stage) (void)hipFree(fe->d_stage);
 		fe->d_stage = nullptr; fe->stage_cap = 0;
@@ -335,20 +338,20 @@ static int stage_input(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, 
 		fe->stage_cap = nsamples;
 	}
 	// the staging buffer is reused block after block: same-stream ordering makes that safe
-	HIP_TRY(hipMemcpyAsync(fe->d_stage, iq, sizeof(float2) * nsamples, hipMemcpyHostToDevice, fe->stream));
+	HIP_TRY(hipMemcpyAsync(fe->d_stage, iq, sample_bytes(fmt) * nsamples, hipMemcpyHostToDevice, fe->stream));
 	*dev = fe->d_stage;
 	return 0;
 }
 
 // Stream A runs the channelizer of block k into buffer k&1; stream B demodulates it.  A may not overwrite a buffer
 // before B has finished with it (two blocks ago); B may not start before A has filled it.
-static int enqueue_channelizer(hfdl_gpu_frontend *fe, const float2 *fresh, int *buf_out)
+static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int *buf_out)
 {
 	const Geometry &g = fe->geo;
 	const int buf = (int)(fe->blocks & 1);
 	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_demod[buf], 0));
-	launch_fft_forward(fe->fft.p, fe->d_hist, fresh, g.overlap, fe->d_work, fe->d_spec, true, fe->stream);
-	launch_copy_tail(fresh, fe->d_hist, g.input_size, g.overlap, fe->stream);
+	launch_fft_forward(fe->fft.p, fe->d_hist, fresh, fmt, g.overlap, fe->d_work, fe->d_spec, true, fe->stream);
+	launch_copy_tail(fresh, fmt, fe->d_hist, g.input_size, g.overlap, fe->stream);
 	if (fe->timing) {
 		std::pair<hipEvent_t, hipEvent_t> e;
 		HIP_TRY(hipEventCreate(&e.first));
@@ -371,24 +374,34 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const float2 *fresh, int *
 
 extern "C" int hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
 {
-	const float2 *fresh = nullptr;
-	int rc = stage_input(fe, iq, nsamples, on_device, &fresh);
+	const void *fresh = nullptr;
+	int rc = stage_input(fe, iq, nsamples, SFMT_CF32, on_device, &fresh);
 	if (rc) return rc;
-	return enqueue_channelizer(fe, fresh, nullptr);
+	return enqueue_channelizer(fe, fresh, SFMT_CF32, nullptr);
 }
 
-extern "C" int hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
+static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int fmt, int on_device)
 {
-	const float2 *fresh = nullptr;
+	const void *fresh = nullptr;
 	int buf = 0;
-	int rc = stage_input(fe, iq, nsamples, on_device, &fresh);
+	int rc = stage_input(fe, raw, nsamples, fmt, on_device, &fresh);
 	if (rc) return rc;
-	if ((rc = enqueue_channelizer(fe, fresh, &buf))) return rc;
+	if ((rc = enqueue_channelizer(fe, fresh, fmt, &buf))) return rc;
 	HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
 	rc = fe->demod.enqueue_block(fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream_b);
 	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_b));
 	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
+{
+	return push_any(fe, iq, nsamples, SFMT_CF32, on_device);
+}
+
+extern "C" int hfdl_gpu_frontend_push_block_raw(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int sample_format, int on_device)
+{
+	return push_any(fe, raw, nsamples, sample_format, on_device);
 }
 
 static int drain_events(hfdl_gpu_frontend *fe)
@@ -483,7 +496,7 @@ extern "C" int hfdl_gpu_fft_forward(int device, const float *in, float *out, int
 	HIP_TRY(hipMalloc(&d_work, sizeof(float2) * (size_t)n));
 	HIP_TRY(hipMalloc(&d_out, sizeof(float2) * (size_t)n));
 	HIP_TRY(hipMemcpy(d_in, in, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
-	launch_fft_forward(plan.p, nullptr, d_in, 0, d_work, d_out, shifted != 0, nullptr);
+	launch_fft_forward(plan.p, nullptr, d_in, SFMT_CF32, 0, d_work, d_out, shifted != 0, nullptr);
 	HIP_TRY(hipDeviceSynchronize());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpy(out, d_out, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost));

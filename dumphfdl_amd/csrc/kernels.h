@@ -37,11 +37,13 @@ struct Geometry {
 };
 
 // ---- launchers (host side, defined next to their kernels) ----
-void launch_fft_forward(const FftPlan &p, const float2 *hist, const float2 *fresh, int split,
+// sample formats of the raw ingest path (reference: src/input-helpers.c:10-78,108-125)
+enum { SFMT_CF32 = 0, SFMT_CS16 = 1, SFMT_CU8 = 2 };
+void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split,
 		float2 *work, float2 *out, bool shifted, hipStream_t st);
 void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st);
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
 		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st);
-void launch_copy_tail(const float2 *fresh, float2 *hist, int input_size, int overlap, hipStream_t st);
+void launch_copy_tail(const void *fresh, int fmt, float2 *hist, int input_size, int overlap, hipStream_t st);
 
 }  // namespace hfdl

@@ -10,6 +10,11 @@ PDU_MAX_OCTETS = 960
 TAP_SPECTRUM, TAP_FILTER, TAP_CHAN_OUT, TAP_RESAMPLED, TAP_MF_OUT, TAP_SYMBOLS, TAP_AGC_LEVEL = range(1, 8)
 
 
+SFMT_CF32, SFMT_CS16, SFMT_CU8 = 0, 1, 2
+FCS_GOOD, FCS_BAD, FCS_TOO_SHORT = 0, 1, 2
+KIND_SPDU, KIND_MPDU_DOWNLINK, KIND_MPDU_UPLINK = 0, 1, 2
+
+
 class GpuError(RuntimeError):
     pass
 
@@ -24,7 +29,8 @@ class Geometry(C.Structure):
 class Pdu(C.Structure):
     _fields_ = [("channel", C.c_int32), ("freq", C.c_int32), ("mode", C.c_int32), ("bit_rate", C.c_int32),
                 ("len", C.c_int32), ("freq_err_hz", C.c_float), ("rssi_db", C.c_float), ("noise_floor_db", C.c_float),
-                ("slot", C.c_char), ("sample_index", C.c_uint64),
+                ("slot", C.c_char), ("fcs_status", C.c_uint8), ("pdu_kind", C.c_uint8), ("hdr_len", C.c_uint16),
+                ("sample_index", C.c_uint64),
                 ("train_bits_bad", C.c_int32), ("train_bits_total", C.c_int32),
                 ("octets", C.c_uint8 * PDU_MAX_OCTETS)]
 
@@ -38,7 +44,7 @@ _lib = None
 EXPORTS = [
     "hfdl_gpu_plan_geometry", "hfdl_gpu_host_alloc", "hfdl_gpu_host_free",
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
-    "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
+    "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode",
@@ -70,6 +76,7 @@ def load():
     L.hfdl_gpu_frontend_geometry.argtypes = [C.c_void_p, C.POINTER(Geometry)]
     L.hfdl_gpu_frontend_push_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.hfdl_gpu_frontend_channelize_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hfdl_gpu_frontend_push_block_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     L.hfdl_gpu_frontend_sync.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_poll_pdus.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.hfdl_gpu_frontend_stream.argtypes = [C.c_void_p]
@@ -132,6 +139,12 @@ class Frontend:
             _check(L.hfdl_gpu_frontend_push_block(self._h, _p(s), len(s), 0))
             # the copy is enqueued asynchronously from pageable memory: HIP stages it before returning
 
+    def push_block_raw(self, raw, sample_format):
+        """raw: int16 (SFMT_CS16) / uint8 (SFMT_CU8) / float32 (SFMT_CF32) numpy array of 2*input_size interleaved I,Q values."""
+        dt = {SFMT_CF32: np.float32, SFMT_CS16: np.int16, SFMT_CU8: np.uint8}[sample_format]
+        r = np.ascontiguousarray(raw, dtype=dt)
+        _check(load().hfdl_gpu_frontend_push_block_raw(self._h, _p(r), len(r) // 2, sample_format, 0))
+
     def channelize_block(self, samples):
         L = load()
         if isinstance(samples, int):
@@ -153,6 +166,7 @@ class Frontend:
             out.append(dict(channel=p.channel, freq=p.freq, mode=p.mode, bit_rate=p.bit_rate,
                             octets=bytes(p.octets[:p.len]), freq_err_hz=p.freq_err_hz, rssi_db=p.rssi_db,
                             noise_floor_db=p.noise_floor_db, slot=p.slot.decode(), sample_index=p.sample_index,
+                            fcs_status=p.fcs_status, pdu_kind=p.pdu_kind, hdr_len=p.hdr_len,
                             train_bits_bad=p.train_bits_bad, train_bits_total=p.train_bits_total))
         return out
 

@@ -38,6 +38,14 @@ extern "C" {
 
 #define HFDL_GPU_PDU_MAX_OCTETS 960
 
+/* on-device header triage of a decoded PDU (what mpdu_parse / spdu_parse do first: src/mpdu.c:56-89, src/spdu.c:55-62) */
+#define HFDL_GPU_FCS_GOOD      0
+#define HFDL_GPU_FCS_BAD       1
+#define HFDL_GPU_FCS_TOO_SHORT 2
+#define HFDL_GPU_KIND_SPDU          0
+#define HFDL_GPU_KIND_MPDU_DOWNLINK 1
+#define HFDL_GPU_KIND_MPDU_UPLINK   2
+
 typedef struct hfdl_gpu_frontend hfdl_gpu_frontend;
 
 /* block geometry: the fields of the reference's fastddc_t (src/fastddc.h:8-27) for shift = 0 */
@@ -64,6 +72,9 @@ typedef struct {
 	int32_t  len;                    /* octets */
 	float    freq_err_hz, rssi_db, noise_floor_db;
 	char     slot;                   /* 'S' / 'D' */
+	uint8_t  fcs_status;             /* HFDL_GPU_FCS_*: header FCS checked on the device (src/pdu.c:68-79) */
+	uint8_t  pdu_kind;               /* HFDL_GPU_KIND_*: SPDU / MPDU direction triage (src/pdu.c:124-128, src/mpdu.c:56-74) */
+	uint16_t hdr_len;                /* octets covered by the FCS */
 	uint64_t sample_index;
 	int32_t  train_bits_bad, train_bits_total;
 	uint8_t  octets[HFDL_GPU_PDU_MAX_OCTETS];
@@ -91,6 +102,13 @@ int  hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_geometry *
 /* Enqueue one block: exactly geometry.input_size new complex samples (interleaved I,Q float32).
  * on_device != 0: `iq` is a device pointer that stays valid until the next sync.  Asynchronous. */
 int  hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
+/* Same, for raw recorder / SDR samples converted on the device inside the overlap-assembly load of the forward FFT
+ * (convert_cs16 / convert_cu8 / convert_cf32, src/input-helpers.c:10-78): interleaved I,Q int16 (full scale 32767.5),
+ * uint8 (offset 63.5, full scale 127) or float32.  Halves / quarters the host->device bytes per sample. */
+#define HFDL_GPU_SFMT_CF32 0
+#define HFDL_GPU_SFMT_CS16 1
+#define HFDL_GPU_SFMT_CU8  2
+int  hfdl_gpu_frontend_push_block_raw(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int sample_format, int on_device);
 /* run only the channelizer part of a block (forward FFT + fold + inverse FFT + NCO); for stage parity/bench */
 int  hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
 int  hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe);

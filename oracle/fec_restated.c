@@ -95,6 +95,32 @@ int orc_fcs_check(const uint8_t *buf, uint32_t hdr_len)
 	return rx == calc;
 }
 
+int orc_pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hdr_len)
+{
+	if (!(buf[0] & 1)) {                                   /* IS_MPDU(buf) is bit 0, src/pdu.c:102 */
+		*kind = 0;
+		*hdr_len = 64;                                     /* SPDU_LEN 66 = 64 + FCS, src/spdu.c:12 */
+		if (len < 66) return 2;
+		return orc_fcs_check(buf, 64) ? 0 : 1;
+	}
+	uint32_t hl;
+	if (buf[0] & 0x2) {                                    /* downlink, src/mpdu.c:62-65 */
+		*kind = 1;
+		hl = 6 + ((buf[0] >> 2) & 0xF);
+	} else {                                               /* uplink, :66-79 */
+		*kind = 2;
+		uint32_t ac = ((buf[0] & 0x70) >> 4) + 1;
+		hl = 2;
+		for (uint32_t i = 0; i < ac; i++) {
+			if (len < hl + 2) { *hdr_len = hl; return 2; }
+			hl += 2 + (buf[hl + 1] >> 4);
+		}
+	}
+	*hdr_len = hl;
+	if (len < hl + 2) return 2;
+	return orc_fcs_check(buf, hl) ? 0 : 1;
+}
+
 uint8_t orc_reverse_byte(uint8_t x)
 {
 	x = (uint8_t)((x >> 4) | (x << 4));

@@ -76,6 +76,9 @@ void     orc_viterbi27_decode(const uint8_t *soft, int32_t nbits, uint8_t *out);
 void     orc_conv27_encode(const uint8_t *bits, int32_t nbits, uint8_t *coded /* 2*nbits, values 0/1 */);
 uint16_t orc_crc16_ccitt(const uint8_t *data, uint32_t len, uint16_t init);   /* src/crc.c:4-47 */
 int      orc_fcs_check(const uint8_t *buf, uint32_t hdr_len);                  /* src/pdu.c:68-79 */
+/* header triage as mpdu_parse / spdu_parse begin: src/mpdu.c:56-89, src/spdu.c:12,55-62, src/pdu.c:124-128.
+ * returns 0 good FCS, 1 bad FCS, 2 too short; kind 0 SPDU, 1 MPDU downlink, 2 MPDU uplink */
+int      orc_pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hdr_len);
 uint8_t  orc_reverse_byte(uint8_t x);                                          /* src/util.h:109 */
 
 /* ---------------- HFDL frame constants (src/hfdl.c:29-46,81-138) ---------------- */

@@ -74,6 +74,7 @@ def lib():
         L.orc_crc16_ccitt.restype = C.c_uint16
         L.orc_crc16_ccitt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint16]
         L.orc_fcs_check.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_pdu_triage.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
         L.orc_viterbi27_decode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.orc_conv27_encode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.orc_fft_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
@@ -208,6 +209,13 @@ def conv_encode(bits):
 def crc16(data, init=0xFFFF):
     data = np.ascontiguousarray(data, dtype=np.uint8)
     return lib().orc_crc16_ccitt(_p(data), len(data), init)
+
+
+def pdu_triage(octets):
+    a = np.frombuffer(bytes(octets), np.uint8).copy()
+    kind, hl = C.c_int(0), C.c_uint32(0)
+    st = lib().orc_pdu_triage(_p(a), len(a), C.byref(kind), C.byref(hl))
+    return st, kind.value, hl.value
 
 
 def decode_user_data(mode, symbols, bitmask_lsb=0):

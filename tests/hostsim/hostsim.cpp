@@ -75,6 +75,8 @@ int sim_taps(Sim *s, float *rs, float *mf, float *sym, float *lvl, int *counts)
 
 void sim_psk_soft(int arity, float re, float im, uint8_t *soft) { cf x; x.x = re; x.y = im; psk_soft(arity, x, soft); }
 
+int sim_pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hdr_len) { return pdu_triage(buf, len, kind, hdr_len); }
+
 void sim_tables(float resamp_rate, DemodTables *out) { build_demod_tables(*out, resamp_rate); }
 
 // planner: geometry + channel constants + time-domain taps as the GPU shim computes them

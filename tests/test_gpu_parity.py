@@ -241,6 +241,9 @@ def test_burst_dense_all_modes_cfg4_shape(gpu, oracle):
     for p in got:
         assert any(p["octets"][:len(b["octets"])] == b["octets"] and p["mode"] == b["mode"] for b in bursts if b["freq"] == p["freq"])
         assert len(p["octets"]) == synth.mode_sizes(p["mode"])["octets"]
+        # on-device FCS / header triage equals the oracle's and (the generator writes valid FCS) says "good"
+        assert (p["fcs_status"], p["pdu_kind"], p["hdr_len"]) == oracle.pdu_triage(p["octets"])
+        assert p["fcs_status"] == F.FCS_GOOD
 
 
 def test_degenerate_inputs(gpu, oracle):
@@ -280,3 +283,34 @@ def test_many_frames_in_one_block(gpu, oracle):
     key = lambda p: (p["freq"], p["mode"], p["octets"])
     assert sorted(map(key, got)) == sorted(map(key, want))
     assert len(got) >= 60
+
+
+@pytest.mark.parametrize("fmt", ["CS16", "CU8"])
+def test_raw_ingest_converted_on_device(gpu, oracle, fmt):
+    """cs16 / cu8 samples converted inside the forward FFT's first load; must equal feeding the
+    oracle the reference's host-side conversion (src/input-helpers.c:33-78) of the same octets."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_958_000, 10_061_000]
+    rng = np.random.default_rng(31)
+    bursts = [dict(freq=freqs[0], mode=2, octets=synth.make_pdu(rng, 2), t0=0.3, amp=0.25, cfo=5.0),
+              dict(freq=freqs[1], mode=1, octets=synth.make_pdu(rng, 1), t0=0.4, amp=0.3, cfo=-7.0)]
+    x = synth.synth_wideband(fs, cf, int(3.3 * fs), bursts, noise_sigma=0.02, seed=3)
+    f = x.view(np.float32)
+    if fmt == "CS16":
+        raw = np.clip(np.round(f * 20000), -32768, 32767).astype(np.int16)
+        conv = (raw.astype(np.float32) / np.float32(32767.5)).view(np.complex64)
+        code = F.SFMT_CS16
+    else:
+        raw = np.clip(np.round(f * 100 + 127.5), 0, 255).astype(np.uint8)
+        conv = ((raw.astype(np.float32) - np.float32(63.5)) / np.float32(127.0)).view(np.complex64)
+        code = F.SFMT_CU8
+    fe = gpu.Frontend(fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs)
+    n = fe.input_size
+    for b in range(len(conv) // n):
+        fe.push_block_raw(raw[2 * b * n:2 * (b + 1) * n], code)
+        ora.push_block(conv[b * n:(b + 1) * n])
+        assert rel_rms(fe.read_tap(F.TAP_SPECTRUM), ora.spectrum()) < 5e-6
+    got = sorted((p["freq"], p["octets"]) for p in fe.poll_pdus())
+    assert got == sorted((p["freq"], p["octets"]) for p in ora.pdus) and len(got) == 2
+    fe.close()

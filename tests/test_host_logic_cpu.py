@@ -179,3 +179,23 @@ def test_demod_core_matches_oracle_bit_for_bit(sim, oracle):
     want = [(p["mode"], p["octets"], p["sample_index"], p["train_bits_bad"], p["train_bits_total"], np.float32(p["freq_err_hz"]))
             for p in ch.pdus]
     assert got == want and len(got) == 4
+
+
+def test_pdu_triage_matches_oracle(sim, oracle):
+    """Device-side FCS / SPDU-MPDU triage (same source compiled for the host) against the oracle's restatement."""
+    rng = np.random.default_rng(21)
+    sim.sim_pdu_triage.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
+    cases = [synth.make_spdu(rng) + bytes(2)] + [synth.make_mpdu(rng, n) for n in (20, 66, 133, 268, 403)]
+    for _ in range(300):                                   # random octets: exercises uplink headers, short frames, bad FCS
+        cases.append(rng.integers(0, 256, int(rng.integers(1, 300)), dtype=np.uint8).tobytes())
+    cases += [c[:-1] + bytes([c[-1] ^ 0x40]) for c in cases[:6]]
+    seen = set()
+    for c in cases:
+        a = np.frombuffer(c, np.uint8).copy()
+        kind, hl = C.c_int(0), C.c_uint32(0)
+        st = sim.sim_pdu_triage(a.ctypes.data, len(a), C.byref(kind), C.byref(hl))
+        assert (st, kind.value, hl.value) == oracle.pdu_triage(c)
+        seen.add((st, kind.value))
+    assert {(0, 0), (0, 1), (2, 2), (1, 1)} <= seen
+    good = synth.make_spdu(rng)
+    assert oracle.pdu_triage(good)[:2] == (0, 0) and oracle.pdu_triage(good[:40])[0] == 2
