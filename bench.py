@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / final reduction at N > 1 (nccl = RCCL; gloo for a 1-GPU smoke of the N>1 path)")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
 
@@ -126,14 +128,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HFDL front end has no CPU path")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    red_device = "cuda"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+            red_device = "cpu"
     import dumphfdl_amd as hf
 
     freqs = channel_plan(w)
     t0 = time.time()
-    fe = hf.Frontend(w["fs"], w["centerfreq"], freqs, device=local_rank)
+    fe = hf.Frontend(w["fs"], w["centerfreq"], freqs, device=dev_index)
     g = fe.geometry
     t_create = time.time() - t0
     t0 = time.time()
@@ -166,7 +174,7 @@ def main():
     fold_ms, fold_n = fe.fold_time_ms()
     barrier()
     from dumphfdl_amd import shard
-    elapsed_max, total_samples, total_pdus = shard.reduce_job(elapsed, args.steps * g.input_size, npdus, dist, device="cuda")
+    elapsed_max, total_samples, total_pdus = shard.reduce_job(elapsed, args.steps * g.input_size, npdus, dist, device=red_device)
 
     if rank == 0:
         good = sum(1 for p in pdus if any(p["octets"][:len(b["octets"])] == b["octets"] for b in bursts if b["freq"] == p["freq"]))

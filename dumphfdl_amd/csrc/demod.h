@@ -32,6 +32,7 @@ struct Demod {
 	int enqueue_block(const float2 *chan_out, const int *out_count, hipStream_t st);
 	int collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);
 	int tap(int what, int channel, const void **src, size_t *nfloats);
+	int stats(int channel, hfdl_gpu_channel_stats *out);
 	void release();
 };
 

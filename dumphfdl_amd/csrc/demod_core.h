@@ -76,6 +76,8 @@ struct ChanScalars {
 	int32_t eq_train_seq_cnt, data_segment_cnt, train_total, train_bad, T_idx, M1;
 	uint32_t bitmask, symsync_out_idx, nf_clk;
 	float frame_symbol_cnt, freq_err_hz, signal_level, noise_floor;
+	// observability: the per-channel StatsD counters of the reference's hot path (src/hfdl.c:818,828,840; doc/STATSD_METRICS.md)
+	uint32_t cnt_a2_found, cnt_m1_found, cnt_m1_not_found, cnt_frames;
 };
 
 struct ChanArrays {
@@ -406,6 +408,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 	case FR_A2: {
 		const float corr = 2.0f * (float)bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo) / (float)A_LEN - 1.0f;
 		if (fabsf(corr) > 0.3f) {
+			s.cnt_a2_found++;                    // statsd "demod.preamble.A2_found"
 			s.pdu_sample_index = s.sample_cnt;
 			s.freq_err_hz = (float)((double)(s.dphi * 1800) / (2.0 * M_PI));
 			s.symbols_wanted = M1_LEN;
@@ -424,6 +427,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 		}
 		if (fabsf(best) > 0.3f) {
 			const ModeParams mp = mode_params(best_idx);
+			s.cnt_m1_found++;                    // "demod.preamble.M1_found"
 			s.data_segment_cnt = mp.segments;
 			s.data_arity = mp.arity;
 			s.M1 = best_idx;
@@ -432,6 +436,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 			s.fr_state = FR_M2_SKIP;
 			s.s_state = SAMPLER_SKIP;
 		} else {
+			s.cnt_m1_not_found++;                // "demod.preamble.errors.M1_not_found"
 			framer_reset(s, a, T.eq_h0);
 		}
 		break; }
@@ -476,6 +481,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 				}
 			}
 			s.data_slot ^= 1;
+			s.cnt_frames++;
 			framer_reset(s, a, T.eq_h0);
 			s.symbol_cnt = 0;
 		}

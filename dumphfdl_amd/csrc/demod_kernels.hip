@@ -353,6 +353,19 @@ int Demod::tap(int what, int channel, const void **src, size_t *nfloats)
 	}
 }
 
+int Demod::stats(int channel, hfdl_gpu_channel_stats *out)
+{
+	ChanScalars sc;
+	D_TRY(hipMemcpy(&sc, &d_states[channel].s, sizeof(sc), hipMemcpyDeviceToHost));
+	out->a2_found = sc.cnt_a2_found; out->m1_found = sc.cnt_m1_found; out->m1_not_found = sc.cnt_m1_not_found; out->frames = sc.cnt_frames;
+	out->noise_floor_db = 20.0f * log10f(sc.noise_floor);
+	out->agc_level = 1.0f / sc.agc_g;
+	out->costas_dphi = sc.dphi;
+	out->framer_state = sc.fr_state;
+	out->sample_cnt = sc.sample_cnt; out->symbol_cnt = sc.symbol_cnt;
+	return 0;
+}
+
 void Demod::release()
 {
 	void *ptrs[] = { d_tables, d_states, d_data, d_frames, d_counts, d_pdus, d_freqs, d_tap_rs, d_tap_mf, d_tap_sym, d_tap_lvl, d_tap_counts };

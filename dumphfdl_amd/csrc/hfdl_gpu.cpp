@@ -456,6 +456,19 @@ extern "C" int hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *
 	return 0;
 }
 
+extern "C" int hfdl_gpu_frontend_channel_stats(hfdl_gpu_frontend *fe, int32_t channel, hfdl_gpu_channel_stats *out)
+{
+	if (!fe || !out) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (channel < 0 || channel >= fe->geo.nch) return fail(HFDL_GPU_EINVAL, "channel out of range");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	memset(out, 0, sizeof(*out));
+	out->freq = fe->freqs[(size_t)channel];
+	rc = fe->demod.stats(channel, out);
+	if (rc) return fail(rc, "stats read failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
 extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel, float *dst, size_t cap, size_t *n_floats)
 {
 	if (!fe || !dst || !n_floats) return fail(HFDL_GPU_EINVAL, "null argument");

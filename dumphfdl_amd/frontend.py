@@ -35,6 +35,12 @@ class Pdu(C.Structure):
                 ("octets", C.c_uint8 * PDU_MAX_OCTETS)]
 
 
+class ChannelStats(C.Structure):
+    _fields_ = [("freq", C.c_int32), ("a2_found", C.c_uint32), ("m1_found", C.c_uint32), ("m1_not_found", C.c_uint32),
+                ("frames", C.c_uint32), ("noise_floor_db", C.c_float), ("agc_level", C.c_float), ("costas_dphi", C.c_float),
+                ("framer_state", C.c_int32), ("sample_cnt", C.c_uint64), ("symbol_cnt", C.c_uint64)]
+
+
 def lib_path():
     return os.path.join(_HERE, "libhfdl_gpu.so")
 
@@ -46,7 +52,7 @@ EXPORTS = [
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
-    "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers",
+    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
@@ -82,6 +88,7 @@ def load():
     L.hfdl_gpu_frontend_stream.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_stream.restype = C.c_void_p
     L.hfdl_gpu_frontend_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.hfdl_gpu_frontend_channel_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ChannelStats)]
     L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_fft_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
@@ -178,6 +185,11 @@ class Frontend:
         _check(load().hfdl_gpu_frontend_read_tap(self._h, what, channel, _p(buf), cap, C.byref(n)))
         out = buf[:n.value].copy()
         return out if what == TAP_AGC_LEVEL else out.view(np.complex64)
+
+    def channel_stats(self, channel):
+        st = ChannelStats()
+        _check(load().hfdl_gpu_frontend_channel_stats(self._h, channel, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in ChannelStats._fields_}
 
     def reset_timers(self, enable=True):
         _check(load().hfdl_gpu_frontend_reset_timers(self._h, int(enable)))

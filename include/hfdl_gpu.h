@@ -117,6 +117,18 @@ int  hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32
 /* the HIP stream all kernels of this front end are launched on (hipStream_t as void*) */
 void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe);
 
+/* per-channel observability: the hot-path StatsD counters and the noise-floor gauge of the reference
+ * (src/hfdl.c:818-840, 1082-1105; doc/STATSD_METRICS.md), read from the device-resident channel state */
+typedef struct {
+	int32_t  freq;
+	uint32_t a2_found, m1_found, m1_not_found, frames;
+	float    noise_floor_db;         /* 20 log10(noise_floor), what noise_floor_stats_thread reports */
+	float    agc_level, costas_dphi;
+	int32_t  framer_state;           /* 1 = A1 search ... 7 = DATA_2 (src/hfdl.c:54-62) */
+	uint64_t sample_cnt, symbol_cnt;
+} hfdl_gpu_channel_stats;
+int  hfdl_gpu_frontend_channel_stats(hfdl_gpu_frontend *fe, int32_t channel, hfdl_gpu_channel_stats *out);
+
 /* stage taps -- the DATADUMPS analogue (src/hfdl.c:616-644): copy an intermediate buffer to host */
 enum {
 	HFDL_GPU_TAP_SPECTRUM = 1,       /* cf32[fft_size], fftshifted forward FFT (shared.buf after src/fft.c:59) */

@@ -400,6 +400,7 @@ struct orc_channel {
 	float frame_symbol_cnt;
 	uint64_t pdu_sample_index;
 	float freq_err_hz, signal_level, noise_floor;
+	uint32_t cnt_a2_found, cnt_m1_found, cnt_m1_not_found, cnt_frames;   /* statsd increments, src/hfdl.c:818,828,840 */
 	/* stage taps */
 	orc_cf *resampled; int32_t resampled_cap, resampled_n;
 	orc_cf *mf_out; float *agc_level;
@@ -471,6 +472,13 @@ void orc_channel_destroy(orc_channel *c)
 }
 
 const orc_ddc *orc_channel_ddc(const orc_channel *c) { return &c->ddc; }
+
+void orc_channel_counters(const orc_channel *c, uint32_t out[4], float *noise_floor, int *framer_state)
+{
+	out[0] = c->cnt_a2_found; out[1] = c->cnt_m1_found; out[2] = c->cnt_m1_not_found; out[3] = c->cnt_frames;
+	*noise_floor = c->noise_floor;
+	*framer_state = c->fr_state;
+}
 const orc_cf *orc_channel_taps(const orc_channel *c) { return c->taps_fft; }
 
 void orc_channel_taps_view(const orc_channel *c, orc_taps_view *v)
@@ -563,6 +571,7 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 	case FR_A2: {
 		float corr = 2.0f * (float)bits_correlate(&seq_A, &c->bits) / (float)A_LEN - 1.0f;
 		if (fabsf(corr) > 0.3f) {
+			c->cnt_a2_found++;
 			c->pdu_sample_index = c->sample_cnt;   /* reference: wall clock, :808-809 */
 			c->freq_err_hz = (float)(c->loop.dphi * 1800 / (2.0 * M_PI));
 			c->symbols_wanted = M1_LEN;
@@ -579,6 +588,7 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 			if (corr > best) { best = corr; best_idx = m; }
 		}
 		if (fabsf(best) > 0.3f) {
+			c->cnt_m1_found++;
 			c->data_segment_cnt = orc_modes[best_idx].segments;
 			c->data_arity = orc_modes[best_idx].arity;
 			c->M1 = best_idx;
@@ -587,6 +597,7 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 			c->fr_state = FR_M2_SKIP;
 			c->s_state = SAMPLER_SKIP;
 		} else {
+			c->cnt_m1_not_found++;
 			framer_reset(c);
 		}
 		break; }
@@ -611,6 +622,7 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 			c->use_data_buffer = 1;
 		} else {
 			emit_pdu(c, sink, ctx);
+			c->cnt_frames++;
 			framer_reset(c);
 			c->symbol_cnt = 0;
 		}

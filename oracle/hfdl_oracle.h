@@ -123,6 +123,8 @@ orc_channel *orc_channel_create(int32_t sample_rate, int32_t decimation, float t
 void orc_channel_destroy(orc_channel *c);
 const orc_ddc *orc_channel_ddc(const orc_channel *c);
 const orc_cf *orc_channel_taps(const orc_channel *c);
+/* StatsD counters of the hot path (src/hfdl.c:818,828,840) + noise floor (linear) + framer state */
+void orc_channel_counters(const orc_channel *c, uint32_t out[4], float *noise_floor, int *framer_state);
 /* one block of the shared spectrum -> PDUs (src/hfdl.c:662-891) */
 void orc_channel_process_spectrum(orc_channel *c, const orc_cf *spectrum, orc_pdu_sink sink, void *ctx);
 /* enter after the channelizer: n samples at fs/decimation */

@@ -97,6 +97,7 @@ def lib():
         L.orc_channel_destroy.argtypes = [C.c_void_p]
         L.orc_channel_ddc.restype = C.POINTER(Ddc)
         L.orc_channel_ddc.argtypes = [C.c_void_p]
+        L.orc_channel_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.orc_channel_taps.restype = C.c_void_p
         L.orc_channel_taps.argtypes = [C.c_void_p]
         L.orc_channel_process_baseband.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, SINK, C.c_void_p]
@@ -300,6 +301,12 @@ class Frontend:
         n = self.ddc.fft_size
         ptr = lib().orc_frontend_spectrum(self.h)
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), (2 * n,)).view(np.complex64).copy()
+
+    def channel_counters(self, i):
+        cnt = (C.c_uint32 * 4)()
+        nf, st = C.c_float(0), C.c_int(0)
+        lib().orc_channel_counters(lib().orc_frontend_channel(self.h, i), cnt, C.byref(nf), C.byref(st))
+        return dict(a2_found=cnt[0], m1_found=cnt[1], m1_not_found=cnt[2], frames=cnt[3], noise_floor=nf.value, framer_state=st.value)
 
     def channel_view(self, i):
         ch = Channel.__new__(Channel)

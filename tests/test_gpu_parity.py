@@ -131,6 +131,13 @@ def _run_both(gpu, oracle, fs, cf, freqs, x, check_stages=False):
                     elif len(got):
                         worst[name] = max(worst[name], rel_rms(got, v[name]))
     pdus = fe.poll_pdus()
+    # hot-path counters and the noise-floor gauge (StatsD analogue) must agree with the oracle's, channel by channel
+    for c in range(len(freqs)):
+        st, oc = fe.channel_stats(c), ora.channel_counters(c)
+        assert (st["a2_found"], st["m1_found"], st["m1_not_found"], st["frames"], st["framer_state"]) == \
+            (oc["a2_found"], oc["m1_found"], oc["m1_not_found"], oc["frames"], oc["framer_state"]), c
+        assert abs(st["noise_floor_db"] - 20 * np.log10(oc["noise_floor"])) < 0.2
+        assert st["freq"] == freqs[c]
     fe.close()
     return pdus, ora.pdus, worst
 
