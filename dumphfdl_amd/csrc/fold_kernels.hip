@@ -99,10 +99,10 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 	const int u = g.m / (2 * FOLD_THREADS);
 #define FOLD_LAUNCH(U, NT, R, CS) hipLaunchKernelGGL((fold_kernel<U, NT, R, CS>), dim3((unsigned)(g.nch * g.slices * CS)), block, 0, st, \
 		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, n, g.m, g.slices, g.rows_per_slice)
-	// variants measured on cfg3 (profiles/r01_experiments.md): non-temporal taps +7 %, two rows per trip +0.5 %,
-	// column-split (lighter, more numerous workgroups) -1..-8 %, S = 4..16 slices flat, S >= 32 slower
+	// variants measured on cfg3 (profiles/r01_experiments.md): non-temporal taps +7 %; two rows per trip +0.5 % alone but
+	// -0.5 % with the demodulator co-resident (166 vs 102 VGPRs); column-split (lighter, more numerous workgroups)
+	// -1..-8 %; S = 4..16 slices flat, S >= 32 slower
 	if (g.m == 2 * FOLD_THREADS * u && u >= 1) {
-		if (u == 8 && (g.rows_per_slice % 2) == 0) { FOLD_LAUNCH(8, true, 2, 1); return; }
 		switch (u) {
 		case 1: FOLD_LAUNCH(1, true, 1, 1); return;
 		case 2: FOLD_LAUNCH(2, true, 1, 1); return;
