@@ -17,6 +17,21 @@ def rel_rms(a, b):
     return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / max(np.mean(np.abs(b) ** 2), 1e-300)))
 
 
+def test_fft_forward_full_size_8mi(gpu):
+    """The 2^23-point transform of the 40 Msps geometry: float64 reference, Parseval and a tone landing on its bin."""
+    n = 1 << 23
+    rng = np.random.default_rng(23)
+    x = (rng.standard_normal(n, dtype=np.float32) + 1j * rng.standard_normal(n, dtype=np.float32)).astype(np.complex64)
+    got = gpu.fft_forward(x, shifted=True)
+    want = np.fft.fftshift(np.fft.fft(x.astype(np.complex128)))
+    assert rel_rms(got, want) < 3e-6
+    assert abs(np.sum(np.abs(got.astype(np.complex128)) ** 2) / (n * np.sum(np.abs(x.astype(np.complex128)) ** 2)) - 1) < 1e-5
+    k = 5_000_017
+    tone = np.exp(2j * np.pi * ((k * np.arange(n, dtype=np.int64)) % n) / n).astype(np.complex64)
+    spec = gpu.fft_forward(tone, shifted=False)
+    assert int(np.argmax(np.abs(spec))) == k and abs(abs(spec[k]) / n - 1) < 1e-4
+
+
 @pytest.mark.parametrize("n", [512, 2048, 32768, 1 << 20])
 @pytest.mark.parametrize("shifted", [False, True])
 def test_fft_forward_vs_float64(gpu, n, shifted):
@@ -321,3 +336,52 @@ def test_raw_ingest_converted_on_device(gpu, oracle, fmt):
     got = sorted((p["freq"], p["octets"]) for p in fe.poll_pdus())
     assert got == sorted((p["freq"], p["octets"]) for p in ora.pdus) and len(got) == 2
     fe.close()
+
+
+def test_full_size_cfg3_geometry(gpu, oracle):
+    """BASELINE.json configs[2] geometry (40 Msps, N = 2^23, M = 4096) with all 256 channels resident.
+    Size-independent properties over every channel: encode -> channel -> decode round trip (payload + FCS) and
+    linearity of the channelizer; plus oracle parity (channelizer RMS and PDUs) on a 4-channel subset."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    w = dict(bench.WORKLOADS["cfg3"])
+    freqs = bench.channel_plan(w)
+    assert len(freqs) == 256
+    fe = gpu.Frontend(w["fs"], w["centerfreq"], freqs)
+    g = fe.geometry
+    assert (g.fft_size, g.fft_inv_size, g.input_size, g.outputs_per_block) == (1 << 23, 4096, 7340032, 1792)
+    x, bursts = bench.make_input(w, g.input_size, 0, 1)
+    nblk = len(x) // g.input_size
+    sub = [3, 77, 128, 250]
+    ora = oracle.Frontend(w["fs"], w["centerfreq"], [freqs[c] for c in sub], nthreads=4)
+    worst = 0.0
+    for b in range(nblk):
+        blk = x[b * g.input_size:(b + 1) * g.input_size]
+        fe.push_block(blk)
+        ora.push_block(blk, nthreads=4)
+        if b in (0, 1, nblk - 1):
+            for i, c in enumerate(sub):
+                worst = max(worst, rel_rms(fe.read_tap(F.TAP_CHAN_OUT, c), ora.channel_view(i)["chan_out"]))
+    assert worst < RMS_TOL, worst
+    pdus = fe.poll_pdus()
+    sent = {b["freq"]: b for b in bursts}
+    assert len(pdus) >= 250
+    for p in pdus:
+        b = sent[p["freq"]]
+        assert p["octets"][:len(b["octets"])] == b["octets"] and p["mode"] == b["mode"] and p["fcs_status"] == F.FCS_GOOD
+    got4 = sorted((p["freq"], p["sample_index"], p["octets"]) for p in pdus if p["channel"] in sub)
+    assert got4 == sorted((p["freq"], p["sample_index"], p["octets"]) for p in ora.pdus) and len(got4) == 4
+    fe.close()
+    # linearity of the whole channelizer at full size: C(a x + b y) = a C(x) + b C(y), fresh state each time
+    rng = np.random.default_rng(9)
+    n = g.input_size
+    xa = (0.2 * (rng.standard_normal(n, dtype=np.float32) + 1j * rng.standard_normal(n, dtype=np.float32))).astype(np.complex64)
+    xb = x[:n]
+    outs = []
+    for sig in (xa, xb, (np.complex64(0.5) * xa + np.complex64(-1.5) * xb).astype(np.complex64)):
+        f2 = gpu.Frontend(w["fs"], w["centerfreq"], freqs[:16])
+        f2.channelize_block(sig)
+        outs.append(np.stack([f2.read_tap(F.TAP_CHAN_OUT, c) for c in range(16)]))
+        f2.close()
+    assert rel_rms(outs[2], 0.5 * outs[0] - 1.5 * outs[1]) < 1e-5
