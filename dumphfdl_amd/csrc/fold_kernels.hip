@@ -6,10 +6,10 @@
 // fold_kernel is THE roofline kernel: per channel it streams N cf32 filter taps (distinct per channel, read once,
 // 8*N bytes) against the shared N-bin spectrum and accumulates the N/M alias rows onto M bins:
 //      Y_c[(h0 + j) mod M] = sum_a  H_c[a*M + j] * X[a*M + j]
-// Workgroup = (channel, slice of alias rows); a row is M contiguous cf32, so every wave issues 1 KiB
-// dwordx4 runs and a workgroup walks a contiguous (rows_per_slice * M * 8)-byte span of the channel's taps.
-// blockIdx -> (slice = b mod S, channel = b div S): the dispatcher puts block b on XCD b mod 8, so with S a
-// multiple of 8 every XCD's L2 only ever sees its own 1/8 of the spectrum, shared by all channels.
+// Workgroup = (channel pair, slice of alias rows, half of the M columns); a row is M contiguous cf32, so every wave
+// issues 1 KiB dwordx4 runs; each spectrum value is loaded once and multiplied into both channels' tap streams.
+// blockIdx -> (column half, slice, pair): the dispatcher puts block b on XCD b mod 8, so every XCD's L2 only ever
+// sees 1/8 of the spectrum (two slices x one column half), shared by all channels.
 #include "kernels.h"
 #include "fft_core.h"
 
@@ -27,49 +27,62 @@ __device__ __forceinline__ float4 load_stream(const float4 *p)
 }
 
 // U float4 (= 2U bins) per thread per alias row; NT = non-temporal tap loads; R = alias rows per loop trip;
-// CS = column split: a workgroup covers 1/CS of a row (more, lighter workgroups -> more waves per SIMD)
-template <int U, bool NT, int R, int CS>
+// CS = column split: a workgroup covers 1/CS of a row; NC = channels per workgroup sharing every spectrum load
+template <int U, bool NT, int R, int CS, int NC>
 __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__restrict__ taps, const float4 *__restrict__ spec,
-		float4 *__restrict__ partial, size_t n, int m, int slices, int rows)
+		float4 *__restrict__ partial, size_t n, int m, int slices, int rows, int c_base)
 {
 	const int cpart = blockIdx.x % CS;
 	const int bs = blockIdx.x / CS;
-	const int s = bs % slices, c = bs / slices;
+	const int s = bs % slices, c0 = c_base + (bs / slices) * NC;
 	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row
 	const size_t off = (((size_t)s * rows * (size_t)m) >> 1) + (size_t)cpart * U * FOLD_THREADS;
-	const float4 *tp = taps + (((size_t)c * n) >> 1) + off + threadIdx.x;
+	const float4 *tp = taps + (((size_t)c0 * n) >> 1) + off + threadIdx.x;
 	const float4 *sp = spec + off + threadIdx.x;
-	float4 acc[U];
+	const size_t cstride = n >> 1;                            // float4 between consecutive channels' taps
+	float4 acc[NC][U];
 #pragma unroll
-	for (int u = 0; u < U; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+	for (int k = 0; k < NC; k++)
+#pragma unroll
+		for (int u = 0; u < U; u++) acc[k][u] = make_float4(0.f, 0.f, 0.f, 0.f);
 	const bool live = (U * CS > 1) || ((int)threadIdx.x < row4);
 	if (live) {
 		for (int r = 0; r < rows; r += R) {
-			float4 h[R][U], x[R][U];
+			float4 h[NC][R][U], x[R][U];
 #pragma unroll
 			for (int q = 0; q < R; q++) {
 #pragma unroll
 				for (int u = 0; u < U; u++) {
-					h[q][u] = NT ? load_stream(tp + (size_t)q * row4 + u * FOLD_THREADS) : tp[(size_t)q * row4 + u * FOLD_THREADS];
+#pragma unroll
+					for (int k = 0; k < NC; k++) {
+						const float4 *p = tp + (size_t)k * cstride + (size_t)q * row4 + u * FOLD_THREADS;
+						h[k][q][u] = NT ? load_stream(p) : *p;
+					}
 					x[q][u] = sp[(size_t)q * row4 + u * FOLD_THREADS];
 				}
 			}
 #pragma unroll
-			for (int q = 0; q < R; q++) {
+			for (int k = 0; k < NC; k++) {
 #pragma unroll
-				for (int u = 0; u < U; u++) {
-					acc[u].x += h[q][u].x * x[q][u].x - h[q][u].y * x[q][u].y;
-					acc[u].y += h[q][u].x * x[q][u].y + h[q][u].y * x[q][u].x;
-					acc[u].z += h[q][u].z * x[q][u].z - h[q][u].w * x[q][u].w;
-					acc[u].w += h[q][u].z * x[q][u].w + h[q][u].w * x[q][u].z;
+				for (int q = 0; q < R; q++) {
+#pragma unroll
+					for (int u = 0; u < U; u++) {
+						acc[k][u].x += h[k][q][u].x * x[q][u].x - h[k][q][u].y * x[q][u].y;
+						acc[k][u].y += h[k][q][u].x * x[q][u].y + h[k][q][u].y * x[q][u].x;
+						acc[k][u].z += h[k][q][u].z * x[q][u].z - h[k][q][u].w * x[q][u].w;
+						acc[k][u].w += h[k][q][u].z * x[q][u].w + h[k][q][u].w * x[q][u].z;
+					}
 				}
 			}
 			tp += (size_t)R * row4;
 			sp += (size_t)R * row4;
 		}
-		float4 *po = partial + (((size_t)c * slices + s) * (size_t)m >> 1) + (size_t)cpart * U * FOLD_THREADS + threadIdx.x;
 #pragma unroll
-		for (int u = 0; u < U; u++) po[u * FOLD_THREADS] = acc[u];
+		for (int k = 0; k < NC; k++) {
+			float4 *po = partial + (((size_t)(c0 + k) * slices + s) * (size_t)m >> 1) + (size_t)cpart * U * FOLD_THREADS + threadIdx.x;
+#pragma unroll
+			for (int u = 0; u < U; u++) po[u * FOLD_THREADS] = acc[k][u];
+		}
 	}
 }
 
@@ -97,18 +110,23 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 	const dim3 block(FOLD_THREADS);
 	const size_t n = (size_t)g.n;
 	const int u = g.m / (2 * FOLD_THREADS);
-#define FOLD_LAUNCH(U, NT, R, CS) hipLaunchKernelGGL((fold_kernel<U, NT, R, CS>), dim3((unsigned)(g.nch * g.slices * CS)), block, 0, st, \
-		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, n, g.m, g.slices, g.rows_per_slice)
-	// variants measured on cfg3 (profiles/r01_experiments.md): non-temporal taps +7 %; two rows per trip +0.5 % alone but
-	// -0.5 % with the demodulator co-resident (166 vs 102 VGPRs); column-split (lighter, more numerous workgroups)
-	// -1..-8 %; S = 4..16 slices flat, S >= 32 slower
+	const int pairs = g.nch / 2, odd = g.nch & 1;
+	// channel pairs first; an odd last channel gets its own single-channel launch
+#define FOLD_LAUNCH(U, CS, NC, GROUPS) do { \
+	if ((GROUPS) > 0) hipLaunchKernelGGL((fold_kernel<U, true, 1, CS, NC>), dim3((unsigned)((GROUPS) * g.slices * CS)), block, 0, st, \
+		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, n, g.m, g.slices, g.rows_per_slice, 0); \
+	if (odd) hipLaunchKernelGGL((fold_kernel<U, true, 1, CS, 1>), dim3((unsigned)(g.slices * CS)), block, 0, st, \
+		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, n, g.m, g.slices, g.rows_per_slice, g.nch - 1); } while (0)
+	// Variants measured on cfg3 (profiles/r01_experiments.md).  What pays: non-temporal tap loads (+7 %) and TWO channels per
+	// workgroup sharing every spectrum load (+14 %: halves the L2->L1 spectrum traffic, which equals the HBM tap traffic
+	// when each channel re-reads the spectrum).  A workgroup = (channel pair, slice, half of the columns).
 	if (g.m == 2 * FOLD_THREADS * u && u >= 1) {
 		switch (u) {
-		case 1: FOLD_LAUNCH(1, true, 1, 1); return;
-		case 2: FOLD_LAUNCH(2, true, 1, 1); return;
-		case 4: FOLD_LAUNCH(4, true, 1, 1); return;
-		case 8: FOLD_LAUNCH(8, true, 1, 1); return;
-		case 16: FOLD_LAUNCH(16, true, 1, 1); return;
+		case 1: FOLD_LAUNCH(1, 1, 2, pairs); return;
+		case 2: FOLD_LAUNCH(1, 2, 2, pairs); return;
+		case 4: FOLD_LAUNCH(2, 2, 2, pairs); return;
+		case 8: FOLD_LAUNCH(4, 2, 2, pairs); return;
+		case 16: FOLD_LAUNCH(8, 2, 2, pairs); return;
 		default: break;
 		}
 	}
