@@ -47,6 +47,7 @@ __global__ __launch_bounds__(64) void demod_kernel(DevTables T, DemodBuffers B, 
 	float *l_mf = (float *)p;                        p += sizeof(float) * 32;
 	float *l_eq = (float *)p;                        p += sizeof(float) * 16;
 	uint64_t *l_m1 = (uint64_t *)p;                  p += sizeof(uint64_t) * 16;
+	float *l_corr = (float *)p;                      p += sizeof(float) * 128;
 	cf *rs = (cf *)p;                                p += sizeof(cf) * (size_t)B.cap;
 	cf *agc = (cf *)p;                               p += sizeof(cf) * (size_t)B.cap;
 	cf *mf = (cf *)p;                                p += sizeof(cf) * (size_t)B.cap;
@@ -63,10 +64,11 @@ __global__ __launch_bounds__(64) void demod_kernel(DevTables T, DemodBuffers B, 
 	if (lane < D_MF) l_mf[lane] = T.c.mf[lane];
 	if (lane < D_EQ) l_eq[lane] = T.c.eq_h0[lane];
 	if (lane < 8) { l_m1[lane] = T.c.m1_hi[lane]; l_m1[8 + lane] = T.c.m1_lo[lane]; }
+	l_corr[lane] = T.c.corr_tab[lane]; l_corr[64 + lane] = T.c.corr_tab[64 + lane];
 	__syncthreads();
 
 	DemodConst K = T.c;
-	K.ss_mf = l_ss_mf; K.ss_dmf = l_ss_dmf; K.mf = l_mf; K.eq_h0 = l_eq; K.m1_hi = l_m1; K.m1_lo = l_m1 + 8;
+	K.ss_mf = l_ss_mf; K.ss_dmf = l_ss_dmf; K.mf = l_mf; K.eq_h0 = l_eq; K.m1_hi = l_m1; K.m1_lo = l_m1 + 8; K.corr_tab = l_corr;
 	BlockIo io;
 	io.rs = rs; io.agc = agc; io.mf = mf; io.lvl = lvl; io.cap = B.cap;
 	io.data = B.data + (size_t)c * 2 * MAX_DATA_SYMBOLS;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(const uint8_t *__rest
 static size_t demod_lds_bytes(int cap)
 {
 	size_t b = (sizeof(ChanArrays) + 15) & ~(size_t)15;
-	b += sizeof(float) * D_SS_NPFB * D_SS_TAPS * 2 + sizeof(float) * 48 + sizeof(uint64_t) * 16;
+	b += sizeof(float) * D_SS_NPFB * D_SS_TAPS * 2 + sizeof(float) * 48 + sizeof(uint64_t) * 16 + sizeof(float) * 128;
 	b += (sizeof(cf) * 3 + sizeof(float)) * (size_t)cap;
 	return b;
 }
@@ -242,6 +244,7 @@ static DevTables resolve_tables(const float *d_img, const DemodTables &h)
 	t.c.m1_hi = (const uint64_t *)at(h.m1_hi);
 	t.c.m1_lo = (const uint64_t *)at(h.m1_lo);
 	t.scrambler = (const uint8_t *)at(h.scrambler);
+	t.c.corr_tab = (const float *)at(h.corr_tab);
 	return t;
 }
 

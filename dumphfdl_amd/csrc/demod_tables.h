@@ -28,6 +28,7 @@ struct DemodTables {
 	float eq_h0[EQ_TAPS];
 	uint64_t a_hi, a_lo, m1_hi[8], m1_lo[8];
 	uint8_t scrambler[120];
+	float corr_tab[128];
 };
 
 namespace tables_detail {
@@ -135,6 +136,13 @@ inline void build_demod_tables(DemodTables &t, float resamp_rate)
 			for (int j = 0; j < 127; j++) s.push((unsigned)(m1[(shifts[m] + j) % 127] - '0'));
 			t.m1_hi[m] = s.hi; t.m1_lo[m] = s.lo;
 		}
+	}
+	// --- preamble correlation value for m matching bits out of 127, in the reference's fp32 expression (src/hfdl.c:781)
+	for (int m = 0; m < 128; m++) {
+		volatile float v = 2.0f * (float)m;
+		v = v / (float)127;
+		v = v - 1.0f;
+		t.corr_tab[m] = v;
 	}
 	// --- descrambler: x^15 + x + 1 LFSR, fill 0x4d4b, 120-symbol period
 	{

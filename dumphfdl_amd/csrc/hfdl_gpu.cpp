@@ -485,6 +485,7 @@ extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32
 		int cnt = 0;
 		HIP_TRY(hipMemcpy(&cnt, fe->d_out_count[fe->last_buf] + channel, sizeof(cnt), hipMemcpyDeviceToHost));
 		src = fe->d_chan_out[fe->last_buf] + (size_t)channel * g.outs; nf = 2 * (size_t)cnt; break; }
+	case HFDL_GPU_TAP_PHASE_CYCLES: src = fe->demod.d_tap_lvl + (size_t)channel * fe->demod.cap + fe->demod.cap - 4; nf = 4; break;
 	default:
 		rc = fe->demod.tap(what, channel, &src, &nf);
 		if (rc) return fail(rc, "unknown tap %d", what);

@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PDU_MAX_OCTETS = 960
 
-TAP_SPECTRUM, TAP_FILTER, TAP_CHAN_OUT, TAP_RESAMPLED, TAP_MF_OUT, TAP_SYMBOLS, TAP_AGC_LEVEL = range(1, 8)
+TAP_SPECTRUM, TAP_FILTER, TAP_CHAN_OUT, TAP_RESAMPLED, TAP_MF_OUT, TAP_SYMBOLS, TAP_AGC_LEVEL, TAP_PHASE_CYCLES = range(1, 9)
 
 
 SFMT_CF32, SFMT_CS16, SFMT_CU8 = 0, 1, 2
@@ -184,7 +184,7 @@ class Frontend:
         n = C.c_size_t(0)
         _check(load().hfdl_gpu_frontend_read_tap(self._h, what, channel, _p(buf), cap, C.byref(n)))
         out = buf[:n.value].copy()
-        return out if what == TAP_AGC_LEVEL else out.view(np.complex64)
+        return out if what in (TAP_AGC_LEVEL, TAP_PHASE_CYCLES) else out.view(np.complex64)
 
     def channel_stats(self, channel):
         st = ChannelStats()

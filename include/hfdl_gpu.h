@@ -137,7 +137,8 @@ enum {
 	HFDL_GPU_TAP_RESAMPLED = 4,      /* cf32[n], msresamp output of the last block */
 	HFDL_GPU_TAP_MF_OUT = 5,         /* cf32[n], AGC + matched filter output of the last block */
 	HFDL_GPU_TAP_SYMBOLS = 6,        /* cf32[n], equalised on-time symbols of the last block */
-	HFDL_GPU_TAP_AGC_LEVEL = 7       /* f32[n], agc signal level per 5400-sps sample */
+	HFDL_GPU_TAP_AGC_LEVEL = 7,      /* f32[n], agc signal level per 5400-sps sample */
+	HFDL_GPU_TAP_PHASE_CYCLES = 8    /* f32[4]: shader cycles the last demod launch spent in resampler / AGC / matched filter / symbol loop */
 };
 /* dst holds `cap` floats; *n_floats receives the number written */
 int  hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel, float *dst, size_t cap, size_t *n_floats);

@@ -111,7 +111,8 @@ def test_demod_tables_match_oracle(sim, oracle):
         _fields_ = [("rs_h", C.c_float * (256 * 14)), ("rs_step", C.c_uint32), ("mf", C.c_float * 19),
                     ("ss_mf", C.c_float * 288), ("ss_dmf", C.c_float * 288), ("lf_b0", C.c_float), ("lf_a1", C.c_float),
                     ("ss_rate_adj", C.c_float), ("eq_h0", C.c_float * 15), ("a_hi", C.c_uint64), ("a_lo", C.c_uint64),
-                    ("m1_hi", C.c_uint64 * 8), ("m1_lo", C.c_uint64 * 8), ("scrambler", C.c_uint8 * 120)]
+                    ("m1_hi", C.c_uint64 * 8), ("m1_lo", C.c_uint64 * 8), ("scrambler", C.c_uint8 * 120),
+                    ("corr_tab", C.c_float * 128)]
     sim.sim_sizeof_tables.restype = C.c_size_t
     assert sim.sim_sizeof_tables() == C.sizeof(T)
     for rate in (0.6912, 0.55296):
@@ -131,6 +132,8 @@ def test_demod_tables_match_oracle(sim, oracle):
     sb = np.zeros(120, np.uint8)
     oracle.lib().orc_scrambler_bits(sb.ctypes.data, 120)
     assert bytes(t.scrambler) == bytes(sb)
+    m = np.arange(128, dtype=np.float32)
+    assert np.array_equal(np.frombuffer(t.corr_tab, np.float32), np.float32(2.0) * m / np.float32(127) - np.float32(1.0))
 
 
 def test_psk_soft_matches_oracle(sim, oracle):
