@@ -143,6 +143,7 @@ def main():
     t0 = time.time()
     fe = hf.Frontend(w["fs"], w["centerfreq"], freqs, device=dev_index)
     g = fe.geometry
+    fe.enable_taps(False)            # per-stage debug taps (DATADUMPS analogue) are a test facility, not part of the path
     t_create = time.time() - t0
     t0 = time.time()
     x, bursts = make_input(w, g.input_size, rank, world)

@@ -22,7 +22,8 @@ struct Demod {
 	int32_t *d_freqs = nullptr;
 	int pdu_cap = 0;
 	// stage taps
-	bool taps_on = true;
+	bool taps_on = true;                    // buffers allocated
+	bool taps_enabled = true;               // written by the kernel this block
 	float2 *d_tap_rs = nullptr, *d_tap_mf = nullptr, *d_tap_sym = nullptr;
 	float *d_tap_lvl = nullptr;
 	int *d_tap_counts = nullptr;            // [nch][2]

@@ -312,7 +312,8 @@ int Demod::enqueue_block(const float2 *chan_out, const int *out_count, hipStream
 	if (!pv) return HFDL_GPU_EINVAL;
 	DemodBuffers B;
 	B.states = d_states; B.data = (cf *)d_data; B.frames = d_frames; B.counts = d_counts; B.frame_cap = nch;
-	B.tap_rs = (cf *)d_tap_rs; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
+	const bool tw = taps_on && taps_enabled;
+	B.tap_rs = tw ? (cf *)d_tap_rs : nullptr; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
 	B.cap = cap;
 	hipLaunchKernelGGL(demod_kernel, dim3((unsigned)nch), dim3(64), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
 	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)d_frames, d_counts, nch,
@@ -344,7 +345,7 @@ int Demod::collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st)
 
 int Demod::tap(int what, int channel, const void **src, size_t *nfloats)
 {
-	if (!taps_on) return HFDL_GPU_EINVAL;
+	if (!taps_on || !taps_enabled) return HFDL_GPU_EINVAL;
 	int counts[2];
 	D_TRY(hipMemcpy(counts, d_tap_counts + 2 * channel, sizeof(counts), hipMemcpyDeviceToHost));
 	switch (what) {

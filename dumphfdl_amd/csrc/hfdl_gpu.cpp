@@ -456,6 +456,15 @@ extern "C" int hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *
 	return 0;
 }
 
+extern "C" int hfdl_gpu_frontend_enable_taps(hfdl_gpu_frontend *fe, int enable)
+{
+	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	fe->demod.taps_enabled = enable != 0;
+	return 0;
+}
+
 extern "C" int hfdl_gpu_frontend_channel_stats(hfdl_gpu_frontend *fe, int32_t channel, hfdl_gpu_channel_stats *out)
 {
 	if (!fe || !out) return fail(HFDL_GPU_EINVAL, "null argument");

@@ -52,7 +52,7 @@ EXPORTS = [
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
-    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers",
+    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
@@ -88,6 +88,7 @@ def load():
     L.hfdl_gpu_frontend_stream.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_stream.restype = C.c_void_p
     L.hfdl_gpu_frontend_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.hfdl_gpu_frontend_enable_taps.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_frontend_channel_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ChannelStats)]
     L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
@@ -185,6 +186,9 @@ class Frontend:
         _check(load().hfdl_gpu_frontend_read_tap(self._h, what, channel, _p(buf), cap, C.byref(n)))
         out = buf[:n.value].copy()
         return out if what in (TAP_AGC_LEVEL, TAP_PHASE_CYCLES) else out.view(np.complex64)
+
+    def enable_taps(self, enable=True):
+        _check(load().hfdl_gpu_frontend_enable_taps(self._h, int(enable)))
 
     def channel_stats(self, channel):
         st = ChannelStats()

@@ -142,6 +142,7 @@ static void *frontend_thread(void *ctx)
 		do_exit = 1;
 	} else {
 		hfdl_gpu_frontend_geometry(fe, &fb->geo);
+		hfdl_gpu_frontend_enable_taps(fe, 0);
 		if (hfdl_gpu_host_alloc((void **)&stage, sizeof(float complex) * (size_t)fb->geo.input_size) != 0)
 			stage = hfdl_xcalloc((size_t)fb->geo.input_size, sizeof(float complex));
 		pdus = hfdl_xcalloc((size_t)max_pdus, sizeof(*pdus));

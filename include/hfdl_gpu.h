@@ -140,6 +140,9 @@ enum {
 	HFDL_GPU_TAP_AGC_LEVEL = 7,      /* f32[n], agc signal level per 5400-sps sample */
 	HFDL_GPU_TAP_PHASE_CYCLES = 8    /* f32[4]: shader cycles the last demod launch spent in resampler / AGC / matched filter / symbol loop */
 };
+/* Stage taps 4..8 make the demodulator write its intermediate samples to HBM every block; on by default (tests), a
+ * production caller / the bench turns them off.  Taps 1..3 are always available (they are the kernels' own buffers). */
+int  hfdl_gpu_frontend_enable_taps(hfdl_gpu_frontend *fe, int enable);
 /* dst holds `cap` floats; *n_floats receives the number written */
 int  hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel, float *dst, size_t cap, size_t *n_floats);
 
