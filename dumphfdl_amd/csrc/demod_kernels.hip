@@ -34,7 +34,12 @@ struct DemodBuffers {
 	int cap;
 };
 
-__global__ __launch_bounds__(64) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
+// __launch_bounds__(64, 8): at most 64 VGPRs.  The 256 demodulator wavefronts are co-resident with the fold kernel's
+// workgroups (stream A); at 83 VGPRs one demod wave made a SIMD too full for the fourth fold wave, so every CU hosting a
+// channel ran 3 instead of 4 fold workgroups and the HBM-bound fold lost ~15 % for as long as the demodulator was
+// resident (measured with sleeping stand-in waves too: profiles/r01_experiments.md).  The few spills land in the short
+// lanes-over-samples phases.
+__global__ __launch_bounds__(64, 8) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
 		const int *__restrict__ n_in, int outs_stride)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
