@@ -385,3 +385,29 @@ def test_full_size_cfg3_geometry(gpu, oracle):
         outs.append(np.stack([f2.read_tap(F.TAP_CHAN_OUT, c) for c in range(16)]))
         f2.close()
     assert rel_rms(outs[2], 0.5 * outs[0] - 1.5 * outs[1]) < 1e-5
+
+
+def test_marginal_snr_same_pdus_even_when_wrong(gpu, oracle):
+    """-6..4 dB in-channel SNR: a third of the dispatched PDUs carry bit errors and some bursts are missed -- the GPU must
+    dispatch exactly the PDUs the oracle does (same octets, right or wrong, same detection instant), FCS verdicts included."""
+    fs, cf = 1_000_000, 10_000_000
+    freqs = [int(cf + (i - 32) * 14_000 + 3_000) for i in range(64)]
+    rng = np.random.default_rng(99)
+    bursts = []
+    for f in freqs:
+        t = float(rng.uniform(0.3, 0.9))
+        for _ in range(2):
+            mode = int(rng.integers(0, 4))
+            amp = float(10 ** (rng.uniform(-6, 4) / 20) * 0.0025)        # in-channel noise rms ~ 0.0025
+            bursts.append(dict(freq=f, mode=mode, octets=synth.make_pdu(rng, mode), t0=t, amp=amp, cfo=float(rng.uniform(-25, 25))))
+            t += synth.burst_symbols_len(mode) / 1800 + 0.4
+    dur = max(b["t0"] for b in bursts) + 2.8
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.02, seed=7)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    good = [p for p in got if any(p["octets"][:len(b["octets"])] == b["octets"] for b in bursts if b["freq"] == p["freq"])]
+    assert 20 < len(good) < len(got) <= len(bursts)          # the regime really is marginal
+    for p in got:
+        assert (p["fcs_status"], p["pdu_kind"], p["hdr_len"]) == oracle.pdu_triage(p["octets"])
+    assert {p["fcs_status"] for p in got} >= {F.FCS_GOOD, F.FCS_BAD}
