@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-input", action="store_true",
+                    help="feed the blocks from page-locked HOST memory (PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--sample-format", default="cf32", choices=["cf32", "cs16"], help="with --host-input: raw format pushed over PCIe")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / final reduction at N > 1 (nccl = RCCL; gloo for a 1-GPU smoke of the N>1 path)")
     args = ap.parse_args()
@@ -149,8 +152,23 @@ def main():
     x, bursts = make_input(w, g.input_size, rank, world)
     t_gen = time.time() - t0
     nblocks = len(x) // g.input_size
-    dev = torch.from_numpy(x.view(np.float32)).cuda()          # resident in HBM before the timed region
-    ptrs = [dev.data_ptr() + 8 * b * g.input_size for b in range(nblocks)]
+    if args.host_input:
+        import ctypes
+        from dumphfdl_amd import frontend as F
+        if args.sample_format == "cs16":
+            raw = np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16)
+            fmt, bps = F.SFMT_CS16, 4
+        else:
+            raw, fmt, bps = x.view(np.float32), F.SFMT_CF32, 8
+        hbuf = hf.host_alloc(raw.nbytes)
+        ctypes.memmove(hbuf, raw.ctypes.data, raw.nbytes)
+        hptrs = [hbuf + bps * b * g.input_size for b in range(nblocks)]
+        push = lambda i: fe.push_host_ptr(hptrs[i], fmt)
+        dev = None
+    else:
+        dev = torch.from_numpy(x.view(np.float32)).cuda()          # resident in HBM before the timed region
+        ptrs = [dev.data_ptr() + 8 * b * g.input_size for b in range(nblocks)]
+        push = lambda i: fe.push_block(ptrs[i])
 
     def barrier():
         torch.cuda.synchronize()
@@ -160,14 +178,14 @@ def main():
 
     step = 0
     for _ in range(args.warmup):
-        fe.push_block(ptrs[step % nblocks]); step += 1
+        push(step % nblocks); step += 1
     fe.poll_pdus()
     fe.reset_timers(True)
     barrier()
     t0 = time.perf_counter()
     npdus = 0
     for _ in range(args.steps):
-        fe.push_block(ptrs[step % nblocks]); step += 1
+        push(step % nblocks); step += 1
     pdus = fe.poll_pdus()           # sync + device->host of every PDU produced by the timed blocks
     npdus = len(pdus)
     torch.cuda.synchronize()
@@ -197,7 +215,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if not args.host_input else "synthetic, fed from page-locked host memory as %s (PCIe-inclusive)" % args.sample_format,
             "config": {"workload": w["name"], "sample_rate": w["fs"], "channels": g.channels, "fft_size": g.fft_size,
                        "fft_inv_size": g.fft_inv_size, "block_samples": g.input_size, "resident_blocks": nblocks,
                        "parallelism": "1 independent %d-channel stream per GPU, no collectives" % g.channels},

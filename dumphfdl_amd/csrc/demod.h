@@ -28,6 +28,7 @@ struct Demod {
 	float *d_tap_lvl = nullptr;
 	int *d_tap_counts = nullptr;            // [nch][2]
 	size_t lds_bytes = 0;
+	void *priv = nullptr;                   // DemodPriv (host image of the tables + resolved device pointers)
 
 	int init(int nch, int outs, float resamp_rate, const int32_t *freqs, hipStream_t st);
 	int enqueue_block(const float2 *chan_out, const int *out_count, hipStream_t st);

@@ -253,15 +253,8 @@ static DevTables resolve_tables(const float *d_img, const DemodTables &h)
 	return t;
 }
 
-static DemodTables g_host_tables;      // last built image (rates differ per front end; kept per Demod below)
 struct DemodPriv { DemodTables h; DevTables t; };
-static std::vector<std::pair<const Demod *, DemodPriv *>> g_priv;
-
-static DemodPriv *priv_of(const Demod *d)
-{
-	for (auto &e : g_priv) if (e.first == d) return e.second;
-	return nullptr;
-}
+static DemodPriv *priv_of(const Demod *d) { return (DemodPriv *)d->priv; }
 
 static int set_big_lds(const void *fn, size_t bytes)
 {
@@ -276,11 +269,10 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	if (resamp_rate <= 0.5f || resamp_rate > 1.0f) return HFDL_GPU_ERANGE;   // one arbitrary stage, no half-band stages
 	auto *pv = new DemodPriv();
 	build_demod_tables(pv->h, resamp_rate);
-	g_host_tables = pv->h;
+	priv = pv;
 	D_TRY(hipMalloc(&d_tables, sizeof(DemodTables)));
 	D_TRY(hipMemcpyAsync(d_tables, &pv->h, sizeof(DemodTables), hipMemcpyHostToDevice, st));
 	pv->t = resolve_tables(d_tables, pv->h);
-	g_priv.emplace_back(this, pv);
 
 	std::vector<ChanState> init((size_t)nch);
 	for (auto &s : init) chan_state_init(s, pv->h.eq_h0);
@@ -381,7 +373,8 @@ void Demod::release()
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	d_tables = nullptr; d_states = nullptr; d_data = nullptr; d_frames = nullptr; d_counts = nullptr; d_pdus = nullptr; d_freqs = nullptr;
 	d_tap_rs = d_tap_mf = d_tap_sym = nullptr; d_tap_lvl = nullptr; d_tap_counts = nullptr;
-	for (size_t i = 0; i < g_priv.size(); i++) if (g_priv[i].first == this) { delete g_priv[i].second; g_priv.erase(g_priv.begin() + (long)i); break; }
+	delete (DemodPriv *)priv;
+	priv = nullptr;
 }
 
 int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out)

@@ -99,7 +99,10 @@ struct hfdl_gpu_frontend {
 	int device = 0;
 	hipStream_t stream = nullptr;       // A: ingest + forward FFT + fold + inverse FFT/NCO of block k
 	hipStream_t stream_b = nullptr;     // B: demodulator + burst decoder of block k-1, concurrent with A
+	hipStream_t stream_c = nullptr;     // C: host -> device copies of block k+1 into the other staging buffer
 	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
+	hipEvent_t ev_stage_ready[2] = { nullptr, nullptr }, ev_stage_free[2] = { nullptr, nullptr };
+	uint64_t host_blocks = 0;
 	int last_buf = 0;
 	int32_t sample_rate = 0, centerfreq = 0, decimation = 0;
 	float tbw = 0;
@@ -109,11 +112,11 @@ struct hfdl_gpu_frontend {
 	std::vector<int32_t> freqs;
 	std::vector<ChanConst> cc;
 	float2 *d_hist = nullptr, *d_work = nullptr, *d_spec = nullptr, *d_taps = nullptr, *d_partial = nullptr;
-	float2 *d_chan_out[2] = { nullptr, nullptr }, *d_tw_m = nullptr, *d_stage = nullptr;
+	float2 *d_chan_out[2] = { nullptr, nullptr }, *d_tw_m = nullptr, *d_stage[2] = { nullptr, nullptr };
 	int *d_out_count[2] = { nullptr, nullptr };
 	ChanConst *d_cc = nullptr;
 	NcoState *d_nco = nullptr;
-	size_t stage_cap = 0;
+	size_t stage_cap[2] = { 0, 0 };
 	Demod demod;
 	// fold timing
 	bool timing = false;
@@ -129,15 +132,18 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	hipSetDevice(fe->device);
 	if (fe->stream) (void)hipStreamSynchronize(fe->stream);
 	if (fe->stream_b) (void)hipStreamSynchronize(fe->stream_b);
-	for (int i = 0; i < 2; i++) { if (fe->ev_chan[i]) (void)hipEventDestroy(fe->ev_chan[i]); if (fe->ev_demod[i]) (void)hipEventDestroy(fe->ev_demod[i]); }
+	if (fe->stream_c) (void)hipStreamSynchronize(fe->stream_c);
+	for (int i = 0; i < 2; i++)
+		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_stage_ready[i], fe->ev_stage_free[i] }) if (e) (void)hipEventDestroy(e);
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	fe->demod.release();
 	fe->fft.release();
 	void *ptrs[] = { fe->d_hist, fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_out[0], fe->d_chan_out[1], fe->d_tw_m,
-		fe->d_stage, fe->d_cc, fe->d_nco, fe->d_out_count[0], fe->d_out_count[1] };
+		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_out_count[0], fe->d_out_count[1] };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (fe->stream) (void)hipStreamDestroy(fe->stream);
 	if (fe->stream_b) (void)hipStreamDestroy(fe->stream_b);
+	if (fe->stream_c) (void)hipStreamDestroy(fe->stream_c);
 	delete fe;
 }
 
@@ -243,7 +249,10 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 		// noise (profiles/r01_experiments.md), so a plain non-blocking stream is used
 		FE_TRY(hipStreamCreateWithFlags(&fe->stream_b, hipStreamNonBlocking));
 	}
+	FE_TRY(hipStreamCreateWithFlags(&fe->stream_c, hipStreamNonBlocking));
 	for (int i = 0; i < 2; i++) {
+		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_ready[i], hipEventDisableTiming));
+		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_free[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_chan[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_demod[i], hipEventDisableTiming));
 	}
@@ -323,35 +332,44 @@ extern "C" void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe) { return fe ? (
 
 static size_t sample_bytes(int fmt) { return fmt == SFMT_CS16 ? 4 : fmt == SFMT_CU8 ? 2 : 8; }
 
-static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, int fmt, int on_device, const void **dev)
+// Host input is double-buffered in HBM: the copy of block k+1 (stream C) runs while block k computes (stream A).
+// *stage_idx = staging buffer used (-1 for device input): the caller records ev_stage_free once stream A has read it.
+static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, int fmt, int on_device, const void **dev, int *stage_idx)
 {
+	*stage_idx = -1;
 	if (!fe || !iq) return fail(HFDL_GPU_EINVAL, "null argument");
 	if (fmt != SFMT_CF32 && fmt != SFMT_CS16 && fmt != SFMT_CU8) return fail(HFDL_GPU_EINVAL, "unknown sample format %d", fmt);
 	if (nsamples != (size_t)fe->plan.input_size)
 		return fail(HFDL_GPU_EINVAL, "a block is exactly %d samples (got %zu)", fe->plan.input_size, nsamples);
 	HIP_TRY(hipSetDevice(fe->device));
 	if (on_device) { *dev = iq; return 0; }
-	if (fe->stage_cap < nsamples) {
-		if (fe->d_stage) (void)hipFree(fe->d_stage);
-		fe->d_stage = nullptr; fe->stage_cap = 0;
-		HIP_TRY(hipMalloc(&fe->d_stage, sizeof(float2) * nsamples));
-		fe->stage_cap = nsamples;
+	const int sb = (int)(fe->host_blocks++ & 1);
+	if (fe->stage_cap[sb] < nsamples) {
+		HIP_TRY(hipStreamSynchronize(fe->stream));
+		if (fe->d_stage[sb]) (void)hipFree(fe->d_stage[sb]);
+		fe->d_stage[sb] = nullptr; fe->stage_cap[sb] = 0;
+		HIP_TRY(hipMalloc(&fe->d_stage[sb], sizeof(float2) * nsamples));
+		fe->stage_cap[sb] = nsamples;
 	}
-	// the staging buffer is reused block after block: same-stream ordering makes that safe
-	HIP_TRY(hipMemcpyAsync(fe->d_stage, iq, sample_bytes(fmt) * nsamples, hipMemcpyHostToDevice, fe->stream));
-	*dev = fe->d_stage;
+	HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_stage_free[sb], 0));     // stream A finished reading this buffer two blocks ago
+	HIP_TRY(hipMemcpyAsync(fe->d_stage[sb], iq, sample_bytes(fmt) * nsamples, hipMemcpyHostToDevice, fe->stream_c));
+	HIP_TRY(hipEventRecord(fe->ev_stage_ready[sb], fe->stream_c));
+	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_stage_ready[sb], 0));
+	*dev = fe->d_stage[sb];
+	*stage_idx = sb;
 	return 0;
 }
 
 // Stream A runs the channelizer of block k into buffer k&1; stream B demodulates it.  A may not overwrite a buffer
 // before B has finished with it (two blocks ago); B may not start before A has filled it.
-static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int *buf_out)
+static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx, int *buf_out)
 {
 	const Geometry &g = fe->geo;
 	const int buf = (int)(fe->blocks & 1);
 	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_demod[buf], 0));
 	launch_fft_forward(fe->fft.p, fe->d_hist, fresh, fmt, g.overlap, fe->d_work, fe->d_spec, true, fe->stream);
 	launch_copy_tail(fresh, fmt, fe->d_hist, g.input_size, g.overlap, fe->stream);
+	if (stage_idx >= 0) HIP_TRY(hipEventRecord(fe->ev_stage_free[stage_idx], fe->stream));   // input consumed: the copy stream may refill it
 	if (fe->timing) {
 		std::pair<hipEvent_t, hipEvent_t> e;
 		HIP_TRY(hipEventCreate(&e.first));
@@ -375,18 +393,19 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 extern "C" int hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
 {
 	const void *fresh = nullptr;
-	int rc = stage_input(fe, iq, nsamples, SFMT_CF32, on_device, &fresh);
+	int sidx = -1;
+	int rc = stage_input(fe, iq, nsamples, SFMT_CF32, on_device, &fresh, &sidx);
 	if (rc) return rc;
-	return enqueue_channelizer(fe, fresh, SFMT_CF32, nullptr);
+	return enqueue_channelizer(fe, fresh, SFMT_CF32, sidx, nullptr);
 }
 
 static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int fmt, int on_device)
 {
 	const void *fresh = nullptr;
-	int buf = 0;
-	int rc = stage_input(fe, raw, nsamples, fmt, on_device, &fresh);
+	int buf = 0, sidx = -1;
+	int rc = stage_input(fe, raw, nsamples, fmt, on_device, &fresh, &sidx);
 	if (rc) return rc;
-	if ((rc = enqueue_channelizer(fe, fresh, fmt, &buf))) return rc;
+	if ((rc = enqueue_channelizer(fe, fresh, fmt, sidx, &buf))) return rc;
 	HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
 	rc = fe->demod.enqueue_block(fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream_b);
 	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
@@ -421,10 +440,19 @@ extern "C" int hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe)
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	HIP_TRY(hipSetDevice(fe->device));
+	HIP_TRY(hipStreamSynchronize(fe->stream_c));
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipStreamSynchronize(fe->stream_b));
 	HIP_TRY(hipGetLastError());
 	return drain_events(fe);
+}
+
+extern "C" int hfdl_gpu_frontend_input_done(hfdl_gpu_frontend *fe)
+{
+	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(fe->device));
+	HIP_TRY(hipStreamSynchronize(fe->stream_c));
+	return 0;
 }
 
 extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)

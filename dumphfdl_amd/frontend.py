@@ -50,7 +50,7 @@ _lib = None
 EXPORTS = [
     "hfdl_gpu_plan_geometry", "hfdl_gpu_host_alloc", "hfdl_gpu_host_free",
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
-    "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
+    "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode",
@@ -84,6 +84,7 @@ def load():
     L.hfdl_gpu_frontend_channelize_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.hfdl_gpu_frontend_push_block_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     L.hfdl_gpu_frontend_sync.argtypes = [C.c_void_p]
+    L.hfdl_gpu_frontend_input_done.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_poll_pdus.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.hfdl_gpu_frontend_stream.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_stream.restype = C.c_void_p
@@ -108,6 +109,16 @@ def plan_geometry(decimation, transition_bw):
     g = Geometry()
     _check(load().hfdl_gpu_plan_geometry(decimation, transition_bw, C.byref(g)))
     return g
+
+
+def host_alloc(nbytes):
+    p = C.c_void_p()
+    _check(load().hfdl_gpu_host_alloc(C.byref(p), nbytes))
+    return p.value
+
+
+def host_free(ptr):
+    load().hfdl_gpu_host_free(C.c_void_p(ptr))
 
 
 def device_count():
@@ -160,6 +171,13 @@ class Frontend:
         else:
             s = np.ascontiguousarray(samples, dtype=np.complex64)
             _check(L.hfdl_gpu_frontend_channelize_block(self._h, _p(s), len(s), 0))
+
+    def push_host_ptr(self, ptr, sample_format=SFMT_CF32):
+        """ptr: address of a (page-locked) host buffer holding one block; valid until input_done() / sync()."""
+        _check(load().hfdl_gpu_frontend_push_block_raw(self._h, C.c_void_p(ptr), self.geometry.input_size, sample_format, 0))
+
+    def input_done(self):
+        _check(load().hfdl_gpu_frontend_input_done(self._h))
 
     def sync(self):
         _check(load().hfdl_gpu_frontend_sync(self._h))

@@ -99,9 +99,14 @@ int  hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int32_t sampl
 void hfdl_gpu_frontend_destroy(hfdl_gpu_frontend *fe);
 int  hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_geometry *g);
 
-/* Enqueue one block: exactly geometry.input_size new complex samples (interleaved I,Q float32).
- * on_device != 0: `iq` is a device pointer that stays valid until the next sync.  Asynchronous. */
+/* Enqueue one block: exactly geometry.input_size new complex samples (interleaved I,Q float32).  Asynchronous.
+ * on_device != 0: `iq` is a device pointer that stays valid until the next sync.
+ * on_device == 0: the host -> device copy runs on its own stream into one of two staging buffers, so the copy of block
+ *   k+1 overlaps the kernels of block k.  A pageable buffer may be reused as soon as the call returns; a page-locked
+ *   one (hfdl_gpu_host_alloc) only after hfdl_gpu_frontend_input_done() / _sync() / _poll_pdus(). */
 int  hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
+/* wait until every host -> device input copy enqueued so far has finished (the kernels keep running) */
+int  hfdl_gpu_frontend_input_done(hfdl_gpu_frontend *fe);
 /* Same, for raw recorder / SDR samples converted on the device inside the overlap-assembly load of the forward FFT
  * (convert_cs16 / convert_cu8 / convert_cf32, src/input-helpers.c:10-78): interleaved I,Q int16 (full scale 32767.5),
  * uint8 (offset 63.5, full scale 127) or float32.  Halves / quarters the host->device bytes per sample. */
