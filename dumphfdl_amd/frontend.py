@@ -42,7 +42,8 @@ class ChannelStats(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libhfdl_gpu.so")
+    # HFDL_GPU_LIB: load a specific build of the library (A/B measurements of two builds in one gpurun)
+    return os.environ.get("HFDL_GPU_LIB") or os.path.join(_HERE, "libhfdl_gpu.so")
 
 
 _lib = None
