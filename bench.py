@@ -184,9 +184,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     npdus = 0
-    for _ in range(args.steps):
+    pdus = []
+    for i in range(args.steps):
         push(step % nblocks); step += 1
-    pdus = fe.poll_pdus()           # sync + device->host of every PDU produced by the timed blocks
+        if i % 256 == 255:          # long runs: drain the device PDU ring now and then (one pipeline sync per 256 blocks)
+            pdus += fe.poll_pdus(16384)
+    pdus += fe.poll_pdus(16384)     # sync + device->host of every PDU produced by the timed blocks
     npdus = len(pdus)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

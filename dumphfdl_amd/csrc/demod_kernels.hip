@@ -283,7 +283,7 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	D_TRY(hipMalloc(&d_frames, sizeof(FrameRec) * (size_t)nch));
 	D_TRY(hipMalloc(&d_counts, sizeof(int) * 4));
 	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int) * 4, st));
-	pdu_cap = std::max(1024, 8 * nch);
+	pdu_cap = std::max(4096, 64 * nch);       // ~1 KiB each; polled by the host at least once per few seconds of signal
 	D_TRY(hipMalloc(&d_pdus, sizeof(hfdl_gpu_pdu) * (size_t)pdu_cap));
 	D_TRY(hipMalloc(&d_freqs, sizeof(int32_t) * (size_t)nch));
 	D_TRY(hipMemcpyAsync(d_freqs, freqs, sizeof(int32_t) * (size_t)nch, hipMemcpyHostToDevice, st));
