@@ -380,20 +380,19 @@ void Demod::release()
 int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out)
 {
 	const size_t in_bytes = (size_t)nframes * 2 * nbits, out_bytes = (size_t)nframes * ((nbits + 7) / 8);
-	uint8_t *d_in = nullptr, *d_out = nullptr;
-	D_TRY(hipMalloc(&d_in, in_bytes));
-	D_TRY(hipMalloc(&d_out, out_bytes));
-	D_TRY(hipMemcpy(d_in, soft, in_bytes, hipMemcpyHostToDevice));
-	D_TRY(hipMemset(d_out, 0, out_bytes));
 	const size_t lds = sizeof(uint64_t) * ((size_t)nbits + 8);
 	if (lds > 160 * 1024) return HFDL_GPU_ERANGE;
+	DevBuf d_in, d_out;
+	D_TRY(d_in.alloc(in_bytes));
+	D_TRY(d_out.alloc(out_bytes));
+	D_TRY(hipMemcpy(d_in.p, soft, in_bytes, hipMemcpyHostToDevice));
+	D_TRY(hipMemset(d_out.p, 0, out_bytes));
 	int rc = set_big_lds((const void *)viterbi_batch_kernel, lds);
 	if (rc) return rc;
-	hipLaunchKernelGGL(viterbi_batch_kernel, dim3((unsigned)nframes), dim3(64), lds, nullptr, d_in, nbits, d_out);
+	hipLaunchKernelGGL(viterbi_batch_kernel, dim3((unsigned)nframes), dim3(64), lds, nullptr, d_in.as<const uint8_t>(), nbits, d_out.as<uint8_t>());
 	D_TRY(hipDeviceSynchronize());
 	D_TRY(hipGetLastError());
-	D_TRY(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
-	(void)hipFree(d_in); (void)hipFree(d_out);
+	D_TRY(hipMemcpy(out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
 	return 0;
 }
 
@@ -417,35 +416,33 @@ int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const i
 		f.signal_level = 1.0f; f.noise_floor = 1.0f;
 		f.sample_index = (uint64_t)i;
 	}
-	uint8_t *d_scr = nullptr; FrameRec *d_fr = nullptr; cf *d_data = nullptr; int *d_counts = nullptr; int32_t *d_freqs = nullptr;
-	hfdl_gpu_pdu *d_pdus = nullptr;
-	D_TRY(hipMalloc(&d_scr, 128));
-	D_TRY(hipMemcpy(d_scr, h.scrambler, 120, hipMemcpyHostToDevice));
-	D_TRY(hipMalloc(&d_fr, sizeof(FrameRec) * fr.size()));
-	D_TRY(hipMemcpy(d_fr, fr.data(), sizeof(FrameRec) * fr.size(), hipMemcpyHostToDevice));
-	D_TRY(hipMalloc(&d_data, sizeof(cf) * data.size()));
-	D_TRY(hipMemcpy(d_data, data.data(), sizeof(cf) * data.size(), hipMemcpyHostToDevice));
+	DevBuf d_scr, d_fr, d_data, d_counts, d_freqs, d_pdus;
 	int counts[4] = { nframes, 0, 0, 0 };
-	D_TRY(hipMalloc(&d_counts, sizeof(counts)));
-	D_TRY(hipMemcpy(d_counts, counts, sizeof(counts), hipMemcpyHostToDevice));
-	D_TRY(hipMalloc(&d_freqs, sizeof(int32_t) * freqs.size()));
-	D_TRY(hipMemcpy(d_freqs, freqs.data(), sizeof(int32_t) * freqs.size(), hipMemcpyHostToDevice));
-	D_TRY(hipMalloc(&d_pdus, sizeof(hfdl_gpu_pdu) * (size_t)nframes));
+	D_TRY(d_scr.alloc(128));
+	D_TRY(hipMemcpy(d_scr.p, h.scrambler, 120, hipMemcpyHostToDevice));
+	D_TRY(d_fr.alloc(sizeof(FrameRec) * fr.size()));
+	D_TRY(hipMemcpy(d_fr.p, fr.data(), sizeof(FrameRec) * fr.size(), hipMemcpyHostToDevice));
+	D_TRY(d_data.alloc(sizeof(cf) * data.size()));
+	D_TRY(hipMemcpy(d_data.p, data.data(), sizeof(cf) * data.size(), hipMemcpyHostToDevice));
+	D_TRY(d_counts.alloc(sizeof(counts)));
+	D_TRY(hipMemcpy(d_counts.p, counts, sizeof(counts), hipMemcpyHostToDevice));
+	D_TRY(d_freqs.alloc(sizeof(int32_t) * freqs.size()));
+	D_TRY(hipMemcpy(d_freqs.p, freqs.data(), sizeof(int32_t) * freqs.size(), hipMemcpyHostToDevice));
+	D_TRY(d_pdus.alloc(sizeof(hfdl_gpu_pdu) * (size_t)nframes));
 	int rc = set_big_lds((const void *)burst_decode_kernel, k5_lds_bytes());
 	if (rc) return rc;
-	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nframes), dim3(64), k5_lds_bytes(), nullptr, (const FrameRec *)d_fr, d_counts, nframes,
-			(const cf *)d_data, (const uint8_t *)d_scr, (const int32_t *)d_freqs, d_pdus, nframes);
+	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nframes), dim3(64), k5_lds_bytes(), nullptr, d_fr.as<const FrameRec>(), d_counts.as<int>(),
+			nframes, d_data.as<const cf>(), d_scr.as<const uint8_t>(), d_freqs.as<const int32_t>(), d_pdus.as<hfdl_gpu_pdu>(), nframes);
 	D_TRY(hipDeviceSynchronize());
 	D_TRY(hipGetLastError());
 	std::vector<hfdl_gpu_pdu> out((size_t)nframes);
-	D_TRY(hipMemcpy(out.data(), d_pdus, sizeof(hfdl_gpu_pdu) * out.size(), hipMemcpyDeviceToHost));
+	D_TRY(hipMemcpy(out.data(), d_pdus.p, sizeof(hfdl_gpu_pdu) * out.size(), hipMemcpyDeviceToHost));
 	for (int i = 0; i < nframes; i++) lens[i] = 0;
 	for (auto &p : out) {       // PDU slots are claimed in completion order: route by channel (= frame index)
 		if (p.channel < 0 || p.channel >= nframes) continue;
 		lens[p.channel] = p.len;
 		std::memcpy(octets + (size_t)p.channel * HFDL_GPU_PDU_MAX_OCTETS, p.octets, (size_t)p.len);
 	}
-	(void)hipFree(d_scr); (void)hipFree(d_fr); (void)hipFree(d_data); (void)hipFree(d_counts); (void)hipFree(d_freqs); (void)hipFree(d_pdus);
 	return 0;
 }
 

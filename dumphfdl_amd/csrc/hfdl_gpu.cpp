@@ -195,8 +195,9 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	if (bad) return fail(HFDL_GPU_EINVAL, "fastddc planning failed for %d channel(s)", (int)bad);
 
 	// frequency-domain taps on the device: zero-pad to N, forward FFT, fftshift (src/fastddc.c:231-240)
-	float2 *d_pad = nullptr;
-	HIP_TRY(hipMalloc(&d_pad, sizeof(float2) * n));
+	DevBuf pad;
+	HIP_TRY(pad.alloc(sizeof(float2) * n));
+	float2 *d_pad = pad.as<float2>();
 	HIP_TRY(hipMemsetAsync(d_pad, 0, sizeof(float2) * n, fe->stream));
 	for (int c = 0; c < nch; c++) {
 		HIP_TRY(hipMemcpyAsync(d_pad, host.data() + (size_t)c * pl.taps_length, sizeof(float2) * (size_t)pl.taps_length,
@@ -205,7 +206,6 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	}
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipGetLastError());
-	(void)hipFree(d_pad);
 	return 0;
 }
 
@@ -540,19 +540,18 @@ extern "C" int hfdl_gpu_fft_forward(int device, const float *in, float *out, int
 	if (!in || !out) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = select_device(device);
 	if (rc) return rc;
-	HostFftPlan plan;
-	if ((rc = plan.build(n))) return rc;
-	float2 *d_in = nullptr, *d_work = nullptr, *d_out = nullptr;
-	HIP_TRY(hipMalloc(&d_in, sizeof(float2) * (size_t)n));
-	HIP_TRY(hipMalloc(&d_work, sizeof(float2) * (size_t)n));
-	HIP_TRY(hipMalloc(&d_out, sizeof(float2) * (size_t)n));
-	HIP_TRY(hipMemcpy(d_in, in, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
-	launch_fft_forward(plan.p, nullptr, d_in, SFMT_CF32, 0, d_work, d_out, shifted != 0, nullptr);
+	struct PlanGuard { HostFftPlan p; ~PlanGuard() { p.release(); } } plan;
+	if ((rc = plan.p.build(n))) return rc;
+	DevBuf d_in, d_work, d_out;
+	const size_t bytes = sizeof(float2) * (size_t)n;
+	HIP_TRY(d_in.alloc(bytes));
+	HIP_TRY(d_work.alloc(bytes));
+	HIP_TRY(d_out.alloc(bytes));
+	HIP_TRY(hipMemcpy(d_in.p, in, bytes, hipMemcpyHostToDevice));
+	launch_fft_forward(plan.p.p, nullptr, d_in.p, SFMT_CF32, 0, d_work.as<float2>(), d_out.as<float2>(), shifted != 0, nullptr);
 	HIP_TRY(hipDeviceSynchronize());
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpy(out, d_out, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost));
-	(void)hipFree(d_in); (void)hipFree(d_work); (void)hipFree(d_out);
-	plan.release();
+	HIP_TRY(hipMemcpy(out, d_out.p, bytes, hipMemcpyDeviceToHost));
 	return 0;
 }
 

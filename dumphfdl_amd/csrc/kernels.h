@@ -36,6 +36,17 @@ struct Geometry {
 	int32_t slices, rows_per_slice, nch;
 };
 
+// owning device allocation for the one-shot stage entry points (freed on every exit path)
+struct DevBuf {
+	void *p = nullptr;
+	DevBuf() = default;
+	DevBuf(const DevBuf &) = delete;
+	DevBuf &operator=(const DevBuf &) = delete;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+	template <typename T> T *as() const { return (T *)p; }
+};
+
 // ---- launchers (host side, defined next to their kernels) ----
 // sample formats of the raw ingest path (reference: src/input-helpers.c:10-78,108-125)
 enum { SFMT_CF32 = 0, SFMT_CS16 = 1, SFMT_CU8 = 2 };
