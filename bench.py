@@ -194,6 +194,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fold_ms, fold_n = fe.fold_time_ms()
+    stream_gbs = fe.stream_read_probe() if rank == 0 else None       # after the timed region: the board's own read ceiling
     barrier()
     from dumphfdl_amd import shard
     elapsed_max, total_samples, total_pdus = shard.reduce_job(elapsed, args.steps * g.input_size, npdus, dist, device=red_device)
@@ -227,7 +228,10 @@ def main():
             "pdus_rank0_fcs_good_on_device": sum(1 for p in pdus if p["fcs_status"] == 0),
             "roofline": {"bound": "hbm", "kernel": "fold_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n,
+                         "literal_bytes_per_launch": 16 * g.fft_size * (g.channels + 1),      # SURVEY 8(d) secondary figure
+                         "stream_read_GBs": stream_gbs,
+                         "frac_of_stream_read": (achieved / stream_gbs) if (achieved and stream_gbs) else None},
             "setup_s": {"frontend_create": round(t_create, 2), "input_synthesis": round(t_gen, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:

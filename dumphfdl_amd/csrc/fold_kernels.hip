@@ -86,6 +86,28 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__rest
 	}
 }
 
+// Read-only streaming probe: what this board's HBM delivers to the same access pattern (non-temporal 16-byte loads,
+// 1 KiB per wave instruction, contiguous spans per workgroup) with nothing else to do.  SURVEY.md 8(d) asks for it next to
+// the spec peak; bench.py reports it as roofline.stream_read_GBs.
+__global__ __launch_bounds__(FOLD_THREADS) void stream_read_kernel(const float4 *__restrict__ src, size_t n4_per_block, float *__restrict__ sink)
+{
+	const float4 *p = src + (size_t)blockIdx.x * n4_per_block + threadIdx.x;
+	float acc = 0.f;
+	for (size_t i = 0; i < n4_per_block; i += 4 * FOLD_THREADS) {
+		const float4 a = load_stream(p + i), b = load_stream(p + i + FOLD_THREADS);
+		const float4 c = load_stream(p + i + 2 * FOLD_THREADS), d = load_stream(p + i + 3 * FOLD_THREADS);
+		acc += a.x + b.y + c.z + d.w;
+	}
+	if (acc == 1.2345e33f) *sink = acc;
+}
+
+void launch_stream_read(const float2 *src, size_t bytes, float *sink, hipStream_t st)
+{
+	const size_t per_block = (size_t)4 << 20;                           // 4 MiB spans, like a fold workgroup's tap span
+	const unsigned blocks = (unsigned)(bytes / per_block);
+	hipLaunchKernelGGL(stream_read_kernel, dim3(blocks), dim3(FOLD_THREADS), 0, st, (const float4 *)src, per_block / 16, sink);
+}
+
 // generic fallback for row sizes that are not 512*2^k bins
 __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel_generic(const float2 *__restrict__ taps, const float2 *__restrict__ spec,
 		float2 *__restrict__ partial, size_t n, int m, int slices, int rows)

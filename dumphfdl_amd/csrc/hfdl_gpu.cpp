@@ -464,6 +464,36 @@ extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
 	return 0;
 }
 
+extern "C" int hfdl_gpu_frontend_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_per_s)
+{
+	if (!fe || !gb_per_s) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	// read the resident filter taps themselves (whole multiples of 4 MiB, at most 16 GiB), best of 3
+	size_t bytes = sizeof(float2) * (size_t)fe->geo.n * (size_t)fe->geo.nch;
+	bytes -= bytes % ((size_t)4 << 20);
+	if (bytes > ((size_t)16 << 30)) bytes = (size_t)16 << 30;
+	if (bytes == 0) return fail(HFDL_GPU_ERANGE, "front end too small for the probe");
+	DevBuf sink;
+	HIP_TRY(sink.alloc(sizeof(float)));
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	double best = 0;
+	for (int it = 0; it < 4; it++) {
+		HIP_TRY(hipEventRecord(e0, fe->stream));
+		launch_stream_read(fe->d_taps, bytes, sink.as<float>(), fe->stream);
+		HIP_TRY(hipEventRecord(e1, fe->stream));
+		HIP_TRY(hipEventSynchronize(e1));
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+		if (it > 0 && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	*gb_per_s = best;
+	return 0;
+}
+
 extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches)
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");

@@ -55,6 +55,7 @@ void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh,
 void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st);
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
 		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st);
+void launch_stream_read(const float2 *src, size_t bytes, float *sink, hipStream_t st);
 void launch_copy_tail(const void *fresh, int fmt, float2 *hist, int input_size, int overlap, hipStream_t st);
 
 }  // namespace hfdl

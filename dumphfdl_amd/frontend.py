@@ -53,7 +53,7 @@ EXPORTS = [
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
-    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers",
+    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
@@ -94,6 +94,7 @@ def load():
     L.hfdl_gpu_frontend_channel_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ChannelStats)]
     L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
+    L.hfdl_gpu_frontend_stream_read_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.hfdl_gpu_fft_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
     L.hfdl_gpu_viterbi27.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.hfdl_gpu_burst_decode.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -222,6 +223,11 @@ class Frontend:
         n = C.c_int64(0)
         _check(load().hfdl_gpu_frontend_fold_time_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def stream_read_probe(self):
+        v = C.c_double(0)
+        _check(load().hfdl_gpu_frontend_stream_read_probe(self._h, C.byref(v)))
+        return v.value
 
     def stream(self):
         return load().hfdl_gpu_frontend_stream(self._h)

@@ -154,6 +154,8 @@ int  hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel
 /* timing of the dominant kernel (fold) measured with HIP events on the front end's stream */
 int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
 int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
+/* what the board's HBM delivers to a read-only streaming kernel with the fold's access pattern (reads the resident taps) */
+int  hfdl_gpu_frontend_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_per_s);
 
 /* ---- stage-level entry points (host pointers; allocate / copy / free internally) ---- */
 
