@@ -411,3 +411,41 @@ def test_marginal_snr_same_pdus_even_when_wrong(gpu, oracle):
     for p in got:
         assert (p["fcs_status"], p["pdu_kind"], p["hdr_len"]) == oracle.pdu_triage(p["octets"])
     assert {p["fcs_status"] for p in got} >= {F.FCS_GOOD, F.FCS_BAD}
+
+
+@pytest.mark.parametrize("fs,offs", [(12_000, [-2_000]), (48_000, [-15_000, 9_000]), (768_000, [-300_000, 5_000, 333_000]),
+                                      (2_400_000, [-1_100_000, 1_050_000])])
+def test_other_sample_rates(gpu, oracle, fs, offs):
+    """Receiver rates outside BASELINE.json's configs (12 ksps = post_decimation only, Airspy 768 ksps, RTL 2.4 Msps):
+    geometry, channelizer output and decoded PDUs against the oracle."""
+    cf = 10_000_000
+    freqs = [cf + o for o in offs]
+    rng = np.random.default_rng(fs)
+    bursts = [dict(freq=f, mode=int(rng.integers(0, 4)), octets=b"", t0=0.4 + 0.1 * i, amp=0.05, cfo=float(rng.uniform(-10, 10)))
+              for i, f in enumerate(freqs)]
+    for b in bursts:
+        b["octets"] = synth.make_pdu(rng, b["mode"])
+    fe = gpu.Frontend(fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs)
+    g, od = fe.geometry, ora.ddc
+    for name in ("fft_size", "fft_inv_size", "input_size", "post_input_size", "scrap", "taps_length", "pre_decimation", "post_decimation"):
+        assert getattr(g, name) == getattr(od, name), name
+    dur = 3.4
+    nsamp = (int(dur * fs) // g.input_size + 1) * g.input_size
+    dec = g.pre_decimation * g.post_decimation
+    x = synth.synth_wideband(fs, cf, nsamp, bursts, noise_sigma=0.01 * np.sqrt(dec / 32.0), seed=3)
+    worst = 0.0
+    for b in range(nsamp // g.input_size):
+        blk = x[b * g.input_size:(b + 1) * g.input_size]
+        fe.push_block(blk)
+        ora.push_block(blk)
+        if b % 7 == 0:
+            for c in range(len(freqs)):
+                got, want = fe.read_tap(F.TAP_CHAN_OUT, c), ora.channel_view(c)["chan_out"]
+                assert len(got) == len(want)
+                worst = max(worst, rel_rms(got, want))
+    assert worst < RMS_TOL, worst
+    got = sorted((p["freq"], p["sample_index"], p["octets"]) for p in fe.poll_pdus())
+    assert got == sorted((p["freq"], p["sample_index"], p["octets"]) for p in ora.pdus)
+    assert len(got) == len(freqs)
+    fe.close()
