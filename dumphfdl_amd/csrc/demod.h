@@ -17,7 +17,9 @@ struct Demod {
 	ChanState *d_states = nullptr;
 	float2 *d_data = nullptr;               // [nch][2][5040] equalised data symbols
 	FrameRec *d_frames = nullptr;
-	int *d_counts = nullptr;                // [0] frames queued this block, [1] pdus waiting, [2] pdus dropped
+	int *d_counts = nullptr;                // [0] frames queued this block, [1] pdus produced, [2] pdus dropped, [3] pdus taken by the host
+	int *h_snap = nullptr;                  // pinned [2][4]: d_counts as of the end of the block that used buffer 0 / 1
+	uint32_t taken = 0, dropped = 0;
 	hfdl_gpu_pdu *d_pdus = nullptr;
 	int32_t *d_freqs = nullptr;
 	int pdu_cap = 0;
@@ -31,8 +33,11 @@ struct Demod {
 	void *priv = nullptr;                   // DemodPriv (host image of the tables + resolved device pointers)
 
 	int init(int nch, int outs, float resamp_rate, const int32_t *freqs, hipStream_t st);
-	int enqueue_block(const float2 *chan_out, const int *out_count, hipStream_t st);
-	int collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);
+	int enqueue_block(const float2 *chan_out, const int *out_count, int buf, hipStream_t st);
+	int collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);                    // stream idle: everything produced
+	int collect_snapshot(int buf, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);  // up to the end of that buffer's block
+	int take(unsigned produced, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);
+	int stats_all(hfdl_gpu_channel_stats *out, int n);
 	int tap(int what, int channel, const void **src, size_t *nfloats);
 	int stats(int channel, hfdl_gpu_channel_stats *out);
 	void release();

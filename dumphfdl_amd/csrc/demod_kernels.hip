@@ -7,6 +7,7 @@
 //                          libfec update_viterbi27_blk / chainback_viterbi27, src/libfec/viterbi27_port.c:105-221).
 //     Viterbi mapping: lane = trellis state (64 = one wavefront); the two predecessor metrics arrive by
 //     cross-lane shuffle, the 64 decisions of a trellis step are one __ballot word kept in LDS.
+#include <cstdlib>
 #include <vector>
 #include <cstring>
 #include "demod_core.h"
@@ -179,10 +180,19 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 			vin[j] = table[((9 * j) % 40) * cols + j / 40];
 		}
 	}
-	int slot = 0;
+	// claim a slot of the PDU ring: counts[1] = PDUs ever produced, counts[3] = PDUs the host has taken (both mod 2^32);
+	// a full ring drops the PDU (counts[2]) without leaving a hole
+	int slot = -1;
 	if (lane == 0) {
-		slot = atomicAdd(&counts[1], 1);
-		if (slot >= pdu_cap) { atomicAdd(&counts[2], 1); slot = -1; }
+		unsigned *produced = (unsigned *)&counts[1];
+		const unsigned taken = *(volatile unsigned *)&counts[3];
+		unsigned t = *(volatile unsigned *)produced;
+		for (;;) {
+			if (t - taken >= (unsigned)pdu_cap) { atomicAdd(&counts[2], 1); break; }
+			const unsigned seen = atomicCAS(produced, t, t + 1u);
+			if (seen == t) { slot = (int)(t % (unsigned)pdu_cap); break; }
+			t = seen;
+		}
 	}
 	slot = __shfl(slot, 0);
 	__syncthreads();
@@ -283,7 +293,14 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	D_TRY(hipMalloc(&d_frames, sizeof(FrameRec) * (size_t)nch));
 	D_TRY(hipMalloc(&d_counts, sizeof(int) * 4));
 	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int) * 4, st));
+	D_TRY(hipHostMalloc((void **)&h_snap, sizeof(int) * 8, hipHostMallocDefault));
+	std::memset(h_snap, 0, sizeof(int) * 8);
+	taken = 0; dropped = 0;
 	pdu_cap = std::max(4096, 64 * nch);       // ~1 KiB each; polled by the host at least once per few seconds of signal
+	if (const char *e = getenv("HFDL_GPU_PDU_RING")) {       // test / tuning knob (include/hfdl_gpu.h)
+		const long v = strtol(e, nullptr, 10);
+		if (v >= 1 && v <= (1 << 20)) pdu_cap = (int)v;
+	}
 	D_TRY(hipMalloc(&d_pdus, sizeof(hfdl_gpu_pdu) * (size_t)pdu_cap));
 	D_TRY(hipMalloc(&d_freqs, sizeof(int32_t) * (size_t)nch));
 	D_TRY(hipMemcpyAsync(d_freqs, freqs, sizeof(int32_t) * (size_t)nch, hipMemcpyHostToDevice, st));
@@ -303,7 +320,7 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	return 0;
 }
 
-int Demod::enqueue_block(const float2 *chan_out, const int *out_count, hipStream_t st)
+int Demod::enqueue_block(const float2 *chan_out, const int *out_count, int buf, hipStream_t st)
 {
 	DemodPriv *pv = priv_of(this);
 	if (!pv) return HFDL_GPU_EINVAL;
@@ -316,7 +333,30 @@ int Demod::enqueue_block(const float2 *chan_out, const int *out_count, hipStream
 	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)d_frames, d_counts, nch,
 			(const cf *)d_data, pv->t.scrambler, (const int32_t *)d_freqs, d_pdus, pdu_cap);
 	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int), st));
+	// what the ring holds once this block is done, for a host that collects without draining the pipeline
+	D_TRY(hipMemcpyAsync(h_snap + 4 * (buf & 1), d_counts, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
 	D_TRY(hipGetLastError());
+	return 0;
+}
+
+// copy ring entries [taken, produced) to the host, at most `max`; every entry below `produced` is complete
+int Demod::take(unsigned produced, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st)
+{
+	unsigned have = produced - taken;
+	if (have > (unsigned)pdu_cap) have = (unsigned)pdu_cap;
+	const unsigned want = max < 0 ? 0u : (unsigned)max;
+	const unsigned cnt = have < want ? have : want;
+	if (cnt > 0 && out) {
+		const unsigned first = taken % (unsigned)pdu_cap;
+		const unsigned run = cnt < (unsigned)pdu_cap - first ? cnt : (unsigned)pdu_cap - first;
+		D_TRY(hipMemcpy(out, d_pdus + first, sizeof(hfdl_gpu_pdu) * run, hipMemcpyDeviceToHost));
+		if (cnt > run) D_TRY(hipMemcpy(out + run, d_pdus, sizeof(hfdl_gpu_pdu) * (cnt - run), hipMemcpyDeviceToHost));
+	}
+	if (cnt > 0) {
+		taken += cnt;
+		D_TRY(hipMemsetD32Async((hipDeviceptr_t)(d_counts + 3), (int)taken, 1, st));    // ordered after the blocks already queued
+	}
+	*n = (int32_t)cnt;
 	return 0;
 }
 
@@ -325,19 +365,15 @@ int Demod::collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st)
 	int counts[4];
 	D_TRY(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, st));
 	D_TRY(hipStreamSynchronize(st));
-	int have = counts[1] > pdu_cap ? pdu_cap : counts[1];
-	int take = have < max ? have : max;
-	if (take > 0 && out) D_TRY(hipMemcpy(out, d_pdus, sizeof(hfdl_gpu_pdu) * (size_t)take, hipMemcpyDeviceToHost));
-	if (take < have) {
-		// keep the rest: slide it to the front of the ring
-		std::vector<hfdl_gpu_pdu> rest((size_t)(have - take));
-		D_TRY(hipMemcpy(rest.data(), d_pdus + take, sizeof(hfdl_gpu_pdu) * rest.size(), hipMemcpyDeviceToHost));
-		D_TRY(hipMemcpy(d_pdus, rest.data(), sizeof(hfdl_gpu_pdu) * rest.size(), hipMemcpyHostToDevice));
-	}
-	int left = have - take;
-	D_TRY(hipMemcpy(d_counts + 1, &left, sizeof(int), hipMemcpyHostToDevice));
-	*n = take;
-	return 0;
+	dropped = (uint32_t)counts[2];
+	return take((unsigned)counts[1], out, max, n, st);
+}
+
+int Demod::collect_snapshot(int buf, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st)
+{
+	const volatile int *snap = h_snap + 4 * (buf & 1);
+	dropped = (uint32_t)snap[2];
+	return take((unsigned)snap[1], out, max, n, st);
 }
 
 int Demod::tap(int what, int channel, const void **src, size_t *nfloats)
@@ -354,16 +390,30 @@ int Demod::tap(int what, int channel, const void **src, size_t *nfloats)
 	}
 }
 
-int Demod::stats(int channel, hfdl_gpu_channel_stats *out)
+static void fill_stats(const ChanScalars &sc, hfdl_gpu_channel_stats *out)
 {
-	ChanScalars sc;
-	D_TRY(hipMemcpy(&sc, &d_states[channel].s, sizeof(sc), hipMemcpyDeviceToHost));
 	out->a2_found = sc.cnt_a2_found; out->m1_found = sc.cnt_m1_found; out->m1_not_found = sc.cnt_m1_not_found; out->frames = sc.cnt_frames;
 	out->noise_floor_db = 20.0f * log10f(sc.noise_floor);
 	out->agc_level = 1.0f / sc.agc_g;
 	out->costas_dphi = sc.dphi;
 	out->framer_state = sc.fr_state;
 	out->sample_cnt = sc.sample_cnt; out->symbol_cnt = sc.symbol_cnt;
+}
+
+int Demod::stats(int channel, hfdl_gpu_channel_stats *out)
+{
+	ChanScalars sc;
+	D_TRY(hipMemcpy(&sc, &d_states[channel].s, sizeof(sc), hipMemcpyDeviceToHost));
+	fill_stats(sc, out);
+	return 0;
+}
+
+// all channels in one strided copy; does not wait for blocks in flight (each field is read whole, the set may straddle a block)
+int Demod::stats_all(hfdl_gpu_channel_stats *out, int n)
+{
+	std::vector<ChanScalars> sc((size_t)n);
+	D_TRY(hipMemcpy2D(sc.data(), sizeof(ChanScalars), &d_states[0].s, sizeof(ChanState), sizeof(ChanScalars), (size_t)n, hipMemcpyDeviceToHost));
+	for (int i = 0; i < n; i++) fill_stats(sc[(size_t)i], out + i);
 	return 0;
 }
 
@@ -371,6 +421,8 @@ void Demod::release()
 {
 	void *ptrs[] = { d_tables, d_states, d_data, d_frames, d_counts, d_pdus, d_freqs, d_tap_rs, d_tap_mf, d_tap_sym, d_tap_lvl, d_tap_counts };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
+	if (h_snap) (void)hipHostFree(h_snap);
+	h_snap = nullptr;
 	d_tables = nullptr; d_states = nullptr; d_data = nullptr; d_frames = nullptr; d_counts = nullptr; d_pdus = nullptr; d_freqs = nullptr;
 	d_tap_rs = d_tap_mf = d_tap_sym = nullptr; d_tap_lvl = nullptr; d_tap_counts = nullptr;
 	delete (DemodPriv *)priv;

@@ -124,12 +124,15 @@ struct hfdl_gpu_frontend {
 	double fold_ms = 0;
 	int64_t fold_launches = 0;
 	uint64_t blocks = 0;
+	uint64_t demod_blocks = 0;          // value of `blocks` after the last block that went through the demodulator
+	int demod_buf = -1;                 // ... and the buffer / snapshot slot it used
+	int prev_demod_buf = -1;            // the one before it
 };
 
 static void frontend_free(hfdl_gpu_frontend *fe)
 {
 	if (!fe) return;
-	hipSetDevice(fe->device);
+	(void)hipSetDevice(fe->device);
 	if (fe->stream) (void)hipStreamSynchronize(fe->stream);
 	if (fe->stream_b) (void)hipStreamSynchronize(fe->stream_b);
 	if (fe->stream_c) (void)hipStreamSynchronize(fe->stream_c);
@@ -407,9 +410,12 @@ static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int
 	if (rc) return rc;
 	if ((rc = enqueue_channelizer(fe, fresh, fmt, sidx, &buf))) return rc;
 	HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
-	rc = fe->demod.enqueue_block(fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream_b);
+	rc = fe->demod.enqueue_block(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b);
 	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_b));
+	fe->demod_blocks = fe->blocks;
+	fe->prev_demod_buf = fe->demod_buf;
+	fe->demod_buf = buf;
 	return 0;
 }
 
@@ -511,6 +517,45 @@ extern "C" int hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *
 	if (rc) return rc;
 	rc = fe->demod.collect(out, max, n, fe->stream_b);
 	if (rc) return fail(rc, "pdu collection failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n, int32_t max_in_flight)
+{
+	if (!fe || !n) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (max_in_flight <= 0) return hfdl_gpu_frontend_poll_pdus(fe, out, max, n);
+	*n = 0;
+	// leave the newest block running: wait for the one before it and take what the ring held when that one finished
+	const int buf = fe->prev_demod_buf;
+	if (buf < 0) return 0;                              // fewer than two blocks pushed: nothing is known to be done
+	HIP_TRY(hipSetDevice(fe->device));
+	HIP_TRY(hipEventSynchronize(fe->ev_demod[buf]));
+	int rc = fe->demod.collect_snapshot(buf, out, max, n, fe->stream_b);
+	if (rc) return fail(rc, "pdu collection failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_all_channel_stats(hfdl_gpu_frontend *fe, hfdl_gpu_channel_stats *out, int32_t cap, int32_t *n)
+{
+	if (!fe || !out || !n) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (cap < fe->geo.nch) return fail(HFDL_GPU_ERANGE, "%d channels, buffer holds %d", fe->geo.nch, cap);
+	HIP_TRY(hipSetDevice(fe->device));
+	memset(out, 0, sizeof(*out) * (size_t)fe->geo.nch);
+	int rc = fe->demod.stats_all(out, fe->geo.nch);
+	if (rc) return fail(rc, "stats read failed: %s", hipGetErrorString(hipGetLastError()));
+	for (int i = 0; i < fe->geo.nch; i++) out[i].freq = fe->freqs[(size_t)i];
+	*n = fe->geo.nch;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_counters(hfdl_gpu_frontend *fe, hfdl_gpu_frontend_counters_t *out)
+{
+	if (!fe || !out) return fail(HFDL_GPU_EINVAL, "null argument");
+	memset(out, 0, sizeof(*out));
+	out->blocks = fe->blocks;
+	out->pdus_taken = fe->demod.taken;
+	out->pdus_dropped = fe->demod.dropped;
+	out->pdu_ring_capacity = (uint32_t)fe->demod.pdu_cap;
 	return 0;
 }
 

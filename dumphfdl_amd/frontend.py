@@ -41,6 +41,10 @@ class ChannelStats(C.Structure):
                 ("framer_state", C.c_int32), ("sample_cnt", C.c_uint64), ("symbol_cnt", C.c_uint64)]
 
 
+class FrontendCounters(C.Structure):
+    _fields_ = [("blocks", C.c_uint64), ("pdus_taken", C.c_uint32), ("pdus_dropped", C.c_uint32), ("pdu_ring_capacity", C.c_uint32)]
+
+
 def lib_path():
     # HFDL_GPU_LIB: load a specific build of the library (A/B measurements of two builds in one gpurun)
     return os.environ.get("HFDL_GPU_LIB") or os.path.join(_HERE, "libhfdl_gpu.so")
@@ -52,7 +56,7 @@ EXPORTS = [
     "hfdl_gpu_plan_geometry", "hfdl_gpu_host_alloc", "hfdl_gpu_host_free",
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
-    "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
+    "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
@@ -87,6 +91,9 @@ def load():
     L.hfdl_gpu_frontend_sync.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_input_done.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_poll_pdus.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.hfdl_gpu_frontend_poll_pdus_ready.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+    L.hfdl_gpu_frontend_counters.argtypes = [C.c_void_p, C.POINTER(FrontendCounters)]
+    L.hfdl_gpu_frontend_all_channel_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.hfdl_gpu_frontend_stream.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_stream.restype = C.c_void_p
     L.hfdl_gpu_frontend_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -184,10 +191,14 @@ class Frontend:
     def sync(self):
         _check(load().hfdl_gpu_frontend_sync(self._h))
 
-    def poll_pdus(self, max_pdus=4096):
+    def poll_pdus(self, max_pdus=4096, max_in_flight=0):
+        """max_in_flight=0: everything decoded so far (drains the pipeline); 1: leave the newest block running."""
         buf = (Pdu * max_pdus)()
         n = C.c_int32(0)
-        _check(load().hfdl_gpu_frontend_poll_pdus(self._h, buf, max_pdus, C.byref(n)))
+        if max_in_flight:
+            _check(load().hfdl_gpu_frontend_poll_pdus_ready(self._h, buf, max_pdus, C.byref(n), max_in_flight))
+        else:
+            _check(load().hfdl_gpu_frontend_poll_pdus(self._h, buf, max_pdus, C.byref(n)))
         out = []
         for i in range(n.value):
             p = buf[i]
@@ -197,6 +208,18 @@ class Frontend:
                             fcs_status=p.fcs_status, pdu_kind=p.pdu_kind, hdr_len=p.hdr_len,
                             train_bits_bad=p.train_bits_bad, train_bits_total=p.train_bits_total))
         return out
+
+    def counters(self):
+        c = FrontendCounters()
+        _check(load().hfdl_gpu_frontend_counters(self._h, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in FrontendCounters._fields_}
+
+    def all_channel_stats(self):
+        nch = self.geometry.channels
+        buf = (ChannelStats * nch)()
+        n = C.c_int32(0)
+        _check(load().hfdl_gpu_frontend_all_channel_stats(self._h, buf, nch, C.byref(n)))
+        return [{k: getattr(buf[i], k) for k, _ in ChannelStats._fields_} for i in range(n.value)]
 
     def read_tap(self, what, channel=0):
         g = self.geometry

@@ -6,6 +6,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdbool.h>
+#include <unistd.h>
+#include <pthread.h>
 #include "hfdl_host.h"
 #include "hfdl_gpu.h"
 #include "host_internal.h"
@@ -91,11 +94,83 @@ size_t hfdl_channels_on_connection(struct block_connection *conn, struct hfdl_ch
 	return n;
 }
 
-void hfdl_print_summary(void) {}
+/* ---- StatsD-style observability (src/hfdl.c:818-840, 1082-1105): fed from the device-resident channel state ---- */
+
+__attribute__((weak)) void statsd_counter_per_channel_increment(int32_t freq, char *counter) { (void)freq; (void)counter; }
+__attribute__((weak)) void statsd_gauge_per_channel_set(int32_t freq, char *gauge, size_t value) { (void)freq; (void)gauge; (void)value; }
+
+static struct {
+	pthread_mutex_t lock;
+	hfdl_gpu_channel_stats *last;       /* newest snapshot, one entry per channel of the front end */
+	int32_t cnt;
+	uint64_t a2, m1, m1_missing, frames; /* totals over all channels */
+} g_obs = { .lock = PTHREAD_MUTEX_INITIALIZER };
+
+static int32_t g_nf_interval;
+void hfdl_nf_stats_set_interval(int32_t seconds) { g_nf_interval = seconds; }
+
+/* one strided device read per block; emits one increment per new event, like the per-symbol calls of the reference */
+static void publish_counters(hfdl_gpu_frontend *fe, hfdl_gpu_channel_stats *now, int32_t nch)
+{
+	int32_t n = 0;
+	if (hfdl_gpu_frontend_all_channel_stats(fe, now, nch, &n) != 0 || n != nch) return;
+	pthread_mutex_lock(&g_obs.lock);
+	if (g_obs.last == NULL || g_obs.cnt != nch) {
+		free(g_obs.last);
+		g_obs.last = hfdl_xcalloc((size_t)nch, sizeof(*g_obs.last));
+		g_obs.cnt = nch;
+	}
+	for (int32_t i = 0; i < nch; i++) {
+		const hfdl_gpu_channel_stats *o = &g_obs.last[i];
+		for (uint32_t k = o->a2_found; k != now[i].a2_found; k++) statsd_counter_per_channel_increment(now[i].freq, "demod.preamble.A2_found");
+		for (uint32_t k = o->m1_found; k != now[i].m1_found; k++) statsd_counter_per_channel_increment(now[i].freq, "demod.preamble.M1_found");
+		for (uint32_t k = o->m1_not_found; k != now[i].m1_not_found; k++) statsd_counter_per_channel_increment(now[i].freq, "demod.preamble.errors.M1_not_found");
+		g_obs.a2 += now[i].a2_found - o->a2_found;
+		g_obs.m1 += now[i].m1_found - o->m1_found;
+		g_obs.m1_missing += now[i].m1_not_found - o->m1_not_found;
+		g_obs.frames += now[i].frames - o->frames;
+	}
+	memcpy(g_obs.last, now, sizeof(*now) * (size_t)nch);
+	pthread_mutex_unlock(&g_obs.lock);
+}
+
+void hfdl_print_summary(void)
+{
+#ifdef DEBUG
+	pthread_mutex_lock(&g_obs.lock);
+	fprintf(stderr, "A2_found:\t\t%llu\nM1_found:\t\t%llu\nM1_not_found:\t\t%llu\nframes:\t\t\t%llu\n",
+			(unsigned long long)g_obs.a2, (unsigned long long)g_obs.m1, (unsigned long long)g_obs.m1_missing, (unsigned long long)g_obs.frames);
+	pthread_mutex_unlock(&g_obs.lock);
+#endif
+}
+
+static void *noise_floor_stats_thread(void *ctx)
+{
+	(void)ctx;
+	for (;;) {
+		sleep((unsigned)g_nf_interval);
+		pthread_mutex_lock(&g_obs.lock);
+		for (int32_t i = 0; i < g_obs.cnt; i++) {
+			/* tenths of dBFS, positive: a StatsD gauge takes neither floats nor negative values (src/hfdl.c:1093-1101) */
+			float nf = g_obs.last[i].noise_floor_db;
+			if (nf <= 0.f) statsd_gauge_per_channel_set(g_obs.last[i].freq, "noise_floor", (size_t)fabsf(roundf(nf * 10.f)));
+		}
+		pthread_mutex_unlock(&g_obs.lock);
+	}
+	return NULL;
+}
+
 int32_t hfdl_nf_stats_thread_start(struct block **channel_block_list, int32_t channel_cnt)
 {
-	(void)channel_block_list; (void)channel_cnt;
-	return 0;            /* StatsD gauges are out of scope */
+	(void)channel_block_list; (void)channel_cnt;     /* every channel of the front end reports; the list is implicit */
+	if (g_nf_interval <= 0) return 0;
+	pthread_t th;
+	pthread_attr_t attr;
+	pthread_attr_init(&attr);
+	pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_DETACHED);    /* start_thread() detaches, src/util.c:45-63 */
+	int ret = pthread_create(&th, &attr, noise_floor_stats_thread, NULL);
+	pthread_attr_destroy(&attr);
+	return ret == 0 ? 0 : -1;
 }
 
 /* ---- the front-end thread ---- */
@@ -128,8 +203,10 @@ static void *frontend_thread(void *ctx)
 	struct circ_buffer *ring = &block->consumer.in->circ_buffer;
 	struct block_connection *down = block->producer.out;
 	hfdl_gpu_frontend *fe = NULL;
-	float complex *stage = NULL;
+	float complex *stage[2] = { NULL, NULL };
+	bool stage_pinned = true;
 	hfdl_gpu_pdu *pdus = NULL;
+	hfdl_gpu_channel_stats *stats = NULL;
 	const int32_t max_pdus = 1024;
 
 	struct hfdl_channel_slot *slots[MAX_SLOTS];
@@ -143,14 +220,22 @@ static void *frontend_thread(void *ctx)
 	} else {
 		hfdl_gpu_frontend_geometry(fe, &fb->geo);
 		hfdl_gpu_frontend_enable_taps(fe, 0);
-		if (hfdl_gpu_host_alloc((void **)&stage, sizeof(float complex) * (size_t)fb->geo.input_size) != 0)
-			stage = hfdl_xcalloc((size_t)fb->geo.input_size, sizeof(float complex));
+		/* two page-locked staging blocks: block k+1 is read from the ring and copied while block k computes */
+		for (int i = 0; i < 2; i++)
+			if (hfdl_gpu_host_alloc((void **)&stage[i], sizeof(float complex) * (size_t)fb->geo.input_size) != 0) stage_pinned = false;
+		if (!stage_pinned)
+			for (int i = 0; i < 2; i++) {
+				if (stage[i]) hfdl_gpu_host_free(stage[i]);
+				stage[i] = hfdl_xcalloc((size_t)fb->geo.input_size, sizeof(float complex));
+			}
 		pdus = hfdl_xcalloc((size_t)max_pdus, sizeof(*pdus));
+		stats = hfdl_xcalloc(nch, sizeof(*stats));
 	}
 	pthread_barrier_wait(down->shared_buffer.consumers_ready);
 	struct timeval t0;
 	gettimeofday(&t0, NULL);
 	const size_t need = ok ? (size_t)fb->geo.input_size : 1;
+	uint64_t k = 0;
 	for (;;) {
 		pthread_mutex_lock(ring->mutex);
 		/* shutdown is honoured only when there is not a whole block left, so buffered samples are flushed (src/fft.c:39-48) */
@@ -158,24 +243,42 @@ static void *frontend_thread(void *ctx)
 			if (block_connection_is_shutdown_signaled(block->consumer.in)) { pthread_mutex_unlock(ring->mutex); goto shutdown; }
 			pthread_cond_wait(ring->cond, ring->mutex);
 		}
-		if (ok) hfdl_ring_read(ring->buf, stage, need); else hfdl_ring_read(ring->buf, (float complex[1]){0}, 1);
+		float complex *blk = stage[k & 1];
+		if (ok) hfdl_ring_read(ring->buf, blk, need); else hfdl_ring_read(ring->buf, (float complex[1]){0}, 1);
+		const bool backlog = hfdl_ring_size(ring->buf) >= need;      /* another whole block is already waiting */
 		pthread_mutex_unlock(ring->mutex);
 		if (!ok) continue;
-		if (hfdl_gpu_frontend_push_block(fe, (const float *)stage, need, 0) != 0) {
+		if (hfdl_gpu_frontend_push_block(fe, (const float *)blk, need, 0) != 0) {
 			fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
 			do_exit = 1;
 			ok = 0;
 			continue;
 		}
+		k++;
+		/* Keeping up with the source (live radio): wait for this block and deliver its PDUs at once.  Behind (file
+		 * replay, catching up): leave it running and collect the previous block, so the next ring read and copy overlap it.
+		 * Either way the other staging block is free again: its copy finished before the block now complete started. */
 		int32_t n = 0;
-		if (hfdl_gpu_frontend_poll_pdus(fe, pdus, max_pdus, &n) == 0)
+		do {
+			if (hfdl_gpu_frontend_poll_pdus_ready(fe, pdus, max_pdus, &n, backlog ? 1 : 0) != 0) break;
 			for (int32_t i = 0; i < n; i++) push_pdu(&pdus[i], &t0);
+		} while (n == max_pdus);
+		publish_counters(fe, stats, (int32_t)nch);
 	}
 shutdown:
+	if (fe) {
+		int32_t n = 0;
+		do {                                                             /* drain what the lagging collection left behind */
+			if (hfdl_gpu_frontend_poll_pdus(fe, pdus, max_pdus, &n) != 0) break;
+			for (int32_t i = 0; i < n; i++) push_pdu(&pdus[i], &t0);
+		} while (n == max_pdus);
+		publish_counters(fe, stats, (int32_t)nch);
+	}
 	block_connection_one2many_shutdown(down);
 	if (fe) hfdl_gpu_frontend_destroy(fe);
-	if (stage) hfdl_gpu_host_free(stage);
+	for (int i = 0; i < 2; i++) if (stage[i]) { if (stage_pinned) hfdl_gpu_host_free(stage[i]); else free(stage[i]); }
 	free(pdus);
+	free(stats);
 	free(freqs);
 	block->running = false;
 	return NULL;

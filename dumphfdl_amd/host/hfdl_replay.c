@@ -1,13 +1,44 @@
 /* hfdl_replay.c -- minimal host program over libhfdl_host.so: the wiring of dumphfdl's main() (src/main.c:687-802) for a raw
  * I/Q file, with the protocol parsers replaced by the library's printing pdu_decoder_queue_push().
  *
- *   hfdl_replay --iq-file FILE --sample-rate HZ --sample-format CF32|CS16|CU8 --centerfreq KHZ [--device N] FREQ_KHZ...
+ *   hfdl_replay --iq-file FILE --sample-rate HZ --sample-format CF32|CS16|CU8 --centerfreq KHZ [--device N]
+ *               [--statsd-print] [--noise-floor-stats-interval S] FREQ_KHZ...
+ *
+ * --statsd-print stands in for dumphfdl's src/statsd.c: the strong statsd_* hooks below print one "STATSD" line per
+ * counter total at exit and one per noise-floor gauge as it arrives (metric names as in doc/STATSD_METRICS.md).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 #include "hfdl_host.h"
+
+static int statsd_print;
+static struct tally { int32_t freq; unsigned a2, m1, m1_missing; } tallies[4096];
+static int ntallies;
+
+static struct tally *tally_of(int32_t freq)
+{
+	for (int i = 0; i < ntallies; i++) if (tallies[i].freq == freq) return &tallies[i];
+	if (ntallies == 4096) return NULL;
+	tallies[ntallies].freq = freq;
+	return &tallies[ntallies++];
+}
+
+/* called from the front-end thread only */
+void statsd_counter_per_channel_increment(int32_t freq, char *counter)
+{
+	struct tally *t = tally_of(freq);
+	if (t == NULL) return;
+	if (!strcmp(counter, "demod.preamble.A2_found")) t->a2++;
+	else if (!strcmp(counter, "demod.preamble.M1_found")) t->m1++;
+	else if (!strcmp(counter, "demod.preamble.errors.M1_not_found")) t->m1_missing++;
+}
+
+void statsd_gauge_per_channel_set(int32_t freq, char *gauge, size_t value)
+{
+	if (statsd_print) fprintf(stderr, "STATSD gauge %d.%s %zu\n", freq, gauge, value);
+}
 
 int main(int argc, char **argv)
 {
@@ -23,6 +54,8 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "--centerfreq") && i + 1 < argc) centerfreq_khz = atof(argv[++i]);
 		else if (!strcmp(argv[i], "--read-buffer-size") && i + 1 < argc) cfg->read_buffer_size = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--device") && i + 1 < argc) hfdl_frontend_set_device(atoi(argv[++i]));
+		else if (!strcmp(argv[i], "--statsd-print")) statsd_print = 1;
+		else if (!strcmp(argv[i], "--noise-floor-stats-interval") && i + 1 < argc) hfdl_nf_stats_set_interval(atoi(argv[++i]));
 		else if (argv[i][0] != '-' && nfreq < 4096) freqs[nfreq++] = (int32_t)(1e3 * atof(argv[i]));     /* kHz -> Hz, src/main.c:197-212 */
 		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
 	}
@@ -52,7 +85,12 @@ int main(int argc, char **argv)
 	if (block_connect_one2one(input, fft) != 1 || block_connect_one2many(fft, (size_t)nfreq, channels) != nfreq) return 1;
 	/* start order: channels, fft, input (src/main.c:770-774) */
 	if (block_set_start((size_t)nfreq, channels) != nfreq || block_start(fft) != 1 || block_start(input) != 1) return 1;
+	if (hfdl_nf_stats_thread_start(channels, nfreq) < 0) return 1;             /* src/main.c:777-783 */
 	while (block_is_running(input) || block_is_running(fft) || block_set_is_any_running((size_t)nfreq, channels)) usleep(20000);
+	hfdl_print_summary();
+	if (statsd_print)
+		for (int i = 0; i < ntallies; i++)
+			fprintf(stderr, "STATSD counter %d A2_found=%u M1_found=%u M1_not_found=%u\n", tallies[i].freq, tallies[i].a2, tallies[i].m1, tallies[i].m1_missing);
 	block_disconnect_one2many(fft, (size_t)nfreq, channels);
 	block_disconnect_one2one(input, fft);
 	for (int i = 0; i < nfreq; i++) hfdl_channel_destroy(channels[i]);

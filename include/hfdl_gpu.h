@@ -119,6 +119,22 @@ int  hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const float *iq, 
 int  hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe);
 /* Collect PDUs produced by all blocks enqueued so far (implies a sync). Returns count in *n. */
 int  hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n);
+/* Same without draining the pipeline: with max_in_flight = 1 the newest block keeps running; the call waits only for
+ * the block before it and returns what had been decoded when that one finished (nothing until two blocks were pushed).
+ * max_in_flight = 0 is hfdl_gpu_frontend_poll_pdus().  A file replay pushes block k+1, then collects block k this way,
+ * so copies, channelizer and demodulator of consecutive blocks overlap; a live receiver that has no further input
+ * queued uses 0 and gets its PDUs at once. */
+int  hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n, int32_t max_in_flight);
+/* PDUs wait in a device ring of pdu_ring_capacity entries; one that finds the ring full is dropped and counted
+ * (the reference's GAsyncQueue is unbounded, src/pdu.c:37-43: poll at least once per few seconds of signal).
+ * Capacity: max(4096, 64 per channel); the environment variable HFDL_GPU_PDU_RING overrides it at create time. */
+typedef struct {
+	uint64_t blocks;                 /* blocks pushed so far */
+	uint32_t pdus_taken;             /* PDUs handed to the host so far (mod 2^32) */
+	uint32_t pdus_dropped;           /* as of the last poll */
+	uint32_t pdu_ring_capacity;
+} hfdl_gpu_frontend_counters_t;
+int  hfdl_gpu_frontend_counters(hfdl_gpu_frontend *fe, hfdl_gpu_frontend_counters_t *out);
 /* the HIP stream all kernels of this front end are launched on (hipStream_t as void*) */
 void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe);
 
@@ -133,6 +149,9 @@ typedef struct {
 	uint64_t sample_cnt, symbol_cnt;
 } hfdl_gpu_channel_stats;
 int  hfdl_gpu_frontend_channel_stats(hfdl_gpu_frontend *fe, int32_t channel, hfdl_gpu_channel_stats *out);
+/* every channel in one strided device read, WITHOUT waiting for blocks in flight: each field is read whole, the set may
+ * straddle a block boundary (what a periodic gauge needs: noise_floor_stats_thread, src/hfdl.c:1082-1105) */
+int  hfdl_gpu_frontend_all_channel_stats(hfdl_gpu_frontend *fe, hfdl_gpu_channel_stats *out, int32_t cap, int32_t *n);
 
 /* stage taps -- the DATADUMPS analogue (src/hfdl.c:616-644): copy an intermediate buffer to host */
 enum {

@@ -160,6 +160,17 @@ void          hfdl_channel_destroy(struct block *channel_block);
 void          hfdl_print_summary(void);
 int32_t       hfdl_nf_stats_thread_start(struct block **channel_block_list, int32_t channel_cnt);
 
+/* seconds between noise-floor gauges (Config.nf_stats_interval, src/main.c:595, src/hfdl.c:1090); 0 = off.  Set before
+ * hfdl_nf_stats_thread_start(); not in the reference, which reads its global Config. */
+void          hfdl_nf_stats_set_interval(int32_t seconds);
+
+/* PROVIDED BY THE HOST PROGRAM when it is built WITH_STATSD (dumphfdl's src/statsd.c, prototypes src/statsd.h:10-20).
+ * The front-end thread calls them with the reference's metric names: "demod.preamble.A2_found", "demod.preamble.M1_found",
+ * "demod.preamble.errors.M1_not_found" once per event (src/hfdl.c:818-840) and the "noise_floor" gauge in tenths of
+ * -dBFS (src/hfdl.c:1093-1101).  libhfdl_host.so carries weak defaults that do nothing. */
+void statsd_counter_per_channel_increment(int32_t freq, char *counter);
+void statsd_gauge_per_channel_set(int32_t freq, char *gauge, size_t value);
+
 /* GPU selection for the front end created by the next fft_create() (default 0); not in the reference */
 void          hfdl_frontend_set_device(int device);
 

@@ -206,7 +206,7 @@ def test_no_device_pointer_confusion(gpu):
     fe.close()
 
 
-def _replay(tmp_path, x_raw, fmt, fs, cf, freqs):
+def _replay(tmp_path, x_raw, fmt, fs, cf, freqs, extra=(), want_stderr=False):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -216,14 +216,14 @@ def _replay(tmp_path, x_raw, fmt, fs, cf, freqs):
     path = tmp_path / ("iq." + fmt.lower())
     x_raw.tofile(path)
     out = subprocess.run([exe, "--iq-file", str(path), "--sample-rate", str(fs), "--sample-format", fmt, "--centerfreq", str(cf / 1e3)]
-                         + ["%.3f" % (f / 1e3) for f in freqs], capture_output=True, text=True, timeout=300)
+                         + list(extra) + ["%.3f" % (f / 1e3) for f in freqs], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     pdus = []
     for line in out.stdout.splitlines():
         if line.startswith("PDU "):
             kv = dict(t.split("=") for t in line.split()[1:-1])
             pdus.append((int(kv["freq"]), int(kv["bit_rate"]), kv["slot"], bytes.fromhex(line.split()[-1])))
-    return pdus
+    return (pdus, out.stderr) if want_stderr else pdus
 
 
 @pytest.mark.parametrize("fmt", ["CF32", "CS16"])
@@ -448,4 +448,128 @@ def test_other_sample_rates(gpu, oracle, fs, offs):
     got = sorted((p["freq"], p["sample_index"], p["octets"]) for p in fe.poll_pdus())
     assert got == sorted((p["freq"], p["sample_index"], p["octets"]) for p in ora.pdus)
     assert len(got) == len(freqs)
+    fe.close()
+
+
+def test_long_idle_then_burst(gpu, oracle):
+    """65 s of noise (twice the 13-frame search timeout that resets the loops, src/hfdl.c:745-752) and then one burst per
+    channel.  In noise the timing/carrier loops random-walk, so last-ulp differences between the lane-parallel float
+    sums on the device and the serial ones in the oracle decorrelate the two trajectories: the decoded octets, modes and
+    event counters must still be identical, the frame position may differ by a fraction of a symbol
+    (tolerance: 3 samples at 5400 Hz = one symbol), the noise-floor estimate by 0.5 dB."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_924_000, 9_978_000, 10_032_000, 10_086_000]
+    dur = 65.0
+    rng = np.random.default_rng(65)
+    bursts = [dict(freq=f, mode=i, octets=synth.make_pdu(rng, i), t0=dur - 3.0, amp=0.02, cfo=float(rng.uniform(-10, 10)))
+              for i, f in enumerate(freqs)]
+    fe = gpu.Frontend(fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs, nthreads=4)
+    n = fe.input_size
+    total, done, k = int(dur * fs) // n * n, 0, 0
+    while done < total:                                  # synthesised in 40-block pieces to bound host memory
+        m = min(40 * n, total - done)
+        live = [dict(b, t0=b["t0"] - done / fs) for b in bursts if -4 < b["t0"] - done / fs < m / fs + 1]
+        x = synth.synth_wideband(fs, cf, m, live, noise_sigma=0.01, seed=650 + k)
+        for b in range(m // n):
+            fe.push_block(x[b * n:(b + 1) * n])
+            ora.push_block(x[b * n:(b + 1) * n], nthreads=4)
+        done, k = done + m, k + 1
+    got = {p["freq"]: p for p in fe.poll_pdus()}
+    want = {p["freq"]: p for p in ora.pdus}
+    assert sorted(got) == sorted(want) == sorted(freqs)
+    for b in bursts:
+        g, w = got[b["freq"]], want[b["freq"]]
+        assert g["octets"] == w["octets"] and g["octets"][:len(b["octets"])] == b["octets"]
+        assert (g["mode"], g["slot"], g["bit_rate"]) == (w["mode"], w["slot"], w["bit_rate"])
+        assert abs(g["sample_index"] - w["sample_index"]) <= 3
+        assert abs(g["freq_err_hz"] - w["freq_err_hz"]) < 0.5
+    for c in range(len(freqs)):
+        sg, so = fe.channel_stats(c), ora.channel_counters(c)
+        for key in ("a2_found", "m1_found", "m1_not_found", "frames"):
+            if key in sg and key in so:
+                assert sg[key] == so[key], key
+        assert abs(sg["noise_floor_db"] - 20 * np.log10(so["noise_floor"])) < 0.5
+    fe.close()
+
+
+def test_host_c_program_statsd_counters(gpu, oracle, tmp_path):
+    """The C host emits the reference's per-channel StatsD counters (src/hfdl.c:818-840) from device state: a program
+    that defines the statsd_* hooks (here hfdl_replay --statsd-print) sees one increment per event, as many as the oracle counts."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_930_000, 10_037_000, 10_081_500]
+    bursts = synth.plan_traffic(freqs, 8.0, seed=8, dense=True)
+    x = synth.synth_wideband(fs, cf, int(8.0 * fs), bursts, noise_sigma=0.01, seed=8)
+    got, err = _replay(tmp_path, x.view(np.float32), "CF32", fs, cf, freqs, extra=["--statsd-print"], want_stderr=True)
+    ora = oracle.Frontend(fs, cf, freqs)
+    n = ora.ddc.input_size
+    for b in range(len(x) // n):
+        ora.push_block(x[b * n:(b + 1) * n])
+    assert sorted(got) == sorted((p["freq"], p["bit_rate"], p["slot"], p["octets"]) for p in ora.pdus) and len(got) == len(bursts)
+    seen = {}
+    for line in err.splitlines():
+        if line.startswith("STATSD counter "):
+            t = line.split()
+            seen[int(t[2])] = {k: int(v) for k, v in (kv.split("=") for kv in t[3:])}
+    for c, f in enumerate(freqs):
+        want = ora.channel_counters(c)
+        assert seen[f] == dict(A2_found=want["a2_found"], M1_found=want["m1_found"], M1_not_found=want["m1_not_found"])
+    assert sum(v["M1_found"] for v in seen.values()) == len(bursts)
+
+
+@pytest.mark.parametrize("ring", [0, 3])
+def test_collect_without_draining_the_pipeline(gpu, oracle, monkeypatch, ring):
+    """hfdl_gpu_frontend_poll_pdus_ready(max_in_flight=1) after every push + one draining poll at the end delivers each
+    PDU exactly once; with a 3-entry device ring (HFDL_GPU_PDU_RING) the slots wrap many times without loss."""
+    if ring:
+        monkeypatch.setenv("HFDL_GPU_PDU_RING", str(ring))
+    fs, cf = 250000, 10_000_000
+    freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000]
+    dur = 14.0
+    bursts = synth.plan_traffic(freqs, dur, seed=21, dense=True, gap_s=0.15, amp=(0.03, 0.1))
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.01, seed=21)
+    fe = gpu.Frontend(fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs)
+    n = fe.input_size
+    got, early = [], 0
+    for b in range(len(x) // n):
+        fe.push_block(x[b * n:(b + 1) * n])
+        ora.push_block(x[b * n:(b + 1) * n])
+        part = fe.poll_pdus(max_in_flight=1)
+        early += len(part)
+        got += part
+    got += fe.poll_pdus()
+    cnt = fe.counters()
+    assert cnt["pdus_dropped"] == 0 and cnt["pdus_taken"] == len(got) and cnt["pdu_ring_capacity"] == (ring or 4096)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, ora.pdus)) and len(got) >= len(bursts) - 1
+    assert early >= len(got) - len(freqs)                 # all but the last block's worth arrived through the lagging path
+    stats = fe.all_channel_stats()
+    assert [s["freq"] for s in stats] == freqs
+    assert [s["frames"] for s in stats] == [fe.channel_stats(c)["frames"] for c in range(len(freqs))]
+    fe.close()
+
+
+def test_full_pdu_ring_drops_and_counts(gpu, oracle, monkeypatch):
+    """More frames finishing in one block than the device ring holds: the surplus is dropped and counted, what is
+    delivered is intact, and the ring keeps working afterwards."""
+    monkeypatch.setenv("HFDL_GPU_PDU_RING", "16")
+    fs, cf = 1_000_000, 10_000_000
+    freqs = [int(cf + (i - 32) * 14_000 + 3_000) for i in range(64)]
+    rng = np.random.default_rng(12)
+    bursts = [dict(freq=f, mode=0, octets=synth.make_pdu(rng, 0), t0=0.3, amp=0.02, cfo=0.0) for f in freqs]
+    late = dict(freq=freqs[5], mode=1, octets=synth.make_pdu(rng, 1), t0=3.4, amp=0.02, cfo=0.0)
+    x = synth.synth_wideband(fs, cf, int(6.5 * fs), bursts + [late], noise_sigma=0.002, seed=12)
+    fe = gpu.Frontend(fs, cf, freqs)
+    n = fe.input_size
+    got = []
+    for b in range(len(x) // n):
+        fe.push_block(x[b * n:(b + 1) * n])
+        got += fe.poll_pdus()
+    cnt = fe.counters()
+    sent = {b["octets"] for b in bursts}
+    first = [p for p in got if p["mode"] == 0]
+    assert len(first) == 16 and cnt["pdus_dropped"] == 64 - 16
+    assert all(p["octets"][:len(next(iter(sent)))] in sent for p in first)
+    assert [p["octets"][:len(late["octets"])] for p in got if p["mode"] == 1] == [late["octets"]]
     fe.close()
