@@ -29,28 +29,31 @@ __device__ __forceinline__ float2 load_sample(const void *__restrict__ raw, int 
 
 // pass 1: columns c = n2*R3+n3 (stride R2*R3 between the R1 samples of a column).  Input is the
 // virtual concatenation [hist(split) , fresh(n-split)] -- the overlap assembly of src/fft.c:49-54.
+// The last `split` samples of the block are the next block's history: they are written to `hist_next` (a second buffer,
+// never the one being read) as they pass through, so no separate copy runs.
 template <int FMT>
 __global__ __launch_bounds__(FFT_THREADS) void fft_pass1(const float2 *__restrict__ hist, const void *__restrict__ fresh,
-		int split, float2 *__restrict__ out, FftPlan p)
+		int split, float2 *__restrict__ hist_next, float2 *__restrict__ out, FftPlan p)
 {
 	extern __shared__ float2 sm[];
 	const int cs = p.n >> p.l1;            // R2*R3 columns
 	const int c0 = blockIdx.x * FFT_TILE;
 	const int total = p.r1 * FFT_TILE;
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
-		const int r = e >> 4, col = e & 15;
+		const int r = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
 		const int c = c0 + col;
 		float2 v = make_float2(0.f, 0.f);
 		if (c < cs) {
 			const int idx = r * cs + c;
 			v = idx < split ? hist[idx] : load_sample<FMT>(fresh, idx - split);
+			if (hist_next != nullptr && idx >= p.n - split) hist_next[idx - (p.n - split)] = v;
 		}
 		sm[e] = v;
 	}
 	__syncthreads();
-	lds_fft_columns<-1>(sm, p.r1, p.l1, FFT_TILE, 4, p.tw1);
+	lds_fft_columns<-1>(sm, p.r1, p.l1, FFT_TILE, FFT_TILE_LOG, p.tw1);
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
-		const int k1 = e >> 4, col = e & 15;
+		const int k1 = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
 		const int c = c0 + col;
 		if (c >= cs) continue;
 		float2 v = sm[bitrev(k1, p.l1) * FFT_TILE + col];
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass2(float2 *__restrict__ bu
 	const int cc0 = blockIdx.x * FFT_TILE;
 	const int total = p.r2 * FFT_TILE;
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
-		const int r = e >> 4, col = e & 15;
+		const int r = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
 		const int cc = cc0 + col;
 		float2 v = make_float2(0.f, 0.f);
 		if (cc < ncol) {
@@ -77,9 +80,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass2(float2 *__restrict__ bu
 		sm[e] = v;
 	}
 	__syncthreads();
-	lds_fft_columns<-1>(sm, p.r2, p.l2, FFT_TILE, 4, p.tw2);
+	lds_fft_columns<-1>(sm, p.r2, p.l2, FFT_TILE, FFT_TILE_LOG, p.tw2);
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
-		const int k2 = e >> 4, col = e & 15;
+		const int k2 = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
 		const int cc = cc0 + col;
 		if (cc >= ncol) continue;
 		const int k1 = cc >> p.l3, n3 = cc & (p.r3 - 1);
@@ -108,10 +111,10 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restric
 		sm[n3 * FFT_TILE + col] = v;
 	}
 	__syncthreads();
-	lds_fft_columns<-1>(sm, p.r3, p.l3, FFT_TILE, 4, p.tw3);
+	lds_fft_columns<-1>(sm, p.r3, p.l3, FFT_TILE, FFT_TILE_LOG, p.tw3);
 	const unsigned half = shifted ? (unsigned)(p.n >> 1) : 0u;
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
-		const int k3 = e >> 4, col = e & 15;
+		const int k3 = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
 		const int cc = cc0 + col;
 		if (cc >= ncol) continue;
 		const int k2 = cc >> p.l1, k1 = cc & (p.r1 - 1);
@@ -120,45 +123,19 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restric
 	}
 }
 
-__global__ void copy_tail_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4)
-{
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-
-void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split,
+void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
 		float2 *work, float2 *out, bool shifted, hipStream_t st)
 {
 	const int c1 = (p.n >> p.l1), c2 = p.r1 * p.r3, c3 = p.r1 * p.r2;
 	const dim3 g1((c1 + FFT_TILE - 1) / FFT_TILE), blk(FFT_THREADS);
-	const size_t l1 = p.r1 * FFT_TILE * sizeof(float2);
-	if (fmt == SFMT_CS16) hipLaunchKernelGGL(fft_pass1<SFMT_CS16>, g1, blk, l1, st, hist, fresh, split, work, p);
-	else if (fmt == SFMT_CU8) hipLaunchKernelGGL(fft_pass1<SFMT_CU8>, g1, blk, l1, st, hist, fresh, split, work, p);
-	else hipLaunchKernelGGL(fft_pass1<SFMT_CF32>, g1, blk, l1, st, hist, fresh, split, work, p);
-	hipLaunchKernelGGL(fft_pass2, dim3((c2 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), p.r2 * FFT_TILE * sizeof(float2), st,
+	const size_t l1 = (size_t)p.r1 * FFT_TILE * sizeof(float2), l2 = (size_t)p.r2 * FFT_TILE * sizeof(float2);
+	if (fmt == SFMT_CS16) hipLaunchKernelGGL(fft_pass1<SFMT_CS16>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
+	else if (fmt == SFMT_CU8) hipLaunchKernelGGL(fft_pass1<SFMT_CU8>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
+	else hipLaunchKernelGGL(fft_pass1<SFMT_CF32>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
+	hipLaunchKernelGGL(fft_pass2, dim3((c2 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), l2, st,
 			work, p);
 	hipLaunchKernelGGL(fft_pass3, dim3((c3 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), p.r3 * FFT_TILE * sizeof(float2), st,
 			(const float2 *)work, out, p, shifted ? 1 : 0);
-}
-
-template <int FMT>
-__global__ void convert_tail_kernel(const void *__restrict__ raw, float2 *__restrict__ dst, int first, int n)
-{
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = load_sample<FMT>(raw, first + i);
-}
-
-// hist <- last `overlap` samples of this block's input (input_size >= overlap always: N >= 4*taps_length)
-void launch_copy_tail(const void *fresh, int fmt, float2 *hist, int input_size, int overlap, hipStream_t st)
-{
-	const int first = input_size - overlap;
-	if (fmt == SFMT_CS16) { hipLaunchKernelGGL(convert_tail_kernel<SFMT_CS16>, dim3(512), dim3(256), 0, st, fresh, hist, first, overlap); return; }
-	if (fmt == SFMT_CU8) { hipLaunchKernelGGL(convert_tail_kernel<SFMT_CU8>, dim3(512), dim3(256), 0, st, fresh, hist, first, overlap); return; }
-	const float2 *src = (const float2 *)fresh + first;
-	if ((((uintptr_t)src | (uintptr_t)hist) & 15) == 0 && (overlap & 1) == 0) {
-		size_t n4 = (size_t)overlap / 2;
-		hipLaunchKernelGGL(copy_tail_kernel, dim3(512), dim3(256), 0, st, (const float4 *)src, (float4 *)hist, n4);
-	} else {
-		(void)hipMemcpyAsync(hist, src, sizeof(float2) * (size_t)overlap, hipMemcpyDeviceToDevice, st);
-	}
 }
 
 }  // namespace hfdl

@@ -161,8 +161,11 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 // inv_in[(h0 + j) mod M] = Y[j], h0 = (N - offsetbin + M/2) mod M      (src/fastddc.c:130)
 // fft_swap_sides(inv_in)  ->  x[u] = Y[(u - h0 - M/2) mod M]            (:190)
 // y = IFFT_M(x) / (pre * M); drop `scrap`; out[k] = y[scrap + rem + q k] * e^{j phi_k}   (:193-211)
-// phi_k follows the reference's fp32 phasor recurrence exactly (one lane runs it; it is 1792 steps).
-__global__ __launch_bounds__(256) void ifft_nco_kernel(const float2 *__restrict__ partial, const ChanConst *__restrict__ cc,
+// phi_k follows the reference's fp32 phasor recurrence exactly: it is serial (1792 dependent steps at cfg3, ~16 us), so
+// wave 0 runs it while the other 15 waves sum the fold slices out of HBM; all 16 then share the inverse FFT.
+constexpr int IFFT_THREADS = 1024;
+
+__global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__restrict__ partial, const ChanConst *__restrict__ cc,
 		NcoState *__restrict__ nco, const float2 *__restrict__ tw, float2 *__restrict__ chan_out, int *__restrict__ out_count,
 		Geometry g, int logm)
 {
@@ -171,39 +174,41 @@ __global__ __launch_bounds__(256) void ifft_nco_kernel(const float2 *__restrict_
 	const int c = blockIdx.x;
 	const ChanConst k = cc[c];
 	const int m = g.m, mask = m - 1;
-	const int h0 = (int)(((long long)g.n - k.offsetbin + m / 2) % m);
-	const float2 *pc = partial + (size_t)c * g.slices * (size_t)m;
-	for (int u = threadIdx.x; u < m; u += blockDim.x) {
-		const int j = (u - h0 - m / 2) & mask;
-		float2 acc = make_float2(0.f, 0.f);
-		for (int s = 0; s < g.slices; s++) {
-			float2 v = pc[(size_t)s * m + j];
-			acc.x += v.x; acc.y += v.y;
-		}
-		sm[u] = acc;
-	}
-	__syncthreads();
-	lds_fft_columns<+1>(sm, m, logm, 1, 0, tw);
-
 	NcoState st = nco[c];
 	const int q = g.post;
 	int cnt = 0;
 	if (st.decimation_remain < g.post_input_size) cnt = (g.post_input_size - st.decimation_remain + q - 1) / q;
-	if (threadIdx.x == 0) {
-		// decimating_shift_addition_cc's phasor recurrence, fp32, no contraction (src/libcsdr_gpl.c:46-66)
-		float cphi = (float)cos((double)st.starting_phase), sphi = (float)sin((double)st.starting_phase);
-		const float cd = k.nco_cosdelta, sd = k.nco_sindelta;
-		for (int i = 0; i < cnt; i++) {
-			ph[i] = make_float2(cphi, sphi);
-			float c0 = cphi, s0 = sphi;
-			cphi = __fsub_rn(__fmul_rn(c0, cd), __fmul_rn(s0, sd));
-			sphi = __fadd_rn(__fmul_rn(s0, cd), __fmul_rn(c0, sd));
+	if (threadIdx.x < 64) {
+		if (threadIdx.x == 0) {
+			// decimating_shift_addition_cc's phasor recurrence, fp32, no contraction (src/libcsdr_gpl.c:46-66)
+			float cphi = (float)cos((double)st.starting_phase), sphi = (float)sin((double)st.starting_phase);
+			const float cd = k.nco_cosdelta, sd = k.nco_sindelta;
+			for (int i = 0; i < cnt; i++) {
+				ph[i] = make_float2(cphi, sphi);
+				float c0 = cphi, s0 = sphi;
+				cphi = __fsub_rn(__fmul_rn(c0, cd), __fmul_rn(s0, sd));
+				sphi = __fadd_rn(__fmul_rn(s0, cd), __fmul_rn(c0, sd));
+			}
+		}
+	} else {
+		const int h0 = (int)(((long long)g.n - k.offsetbin + m / 2) % m);
+		const float2 *pc = partial + (size_t)c * g.slices * (size_t)m;
+		for (int u = threadIdx.x - 64; u < m; u += IFFT_THREADS - 64) {
+			const int j = (u - h0 - m / 2) & mask;
+			float2 acc = make_float2(0.f, 0.f);
+			for (int s = 0; s < g.slices; s++) {
+				float2 v = pc[(size_t)s * m + j];
+				acc.x += v.x; acc.y += v.y;
+			}
+			sm[u] = acc;
 		}
 	}
 	__syncthreads();
+	lds_fft_columns<+1>(sm, m, logm, 1, 0, tw);
+
 	const float norm = (float)g.pre * (float)m;
 	float2 *o = chan_out + (size_t)c * g.outs;
-	for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+	for (int i = threadIdx.x; i < cnt; i += IFFT_THREADS) {
 		const int idx = g.scrap + st.decimation_remain + q * i;
 		float2 v = sm[(int)(__brev((unsigned)idx) >> (32 - logm))];
 		v.x = __fdiv_rn(v.x, norm); v.y = __fdiv_rn(v.y, norm);
@@ -231,7 +236,8 @@ void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *
 	int logm = 0;
 	while ((1 << logm) < g.m) logm++;
 	size_t lds = sizeof(float2) * ((size_t)g.m + (size_t)g.outs + 1);
-	hipLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(256), lds, st, partial, cc, nco, tw_m, chan_out, out_count, g, logm);
+	if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)ifft_nco_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(IFFT_THREADS), lds, st, partial, cc, nco, tw_m, chan_out, out_count, g, logm);
 }
 
 }  // namespace hfdl

@@ -98,7 +98,7 @@ int HostFftPlan::build(int n)
 struct hfdl_gpu_frontend {
 	int device = 0;
 	hipStream_t stream = nullptr;       // A: ingest + forward FFT + fold + inverse FFT/NCO of block k
-	hipStream_t stream_b = nullptr;     // B: demodulator + burst decoder of block k-1, concurrent with A
+	hipStream_t stream_b = nullptr;     // B: demodulator + burst decoder of block k-1, concurrent with the fold of block k
 	hipStream_t stream_c = nullptr;     // C: host -> device copies of block k+1 into the other staging buffer
 	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
 	hipEvent_t ev_stage_ready[2] = { nullptr, nullptr }, ev_stage_free[2] = { nullptr, nullptr };
@@ -111,7 +111,7 @@ struct hfdl_gpu_frontend {
 	HostFftPlan fft;
 	std::vector<int32_t> freqs;
 	std::vector<ChanConst> cc;
-	float2 *d_hist = nullptr, *d_work = nullptr, *d_spec = nullptr, *d_taps = nullptr, *d_partial = nullptr;
+	float2 *d_hist[2] = { nullptr, nullptr }, *d_work = nullptr, *d_spec = nullptr, *d_taps = nullptr, *d_partial = nullptr;
 	float2 *d_chan_out[2] = { nullptr, nullptr }, *d_tw_m = nullptr, *d_stage[2] = { nullptr, nullptr };
 	int *d_out_count[2] = { nullptr, nullptr };
 	ChanConst *d_cc = nullptr;
@@ -124,6 +124,8 @@ struct hfdl_gpu_frontend {
 	double fold_ms = 0;
 	int64_t fold_launches = 0;
 	uint64_t blocks = 0;
+	int pending_demod_buf = -1;         // block whose demodulator launch is held back until the next forward FFT is queued
+	hipEvent_t ev_fft = nullptr;
 	uint64_t demod_blocks = 0;          // value of `blocks` after the last block that went through the demodulator
 	int demod_buf = -1;                 // ... and the buffer / snapshot slot it used
 	int prev_demod_buf = -1;            // the one before it
@@ -139,9 +141,10 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	for (int i = 0; i < 2; i++)
 		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_stage_ready[i], fe->ev_stage_free[i] }) if (e) (void)hipEventDestroy(e);
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+	if (fe->ev_fft) (void)hipEventDestroy(fe->ev_fft);
 	fe->demod.release();
 	fe->fft.release();
-	void *ptrs[] = { fe->d_hist, fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_out[0], fe->d_chan_out[1], fe->d_tw_m,
+	void *ptrs[] = { fe->d_hist[0], fe->d_hist[1], fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_out[0], fe->d_chan_out[1], fe->d_tw_m,
 		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_out_count[0], fe->d_out_count[1] };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (fe->stream) (void)hipStreamDestroy(fe->stream);
@@ -205,7 +208,7 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	for (int c = 0; c < nch; c++) {
 		HIP_TRY(hipMemcpyAsync(d_pad, host.data() + (size_t)c * pl.taps_length, sizeof(float2) * (size_t)pl.taps_length,
 				hipMemcpyHostToDevice, fe->stream));
-		launch_fft_forward(fe->fft.p, nullptr, d_pad, SFMT_CF32, 0, fe->d_work, fe->d_taps + (size_t)c * n, true, fe->stream);
+		launch_fft_forward(fe->fft.p, nullptr, d_pad, SFMT_CF32, 0, nullptr, fe->d_work, fe->d_taps + (size_t)c * n, true, fe->stream);
 	}
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipGetLastError());
@@ -261,8 +264,10 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	}
 	if ((rc = fe->fft.build(pl.n))) { frontend_free(fe); return rc; }
 	const size_t n = (size_t)pl.n;
-	FE_TRY(hipMalloc(&fe->d_hist, sizeof(float2) * (size_t)pl.overlap));
-	FE_TRY(hipMemsetAsync(fe->d_hist, 0, sizeof(float2) * (size_t)pl.overlap, fe->stream));   // calloc'ed history, src/fft.c:79
+	for (int i = 0; i < 2; i++) {      // overlap history, ping-pong: block k reads [k&1] and leaves the next one in [(k+1)&1]
+		FE_TRY(hipMalloc(&fe->d_hist[i], sizeof(float2) * (size_t)pl.overlap));
+		FE_TRY(hipMemsetAsync(fe->d_hist[i], 0, sizeof(float2) * (size_t)pl.overlap, fe->stream));   // calloc'ed history, src/fft.c:79
+	}
 	FE_TRY(hipMalloc(&fe->d_work, sizeof(float2) * n));
 	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n));
 	FE_TRY(hipMalloc(&fe->d_taps, sizeof(float2) * n * (size_t)nch));
@@ -363,6 +368,30 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 	return 0;
 }
 
+// Where the demodulator's 256 single-wave workgroups land decides how much they disturb the fold kernel they run beside.
+// Launched the moment the channelizer of block k is done, they race the next block's forward-FFT workgroups for LDS and
+// the outcome depends on details as small as the FFT's LDS footprint: measured on MI355X, the same fold kernel took
+// 2.56 ms or 2.87 ms per launch (profiles/r01_experiments.md).  So the launch of demod(k) is held back until the forward
+// FFT of block k+1 has finished: the workgroups then arrive while only the LDS-free fold kernel is resident, spread
+// evenly, and the fold time is the good one every time.  A sync / poll launches a held-back demodulator at once.
+static int launch_demod(hfdl_gpu_frontend *fe, int buf, bool after_fft)
+{
+	if (after_fft) HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_fft, 0));
+	HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
+	int rc = fe->demod.enqueue_block(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b);
+	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
+	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_b));
+	return 0;
+}
+
+static int flush_pending_demod(hfdl_gpu_frontend *fe, bool after_fft)
+{
+	if (fe->pending_demod_buf < 0) return 0;
+	const int buf = fe->pending_demod_buf;
+	fe->pending_demod_buf = -1;
+	return launch_demod(fe, buf, after_fft);
+}
+
 // Stream A runs the channelizer of block k into buffer k&1; stream B demodulates it.  A may not overwrite a buffer
 // before B has finished with it (two blocks ago); B may not start before A has filled it.
 static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx, int *buf_out)
@@ -370,8 +399,13 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 	const Geometry &g = fe->geo;
 	const int buf = (int)(fe->blocks & 1);
 	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_demod[buf], 0));
-	launch_fft_forward(fe->fft.p, fe->d_hist, fresh, fmt, g.overlap, fe->d_work, fe->d_spec, true, fe->stream);
-	launch_copy_tail(fresh, fmt, fe->d_hist, g.input_size, g.overlap, fe->stream);
+	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->d_spec, true, fe->stream);
+	if (fe->pending_demod_buf >= 0) {
+		if (!fe->ev_fft) HIP_TRY(hipEventCreateWithFlags(&fe->ev_fft, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(fe->ev_fft, fe->stream));
+		int rc = flush_pending_demod(fe, true);
+		if (rc) return rc;
+	}
 	if (stage_idx >= 0) HIP_TRY(hipEventRecord(fe->ev_stage_free[stage_idx], fe->stream));   // input consumed: the copy stream may refill it
 	if (fe->timing) {
 		std::pair<hipEvent_t, hipEvent_t> e;
@@ -409,10 +443,7 @@ static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int
 	int rc = stage_input(fe, raw, nsamples, fmt, on_device, &fresh, &sidx);
 	if (rc) return rc;
 	if ((rc = enqueue_channelizer(fe, fresh, fmt, sidx, &buf))) return rc;
-	HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
-	rc = fe->demod.enqueue_block(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b);
-	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
-	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_b));
+	fe->pending_demod_buf = buf;
 	fe->demod_blocks = fe->blocks;
 	fe->prev_demod_buf = fe->demod_buf;
 	fe->demod_buf = buf;
@@ -446,6 +477,7 @@ extern "C" int hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe)
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	HIP_TRY(hipSetDevice(fe->device));
+	{ int rc = flush_pending_demod(fe, false); if (rc) return rc; }
 	HIP_TRY(hipStreamSynchronize(fe->stream_c));
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipStreamSynchronize(fe->stream_b));
@@ -623,7 +655,7 @@ extern "C" int hfdl_gpu_fft_forward(int device, const float *in, float *out, int
 	HIP_TRY(d_work.alloc(bytes));
 	HIP_TRY(d_out.alloc(bytes));
 	HIP_TRY(hipMemcpy(d_in.p, in, bytes, hipMemcpyHostToDevice));
-	launch_fft_forward(plan.p.p, nullptr, d_in.p, SFMT_CF32, 0, d_work.as<float2>(), d_out.as<float2>(), shifted != 0, nullptr);
+	launch_fft_forward(plan.p.p, nullptr, d_in.p, SFMT_CF32, 0, nullptr, d_work.as<float2>(), d_out.as<float2>(), shifted != 0, nullptr);
 	HIP_TRY(hipDeviceSynchronize());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpy(out, d_out.p, bytes, hipMemcpyDeviceToHost));

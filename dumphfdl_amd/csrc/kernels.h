@@ -5,7 +5,8 @@
 
 namespace hfdl {
 
-constexpr int FFT_TILE = 16;          // columns per workgroup in the strided FFT passes
+constexpr int FFT_TILE_LOG = 4;
+constexpr int FFT_TILE = 1 << FFT_TILE_LOG;   // columns per workgroup in the strided FFT passes (8-byte samples: 128-byte runs at 16)
 constexpr int FFT_THREADS = 256;
 
 // N = R1*R2*R3 three-pass plan for the wideband forward FFT (all radices powers of two <= 256)
@@ -50,12 +51,11 @@ struct DevBuf {
 // ---- launchers (host side, defined next to their kernels) ----
 // sample formats of the raw ingest path (reference: src/input-helpers.c:10-78,108-125)
 enum { SFMT_CF32 = 0, SFMT_CS16 = 1, SFMT_CU8 = 2 };
-void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split,
+void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
 		float2 *work, float2 *out, bool shifted, hipStream_t st);
 void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st);
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
 		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st);
 void launch_stream_read(const float2 *src, size_t bytes, float *sink, hipStream_t st);
-void launch_copy_tail(const void *fresh, int fmt, float2 *hist, int input_size, int overlap, hipStream_t st);
 
 }  // namespace hfdl
