@@ -112,8 +112,8 @@ def cpu_baseline(w, x, input_size, target_seconds=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=256, help="timed blocks (one step = one block of input_size samples through the whole path); 256 blocks of the 40 Msps geometry = 0.75 s, so pipeline fill and drain stay below 1 %")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-input", action="store_true",

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass2(float2 *__restrict__ bu
 
 // pass 3: for each (k1,k2): contiguous R3-point FFT; X[k1 + R1 k2 + R1 R2 k3] stored at (k + n/2) mod n
 // when `shifted` (fft_swap_sides as an index remap).  A tile is 16 adjacent k1 so stores stay 128-byte runs.
-__global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restrict__ in, float2 *__restrict__ out, FftPlan p, int shifted)
+__global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restrict__ in, float2 *__restrict__ out, FftPlan p, int shifted,
+		FftOutLayout lay)
 {
 	extern __shared__ float2 sm[];
 	const int r23 = p.n >> p.l1, ncol = p.r1 * p.r2;
@@ -119,12 +120,14 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restric
 		if (cc >= ncol) continue;
 		const int k2 = cc >> p.l1, k1 = cc & (p.r1 - 1);
 		const unsigned k = (unsigned)k1 + ((unsigned)k2 << p.l1) + ((unsigned)k3 << (p.l1 + p.l2));
-		out[(k + half) & (unsigned)(p.n - 1)] = sm[bitrev(k3, p.l3) * FFT_TILE + col];
+		const unsigned i = (k + half) & (unsigned)(p.n - 1);
+		const size_t at = lay.row_log ? (size_t)(i >> lay.row_log) * (size_t)lay.row_stride + (i & ((1u << lay.row_log) - 1u)) : (size_t)i;
+		out[at] = sm[bitrev(k3, p.l3) * FFT_TILE + col];
 	}
 }
 
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
-		float2 *work, float2 *out, bool shifted, hipStream_t st)
+		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay)
 {
 	const int c1 = (p.n >> p.l1), c2 = p.r1 * p.r3, c3 = p.r1 * p.r2;
 	const dim3 g1((c1 + FFT_TILE - 1) / FFT_TILE), blk(FFT_THREADS);
@@ -135,7 +138,7 @@ void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh,
 	hipLaunchKernelGGL(fft_pass2, dim3((c2 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), l2, st,
 			work, p);
 	hipLaunchKernelGGL(fft_pass3, dim3((c3 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), p.r3 * FFT_TILE * sizeof(float2), st,
-			(const float2 *)work, out, p, shifted ? 1 : 0);
+			(const float2 *)work, out, p, shifted ? 1 : 0, lay);
 }
 
 }  // namespace hfdl

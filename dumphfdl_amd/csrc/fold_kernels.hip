@@ -30,16 +30,16 @@ __device__ __forceinline__ float4 load_stream(const float4 *p)
 // CS = column split: a workgroup covers 1/CS of a row; NC = channels per workgroup sharing every spectrum load
 template <int U, bool NT, int R, int CS, int NC>
 __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__restrict__ taps, const float4 *__restrict__ spec,
-		float4 *__restrict__ partial, size_t n, int m, int slices, int rows, int c_base)
+		float4 *__restrict__ partial, size_t chan_stride4, size_t row_stride4, int m, int slices, int rows, int c_base)
 {
 	const int cpart = blockIdx.x % CS;
 	const int bs = blockIdx.x / CS;
 	const int s = bs % slices, c0 = c_base + (bs / slices) * NC;
-	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row
-	const size_t off = (((size_t)s * rows * (size_t)m) >> 1) + (size_t)cpart * U * FOLD_THREADS;
-	const float4 *tp = taps + (((size_t)c0 * n) >> 1) + off + threadIdx.x;
-	const float4 *sp = spec + off + threadIdx.x;
-	const size_t cstride = n >> 1;                            // float4 between consecutive channels' taps
+	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row of the spectrum
+	const size_t col = (size_t)cpart * U * FOLD_THREADS + threadIdx.x;
+	const float4 *tp = taps + (size_t)c0 * chan_stride4 + (size_t)s * rows * row_stride4 + col;
+	const float4 *sp = spec + (((size_t)s * rows * (size_t)m) >> 1) + col;
+	const size_t cstride = chan_stride4;                      // float4 between consecutive channels' taps
 	float4 acc[NC][U];
 #pragma unroll
 	for (int k = 0; k < NC; k++)
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__rest
 				for (int u = 0; u < U; u++) {
 #pragma unroll
 					for (int k = 0; k < NC; k++) {
-						const float4 *p = tp + (size_t)k * cstride + (size_t)q * row4 + u * FOLD_THREADS;
+						const float4 *p = tp + (size_t)k * cstride + (size_t)q * row_stride4 + u * FOLD_THREADS;
 						h[k][q][u] = NT ? load_stream(p) : *p;
 					}
 					x[q][u] = sp[(size_t)q * row4 + u * FOLD_THREADS];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__rest
 					}
 				}
 			}
-			tp += (size_t)R * row4;
+			tp += (size_t)R * row_stride4;
 			sp += (size_t)R * row4;
 		}
 #pragma unroll
@@ -86,40 +86,52 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__rest
 	}
 }
 
-// Read-only streaming probe: what this board's HBM delivers to the same access pattern (non-temporal 16-byte loads,
-// 1 KiB per wave instruction, contiguous spans per workgroup) with nothing else to do.  SURVEY.md 8(d) asks for it next to
-// the spec peak; bench.py reports it as roofline.stream_read_GBs.
-__global__ __launch_bounds__(FOLD_THREADS) void stream_read_kernel(const float4 *__restrict__ src, size_t n4_per_block, float *__restrict__ sink)
+// Read-only streaming probe: what this board's HBM delivers to a bare kernel doing nothing but non-temporal 16-byte loads
+// (1 KiB per wave instruction).  L loads in flight per thread; SPAN: every workgroup walks its own contiguous 4 MiB span,
+// otherwise the whole grid sweeps one moving window (workgroup b reads chunks b, b + grid, ...).  The front end reports the
+// best of the variants: SURVEY.md 8(d) asks for it next to the spec peak; bench.py prints it as roofline.stream_read_GBs.
+template <int L, bool SPAN>
+__global__ __launch_bounds__(FOLD_THREADS) void stream_read_kernel(const float4 *__restrict__ src, size_t chunks, float *__restrict__ sink)
 {
-	const float4 *p = src + (size_t)blockIdx.x * n4_per_block + threadIdx.x;
 	float acc = 0.f;
-	for (size_t i = 0; i < n4_per_block; i += 4 * FOLD_THREADS) {
-		const float4 a = load_stream(p + i), b = load_stream(p + i + FOLD_THREADS);
-		const float4 c = load_stream(p + i + 2 * FOLD_THREADS), d = load_stream(p + i + 3 * FOLD_THREADS);
-		acc += a.x + b.y + c.z + d.w;
+	const size_t per_block = chunks / gridDim.x;
+	const size_t first = SPAN ? (size_t)blockIdx.x * per_block : blockIdx.x, step = SPAN ? 1 : gridDim.x;
+	const size_t last = SPAN ? first + per_block : chunks;
+	for (size_t ch = first; ch < last; ch += step) {
+		const float4 *p = src + ch * (L * FOLD_THREADS) + threadIdx.x;
+		float4 v[L];
+#pragma unroll
+		for (int i = 0; i < L; i++) v[i] = load_stream(p + i * FOLD_THREADS);
+#pragma unroll
+		for (int i = 0; i < L; i++) acc += v[i].x + v[i].w;
 	}
 	if (acc == 1.2345e33f) *sink = acc;
 }
 
-void launch_stream_read(const float2 *src, size_t bytes, float *sink, hipStream_t st)
+int stream_read_variants() { return 4; }
+
+void launch_stream_read(int variant, const float2 *src, size_t bytes, float *sink, hipStream_t st)
 {
-	const size_t per_block = (size_t)4 << 20;                           // 4 MiB spans, like a fold workgroup's tap span
-	const unsigned blocks = (unsigned)(bytes / per_block);
-	hipLaunchKernelGGL(stream_read_kernel, dim3(blocks), dim3(FOLD_THREADS), 0, st, (const float4 *)src, per_block / 16, sink);
+	const dim3 block(FOLD_THREADS);
+	switch (variant) {
+	case 0: hipLaunchKernelGGL((stream_read_kernel<4, false>), dim3(2048), block, 0, st, (const float4 *)src, bytes / (64 * FOLD_THREADS), sink); break;
+	case 1: hipLaunchKernelGGL((stream_read_kernel<8, false>), dim3(2048), block, 0, st, (const float4 *)src, bytes / (128 * FOLD_THREADS), sink); break;
+	case 2: hipLaunchKernelGGL((stream_read_kernel<4, true>), dim3((unsigned)(bytes >> 22)), block, 0, st, (const float4 *)src, bytes / (64 * FOLD_THREADS), sink); break;
+	default: hipLaunchKernelGGL((stream_read_kernel<8, true>), dim3((unsigned)(bytes >> 22)), block, 0, st, (const float4 *)src, bytes / (128 * FOLD_THREADS), sink); break;
+	}
 }
 
 // generic fallback for row sizes that are not 512*2^k bins
 __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel_generic(const float2 *__restrict__ taps, const float2 *__restrict__ spec,
-		float2 *__restrict__ partial, size_t n, int m, int slices, int rows)
+		float2 *__restrict__ partial, size_t chan_stride, size_t row_stride, int m, int slices, int rows)
 {
 	const int s = blockIdx.x % slices, c = blockIdx.x / slices;
-	const size_t off = (size_t)s * rows * (size_t)m;
 	for (int j = threadIdx.x; j < m; j += FOLD_THREADS) {
-		const float2 *tp = taps + (size_t)c * n + off + j;
-		const float2 *sp = spec + off + j;
+		const float2 *tp = taps + (size_t)c * chan_stride + (size_t)s * rows * row_stride + j;
+		const float2 *sp = spec + (size_t)s * rows * (size_t)m + j;
 		float2 acc = make_float2(0.f, 0.f);
 		for (int r = 0; r < rows; r++) {
-			float2 h = tp[(size_t)r * m], x = sp[(size_t)r * m];
+			float2 h = tp[(size_t)r * row_stride], x = sp[(size_t)r * m];
 			acc.x += h.x * x.x - h.y * x.y;
 			acc.y += h.x * x.y + h.y * x.x;
 		}
@@ -130,15 +142,15 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel_generic(const float2
 void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st)
 {
 	const dim3 block(FOLD_THREADS);
-	const size_t n = (size_t)g.n;
+	const size_t cs4 = (size_t)g.tap_chan_stride >> 1, rs4 = (size_t)g.tap_row_stride >> 1;     // in float4
 	const int u = g.m / (2 * FOLD_THREADS);
 	const int pairs = g.nch / 2, odd = g.nch & 1;
 	// channel pairs first; an odd last channel gets its own single-channel launch
 #define FOLD_LAUNCH(U, CS, NC, GROUPS) do { \
 	if ((GROUPS) > 0) hipLaunchKernelGGL((fold_kernel<U, true, 1, CS, NC>), dim3((unsigned)((GROUPS) * g.slices * CS)), block, 0, st, \
-		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, n, g.m, g.slices, g.rows_per_slice, 0); \
+		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, cs4, rs4, g.m, g.slices, g.rows_per_slice, 0); \
 	if (odd) hipLaunchKernelGGL((fold_kernel<U, true, 1, CS, 1>), dim3((unsigned)(g.slices * CS)), block, 0, st, \
-		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, n, g.m, g.slices, g.rows_per_slice, g.nch - 1); } while (0)
+		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, cs4, rs4, g.m, g.slices, g.rows_per_slice, g.nch - 1); } while (0)
 	// Variants measured on cfg3 (profiles/r01_experiments.md).  What pays: non-temporal tap loads (+7 %) and TWO channels per
 	// workgroup sharing every spectrum load (+14 %: halves the L2->L1 spectrum traffic, which equals the HBM tap traffic
 	// when each channel re-reads the spectrum).  A workgroup = (channel pair, slice, half of the columns).
@@ -152,7 +164,7 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 		default: break;
 		}
 	}
-	hipLaunchKernelGGL(fold_kernel_generic, dim3((unsigned)(g.nch * g.slices)), block, 0, st, taps, spectrum, partial, n, g.m, g.slices, g.rows_per_slice);
+	hipLaunchKernelGGL(fold_kernel_generic, dim3((unsigned)(g.nch * g.slices)), block, 0, st, taps, spectrum, partial, (size_t)g.tap_chan_stride, (size_t)g.tap_row_stride, g.m, g.slices, g.rows_per_slice);
 #undef FOLD_LAUNCH
 }
 

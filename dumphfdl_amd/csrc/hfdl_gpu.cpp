@@ -124,6 +124,7 @@ struct hfdl_gpu_frontend {
 	double fold_ms = 0;
 	int64_t fold_launches = 0;
 	uint64_t blocks = 0;
+	FftOutLayout tap_layout;
 	int pending_demod_buf = -1;         // block whose demodulator launch is held back until the next forward FFT is queued
 	hipEvent_t ev_fft = nullptr;
 	uint64_t demod_blocks = 0;          // value of `blocks` after the last block that went through the demodulator
@@ -157,10 +158,11 @@ extern "C" void hfdl_gpu_frontend_destroy(hfdl_gpu_frontend *fe) { frontend_free
 
 static int pick_slices(int nch, int rows)
 {
-	// enough workgroups to fill 256 CUs several times over, a multiple of 8 (XCDs) when possible,
-	// but keep >= 8 alias rows per slice so the partial-sum traffic stays small against the taps
+	// nch * slices workgroups (a channel pair x a slice x half the columns each): 1024 = the 4 that fit a CU x 256 CUs, all
+	// resident at once (measured best: profiles/r01_experiments.md); keep >= 8 alias rows per slice so the partial-sum
+	// traffic stays small against the taps
 	int s = 1;
-	while (s * 2 <= rows / 8 && nch * s < 2048) s *= 2;
+	while (s * 2 <= rows / 8 && nch * s < 1024) s *= 2;
 	return s;
 }
 
@@ -208,7 +210,7 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	for (int c = 0; c < nch; c++) {
 		HIP_TRY(hipMemcpyAsync(d_pad, host.data() + (size_t)c * pl.taps_length, sizeof(float2) * (size_t)pl.taps_length,
 				hipMemcpyHostToDevice, fe->stream));
-		launch_fft_forward(fe->fft.p, nullptr, d_pad, SFMT_CF32, 0, nullptr, fe->d_work, fe->d_taps + (size_t)c * n, true, fe->stream);
+		launch_fft_forward(fe->fft.p, nullptr, d_pad, SFMT_CF32, 0, nullptr, fe->d_work, fe->d_taps + (size_t)c * (size_t)fe->geo.tap_chan_stride, true, fe->stream, fe->tap_layout);
 	}
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipGetLastError());
@@ -242,6 +244,11 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	g.n = pl.n; g.m = pl.m; g.pre = pl.pre; g.post = pl.post; g.scrap = pl.scrap; g.post_input_size = pl.post_input_size;
 	g.overlap = pl.overlap; g.input_size = pl.input_size; g.outs = (pl.post_input_size + pl.post - 1) / pl.post + 1;
 	g.nch = nch;
+	// Filter taps row-major over channels: alias row r of every channel sits in one nch*M run, so the workgroups of all
+	// channels, which walk the rows together, stream through a few moving windows of HBM instead of nch windows 8N bytes
+	// apart (fold kernel 2.58 -> 2.48 ms on cfg3 and a tighter run-to-run spread, profiles/r01_experiments.md)
+	g.tap_chan_stride = pl.m; g.tap_row_stride = (int64_t)nch * pl.m;
+	fe->tap_layout.row_log = ilog2(pl.m); fe->tap_layout.row_stride = g.tap_row_stride;
 	g.slices = pick_slices(nch, pl.pre);
 	g.rows_per_slice = pl.pre / g.slices;
 	if (pl.m > 8192 || pl.m < 16) { delete fe; return fail(HFDL_GPU_ERANGE, "inverse FFT size %d unsupported", pl.m); }
@@ -392,13 +399,12 @@ static int flush_pending_demod(hfdl_gpu_frontend *fe, bool after_fft)
 	return launch_demod(fe, buf, after_fft);
 }
 
-// Stream A runs the channelizer of block k into buffer k&1; stream B demodulates it.  A may not overwrite a buffer
-// before B has finished with it (two blocks ago); B may not start before A has filled it.
+// Stream A runs the channelizer of block k into buffer k&1; stream B demodulates it.  A's inverse FFT may not overwrite
+// a buffer before B has finished with it (two blocks ago); B may not start before A has filled it.
 static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx, int *buf_out)
 {
 	const Geometry &g = fe->geo;
 	const int buf = (int)(fe->blocks & 1);
-	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_demod[buf], 0));
 	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->d_spec, true, fe->stream);
 	if (fe->pending_demod_buf >= 0) {
 		if (!fe->ev_fft) HIP_TRY(hipEventCreateWithFlags(&fe->ev_fft, hipEventDisableTiming));
@@ -418,6 +424,7 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 	} else {
 		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
 	}
+	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_demod[buf], 0));       // chan_out[buf] is free once demod(k-2) has read it
 	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_tw_m, fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(fe->ev_chan[buf], fe->stream));
@@ -507,7 +514,7 @@ extern "C" int hfdl_gpu_frontend_stream_read_probe(hfdl_gpu_frontend *fe, double
 	if (!fe || !gb_per_s) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
-	// read the resident filter taps themselves (whole multiples of 4 MiB, at most 16 GiB), best of 3
+	// read the resident filter taps themselves (whole multiples of 4 MiB, at most 16 GiB): best launch of every variant
 	size_t bytes = sizeof(float2) * (size_t)fe->geo.n * (size_t)fe->geo.nch;
 	bytes -= bytes % ((size_t)4 << 20);
 	if (bytes > ((size_t)16 << 30)) bytes = (size_t)16 << 30;
@@ -518,15 +525,17 @@ extern "C" int hfdl_gpu_frontend_stream_read_probe(hfdl_gpu_frontend *fe, double
 	HIP_TRY(hipEventCreate(&e0));
 	HIP_TRY(hipEventCreate(&e1));
 	double best = 0;
-	for (int it = 0; it < 4; it++) {
-		HIP_TRY(hipEventRecord(e0, fe->stream));
-		launch_stream_read(fe->d_taps, bytes, sink.as<float>(), fe->stream);
-		HIP_TRY(hipEventRecord(e1, fe->stream));
-		HIP_TRY(hipEventSynchronize(e1));
-		float ms = 0;
-		HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-		if (it > 0 && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
-	}
+	for (int variant = 0; variant < stream_read_variants(); variant++)
+		for (int it = 0; it < 3; it++) {
+			HIP_TRY(hipEventRecord(e0, fe->stream));
+			launch_stream_read(variant, fe->d_taps, bytes, sink.as<float>(), fe->stream);
+			HIP_TRY(hipEventRecord(e1, fe->stream));
+			HIP_TRY(hipEventSynchronize(e1));
+			float ms = 0;
+			HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+			if (getenv("HFDL_GPU_PROBE_VERBOSE")) fprintf(stderr, "stream read variant %d: %.1f GB/s\n", variant, (double)bytes / (ms * 1e-3) / 1e9);
+			if (it > 0 && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+		}
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	*gb_per_s = best;
 	return 0;
@@ -624,7 +633,13 @@ extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32
 	size_t nf = 0;
 	switch (what) {
 	case HFDL_GPU_TAP_SPECTRUM: src = fe->d_spec; nf = 2 * (size_t)g.n; break;
-	case HFDL_GPU_TAP_FILTER: src = fe->d_taps + (size_t)channel * g.n; nf = 2 * (size_t)g.n; break;
+	case HFDL_GPU_TAP_FILTER: {
+		// rows of M bins, tap_row_stride apart: gather them into the caller's contiguous cf32[N]
+		if (2 * (size_t)g.n > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", 2 * (size_t)g.n, cap);
+		HIP_TRY(hipMemcpy2D(dst, sizeof(float2) * (size_t)g.m, fe->d_taps + (size_t)channel * (size_t)g.tap_chan_stride,
+				sizeof(float2) * (size_t)g.tap_row_stride, sizeof(float2) * (size_t)g.m, (size_t)g.pre, hipMemcpyDeviceToHost));
+		*n_floats = 2 * (size_t)g.n;
+		return 0; }
 	case HFDL_GPU_TAP_CHAN_OUT: {
 		int cnt = 0;
 		HIP_TRY(hipMemcpy(&cnt, fe->d_out_count[fe->last_buf] + channel, sizeof(cnt), hipMemcpyDeviceToHost));

@@ -7,7 +7,7 @@ namespace hfdl {
 
 constexpr int FFT_TILE_LOG = 4;
 constexpr int FFT_TILE = 1 << FFT_TILE_LOG;   // columns per workgroup in the strided FFT passes (8-byte samples: 128-byte runs at 16)
-constexpr int FFT_THREADS = 256;
+constexpr int FFT_THREADS = 512;            // measured: 512 threads per 256x16 tile beat 256 and 1024 (profiles/r01_experiments.md)
 
 // N = R1*R2*R3 three-pass plan for the wideband forward FFT (all radices powers of two <= 256)
 struct FftPlan {
@@ -35,6 +35,8 @@ struct NcoState {
 struct Geometry {
 	int32_t n, m, pre, post, scrap, post_input_size, overlap, input_size, outs;
 	int32_t slices, rows_per_slice, nch;
+	// filter taps in HBM: element (channel c, alias row r, bin j) at c*tap_chan_stride + r*tap_row_stride + j  (cf32 units)
+	int64_t tap_chan_stride, tap_row_stride;
 };
 
 // owning device allocation for the one-shot stage entry points (freed on every exit path)
@@ -51,11 +53,14 @@ struct DevBuf {
 // ---- launchers (host side, defined next to their kernels) ----
 // sample formats of the raw ingest path (reference: src/input-helpers.c:10-78,108-125)
 enum { SFMT_CF32 = 0, SFMT_CS16 = 1, SFMT_CU8 = 2 };
+// output index i of the transform is stored at (i >> row_log) * row_stride + (i & (2^row_log - 1)); row_log = 0: contiguous
+struct FftOutLayout { int row_log = 0; int64_t row_stride = 0; };
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
-		float2 *work, float2 *out, bool shifted, hipStream_t st);
+		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay = FftOutLayout());
 void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st);
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
 		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st);
-void launch_stream_read(const float2 *src, size_t bytes, float *sink, hipStream_t st);
+int stream_read_variants();
+void launch_stream_read(int variant, const float2 *src, size_t bytes, float *sink, hipStream_t st);
 
 }  // namespace hfdl

@@ -7,6 +7,6 @@ for lib in "$@"; do
 	rm -rf /tmp/ab_trace
 	HFDL_GPU_LIB=/root/repo/$lib rocprofv3 --kernel-trace -d /tmp/ab_trace -- python /root/repo/bench.py --no-cpu-baseline --steps 24 --warmup 4 > /tmp/ab.log 2>&1
 	DB=$(find /tmp/ab_trace -name "*.db" | head -1)
-	python /root/repo/profiles/summarize_rocpd.py $DB "$lib" | grep -E "fft_pass|ifft|fold_kernel|copy_tail|demod_kernel" | cut -d'|' -f2-5
-	for i in 1 2 3; do HFDL_GPU_LIB=/root/repo/$lib python /root/repo/bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['roofline']['avg_launch_ms'],4))"; done
+	python /root/repo/profiles/timeline_rocpd.py $DB 1 | grep -E "fft_pass|ifft|fold_kernel" | cut -d'|' -f2,6
+	for i in 1 2; do HFDL_GPU_LIB=/root/repo/$lib python /root/repo/bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['roofline']['avg_launch_ms'],4))"; done
 done
