@@ -183,16 +183,16 @@ def main():
     fe.reset_timers(True)
     barrier()
     t0 = time.perf_counter()
-    npdus = 0
-    pdus = []
+    raw = []
     for i in range(args.steps):
         push(step % nblocks); step += 1
-        if i % 256 == 255:          # long runs: drain the device PDU ring now and then (one pipeline sync per 256 blocks)
-            pdus += fe.poll_pdus(16384)
-    pdus += fe.poll_pdus(16384)     # sync + device->host of every PDU produced by the timed blocks
-    npdus = len(pdus)
+        if i % 256 == 255 and i + 1 < args.steps:      # long runs: empty the device PDU ring now and then, pipeline kept running
+            raw.append(fe.poll_pdus_raw(16384, max_in_flight=1))
+    raw.append(fe.poll_pdus_raw(16384))     # sync + device->host of every PDU struct produced by the timed blocks (what the C host gets)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    pdus = [p for buf, n in raw for p in fe.pdus_to_dicts(buf, n)]     # Python-side unpacking for the checks below: not part of the path
+    npdus = len(pdus)
     fold_ms, fold_n = fe.fold_time_ms()
     stream_gbs = fe.stream_read_probe() if rank == 0 else None       # after the timed region: the board's own read ceiling
     barrier()

@@ -191,16 +191,20 @@ class Frontend:
     def sync(self):
         _check(load().hfdl_gpu_frontend_sync(self._h))
 
-    def poll_pdus(self, max_pdus=4096, max_in_flight=0):
-        """max_in_flight=0: everything decoded so far (drains the pipeline); 1: leave the newest block running."""
+    def poll_pdus_raw(self, max_pdus=4096, max_in_flight=0):
+        """The C structs as the library hands them over: (ctypes array of hfdl_gpu_pdu, count)."""
         buf = (Pdu * max_pdus)()
         n = C.c_int32(0)
         if max_in_flight:
             _check(load().hfdl_gpu_frontend_poll_pdus_ready(self._h, buf, max_pdus, C.byref(n), max_in_flight))
         else:
             _check(load().hfdl_gpu_frontend_poll_pdus(self._h, buf, max_pdus, C.byref(n)))
+        return buf, n.value
+
+    @staticmethod
+    def pdus_to_dicts(buf, n):
         out = []
-        for i in range(n.value):
+        for i in range(n):
             p = buf[i]
             out.append(dict(channel=p.channel, freq=p.freq, mode=p.mode, bit_rate=p.bit_rate,
                             octets=bytes(p.octets[:p.len]), freq_err_hz=p.freq_err_hz, rssi_db=p.rssi_db,
@@ -208,6 +212,10 @@ class Frontend:
                             fcs_status=p.fcs_status, pdu_kind=p.pdu_kind, hdr_len=p.hdr_len,
                             train_bits_bad=p.train_bits_bad, train_bits_total=p.train_bits_total))
         return out
+
+    def poll_pdus(self, max_pdus=4096, max_in_flight=0):
+        """max_in_flight=0: everything decoded so far (drains the pipeline); 1: leave the newest block running."""
+        return self.pdus_to_dicts(*self.poll_pdus_raw(max_pdus, max_in_flight))
 
     def counters(self):
         c = FrontendCounters()
