@@ -103,6 +103,7 @@ __device__ inline int parity_u32(uint32_t x) { return __popc(x) & 1; }
 
 // K=7 r=1/2 Viterbi over `nbits` trellis steps; vin = 2*nbits soft bytes (LDS or global); decw = nbits words of LDS.
 // out receives ceil(nbits/8) octets: MSB-first as libfec leaves them, or bit-reversed (what dumphfdl dispatches).
+// Lane = trellis state; arithmetic as update_viterbi27_blk's BFLY (src/libfec/viterbi27_port.c:147-160).
 __device__ void viterbi27_wave(const uint8_t *vin, int nbits, uint64_t *decw, uint8_t *out, bool reverse_bits)
 {
 	const int lane = threadIdx.x;
@@ -110,25 +111,41 @@ __device__ void viterbi27_wave(const uint8_t *vin, int nbits, uint64_t *decw, ui
 	const uint32_t t0 = parity_u32((2u * i) & 0x6d) ? 255u : 0u;
 	const uint32_t t1 = parity_u32((2u * i) & 0x4f) ? 255u : 0u;
 	uint32_t metric = lane == 0 ? 0u : 63u;           // init_viterbi27(vp, 0)
-	for (int t = 0; t < nbits; t++) {
-		const uint32_t s0 = vin[2 * t], s1 = vin[2 * t + 1];
-		const uint32_t bm = (t0 ^ s0) + (t1 ^ s1);
-		const uint32_t lo = (uint32_t)__shfl((int)metric, i), hi = (uint32_t)__shfl((int)metric, i + 32);
-		const uint32_t a = lo + (odd ? 510u - bm : bm);
-		const uint32_t b = hi + (odd ? bm : 510u - bm);
-		const bool pick = (int32_t)(a - b) > 0;
-		metric = pick ? b : a;
-		const uint64_t word = __ballot(pick);
-		if (lane == 0) decw[t] = word;
+	// 64 trellis steps per trip: every lane fetches the soft pair of one step, the serial loop then takes them with
+	// v_readlane (the step index is wave-uniform), so no memory latency sits on the add-compare-select chain
+	for (int base = 0; base < nbits; base += 64) {
+		const int tt = base + lane;
+		const uint32_t pair = tt < nbits ? ((uint32_t)vin[2 * tt] | ((uint32_t)vin[2 * tt + 1] << 8)) : 0u;
+		const int lim = nbits - base < 64 ? nbits - base : 64;
+		for (int j = 0; j < lim; j++) {
+			const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)pair, j);
+			const uint32_t s0 = sj & 255u, s1 = sj >> 8;
+			const uint32_t bm = (t0 ^ s0) + (t1 ^ s1);
+			const uint32_t lo = (uint32_t)__shfl((int)metric, i), hi = (uint32_t)__shfl((int)metric, i + 32);
+			const uint32_t a = lo + (odd ? 510u - bm : bm);
+			const uint32_t b = hi + (odd ? bm : 510u - bm);
+			const bool pick = (int32_t)(a - b) > 0;
+			metric = pick ? b : a;
+			const uint64_t word = __ballot(pick);
+			if (lane == 0) decw[base + j] = word;
+		}
 	}
 	__syncthreads();
-	if (lane == 0) {
-		uint32_t reg = 0;
-		for (int idx = nbits - 1; idx >= 0; idx--) {
-			const uint64_t w = (idx + 6 < nbits) ? decw[idx + 6] : 0ull;    // "d += 6": words past the end were never written
-			const uint32_t k = (uint32_t)(w >> (reg >> 2)) & 1u;
+	// chainback_viterbi27 with the "d += 6" offset (words past the end were never written: read as 0).  The state register is
+	// wave-uniform; 64 decision words per trip are fetched lane-parallel and picked with v_readlane.
+	uint32_t reg = 0;
+	for (int top = nbits - 1; top >= 0; top -= 64) {
+		const int mine = top - lane;
+		const uint64_t w = (mine >= 0 && mine + 6 < nbits) ? decw[mine + 6] : 0ull;
+		const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32);
+		const int lim = top + 1 < 64 ? top + 1 : 64;
+		for (int j = 0; j < lim; j++) {
+			const int idx = top - j;
+			const uint64_t wj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wlo, j)
+				| ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)whi, j) << 32);
+			const uint32_t k = (uint32_t)(wj >> (reg >> 2)) & 1u;
 			reg = (reg >> 1) | (k << 7);
-			if ((idx & 7) == 0) out[idx >> 3] = reverse_bits ? (uint8_t)(__brev(reg) >> 24) : (uint8_t)reg;
+			if ((idx & 7) == 0 && lane == 0) out[idx >> 3] = reverse_bits ? (uint8_t)(__brev(reg) >> 24) : (uint8_t)reg;
 		}
 	}
 }
