@@ -675,14 +675,18 @@ HFDL_FN int demod_block(ChanScalars &s, ChanArrays &a, const DemodConst &T, cons
 			// symsync_crcf_execute: push one sample into both windows (lane 0 = newest)
 			wmf.x = wave_shr1(mfo.x, wmf.x); wmf.y = wave_shr1(mfo.y, wmf.y);
 			wdmf.x = wave_shr1(mfo.x, wdmf.x); wdmf.y = wave_shr1(mfo.y, wdmf.y);
-			cf out[4];
+			// at most 4 outputs per input sample, kept in named registers: an array indexed by `produced` would live in
+			// scratch memory, and beside the HBM-saturating fold kernel every scratch access is a multi-microsecond stall
+			cf out0 = cf{0.f, 0.f}, out1 = out0, out2 = out0, out3 = out0;
 			int produced = 0;
 			while (s.ss_b < D_SS_NPFB && produced < 4) {
 				cf m, d;
 				m.x = row32_sum(hmf * wmf.x); m.y = row32_sum(hmf * wmf.y);
 				d.x = row32_sum(hdm * wdmf.x); d.y = row32_sum(hdm * wdmf.y);
-				out[produced].x = m.x / 3.0f;
-				out[produced].y = m.y / 3.0f;
+				{
+					cf o; o.x = m.x / 3.0f; o.y = m.y / 3.0f;
+					if (produced == 0) out0 = o; else if (produced == 1) out1 = o; else if (produced == 2) out2 = o; else out3 = o;
+				}
 				if (s.ss_decim == 2) {
 					s.ss_decim = 0;
 					float q = m.x * d.x + m.y * d.y;
@@ -718,9 +722,10 @@ HFDL_FN int demod_block(ChanScalars &s, ChanArrays &a, const DemodConst &T, cons
 				// |phi| <= pi: the hardware sin/cos (argument in revolutions) needs no range reduction
 				const float rev = s.phi * 0.15915494309189535f;
 				const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
+				const cf oi = i == 0 ? out0 : (i == 1 ? out1 : (i == 2 ? out2 : out3));
 				cf r;
-				r.x = out[i].x * cp + out[i].y * sp;
-				r.y = out[i].y * cp - out[i].x * sp;
+				r.x = oi.x * cp + oi.y * sp;
+				r.y = oi.y * cp - oi.x * sp;
 				if (fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1) {
 					s.dphi = s.phi = 0.f;
 					symsync_reset(s, a);

@@ -35,12 +35,28 @@ struct DemodBuffers {
 	int cap;
 };
 
-// __launch_bounds__(64, 8): at most 64 VGPRs.  The 256 demodulator wavefronts are co-resident with the fold kernel's
-// workgroups (stream A); at 83 VGPRs one demod wave made a SIMD too full for the fourth fold wave, so every CU hosting a
-// channel ran 3 instead of 4 fold workgroups and the HBM-bound fold lost ~15 % for as long as the demodulator was
-// resident (measured with sleeping stand-in waves too: profiles/r01_experiments.md).  The few spills land in the short
-// lanes-over-samples phases.
-__global__ __launch_bounds__(64, 8) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
+// global -> LDS copy by one wave, 8 independent loads per lane issued before the first is used
+template <typename T>
+__device__ __forceinline__ void stage_copy(T *__restrict__ dst, const T *__restrict__ src, int n, int lane)
+{
+	int i = lane;
+	for (; i + 7 * 64 < n; i += 8 * 64) {
+		T v[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) v[u] = src[i + u * 64];
+#pragma unroll
+		for (int u = 0; u < 8; u++) dst[i + u * 64] = v[u];
+	}
+	for (; i < n; i += 64) dst[i] = src[i];
+}
+
+// __launch_bounds__(64, 5): at most 96 VGPRs.  The 256 demodulator wavefronts are co-resident with the fold kernel's
+// workgroups (stream A): four fold waves of 104 VGPRs leave exactly 96 of a SIMD's 512; one register more and every CU
+// hosting a channel runs 3 instead of 4 fold workgroups, and the HBM-bound fold loses ~15 % for as long as the
+// demodulator is resident (profiles/r01_experiments.md).  Staying inside 96 also keeps the symbol loop free of scratch
+// spills: scratch is memory, and beside a kernel that saturates HBM every spill reload is a multi-microsecond stall
+// (the 64-VGPR version of this kernel ran 2.2 x slower beside the fold than alone for exactly that reason).
+__global__ __launch_bounds__(64, 5) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
 		const int *__restrict__ n_in, int outs_stride)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -57,16 +73,22 @@ __global__ __launch_bounds__(64, 8) void demod_kernel(DevTables T, DemodBuffers 
 	cf *rs = (cf *)p;                                p += sizeof(cf) * (size_t)B.cap;
 	cf *agc = (cf *)p;                               p += sizeof(cf) * (size_t)B.cap;
 	cf *mf = (cf *)p;                                p += sizeof(cf) * (size_t)B.cap;
-	float *lvl = (float *)p;
+	float *lvl = (float *)p;                         p += sizeof(float) * (size_t)B.cap;
+	float *l_rs_h = (float *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+	// The channelizer output of this block is staged in LDS (in the space of agc + mf, which are written only after the
+	// resampler has consumed it: 16 cap >= 8 n_in because the resampling rate is > 0.5), and so is the resampler's filter
+	// bank: all loads of a lane are in flight together, instead of one dependent memory round trip per filter tap.
+	cf *l_in = agc;
 
 	ChanState *gs = B.states + c;
 	ChanScalars S = gs->s;
-	{
-		const uint32_t *src = (const uint32_t *)&gs->a;
-		uint32_t *dst = (uint32_t *)A;
-		for (unsigned i = lane; i < sizeof(ChanArrays) / 4; i += 64) dst[i] = src[i];
-	}
-	for (int i = lane; i < D_SS_NPFB * D_SS_TAPS; i += 64) { l_ss_mf[i] = T.c.ss_mf[i]; l_ss_dmf[i] = T.c.ss_dmf[i]; }
+	const int n_block = n_in[c];
+	// prologue copies with 8 loads of a lane in flight at a time: beside the fold kernel a dependent load costs microseconds
+	stage_copy((uint32_t *)A, (const uint32_t *)&gs->a, (int)(sizeof(ChanArrays) / 4), lane);
+	stage_copy(l_in, chan_out + (size_t)c * outs_stride, n_block, lane);
+	stage_copy((float4 *)l_rs_h, (const float4 *)T.c.rs_h, D_RS_NPFB * D_RS_TAPS / 4, lane);
+	stage_copy(l_ss_mf, T.c.ss_mf, D_SS_NPFB * D_SS_TAPS, lane);
+	stage_copy(l_ss_dmf, T.c.ss_dmf, D_SS_NPFB * D_SS_TAPS, lane);
 	if (lane < D_MF) l_mf[lane] = T.c.mf[lane];
 	if (lane < D_EQ) l_eq[lane] = T.c.eq_h0[lane];
 	if (lane < 8) { l_m1[lane] = T.c.m1_hi[lane]; l_m1[8 + lane] = T.c.m1_lo[lane]; }
@@ -74,7 +96,7 @@ __global__ __launch_bounds__(64, 8) void demod_kernel(DevTables T, DemodBuffers 
 	__syncthreads();
 
 	DemodConst K = T.c;
-	K.ss_mf = l_ss_mf; K.ss_dmf = l_ss_dmf; K.mf = l_mf; K.eq_h0 = l_eq; K.m1_hi = l_m1; K.m1_lo = l_m1 + 8; K.corr_tab = l_corr;
+	K.rs_h = l_rs_h; K.ss_mf = l_ss_mf; K.ss_dmf = l_ss_dmf; K.mf = l_mf; K.eq_h0 = l_eq; K.m1_hi = l_m1; K.m1_lo = l_m1 + 8; K.corr_tab = l_corr;
 	BlockIo io;
 	io.rs = rs; io.agc = agc; io.mf = mf; io.lvl = lvl; io.cap = B.cap;
 	io.data = B.data + (size_t)c * 2 * MAX_DATA_SYMBOLS;
@@ -87,7 +109,7 @@ __global__ __launch_bounds__(64, 8) void demod_kernel(DevTables T, DemodBuffers 
 	} else {
 		io.tap_resampled = nullptr; io.tap_mf = nullptr; io.tap_symbols = nullptr; io.tap_level = nullptr; io.tap_counts = nullptr;
 	}
-	demod_block(S, *A, K, io, chan_out + (size_t)c * outs_stride, n_in[c]);
+	demod_block(S, *A, K, io, l_in, n_block);
 	__syncthreads();
 	if (lane == 0) gs->s = S;
 	{
@@ -255,6 +277,7 @@ static size_t demod_lds_bytes(int cap)
 	size_t b = (sizeof(ChanArrays) + 15) & ~(size_t)15;
 	b += sizeof(float) * D_SS_NPFB * D_SS_TAPS * 2 + sizeof(float) * 48 + sizeof(uint64_t) * 16 + sizeof(float) * 128;
 	b += (sizeof(cf) * 3 + sizeof(float)) * (size_t)cap;
+	b += 16 + sizeof(float) * D_RS_NPFB * D_RS_TAPS;
 	return b;
 }
 
