@@ -186,25 +186,38 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 	uint8_t *table = lds;
 	uint8_t *vin = lds + K5_TABLE_BYTES;
 	uint64_t *decw = (uint64_t *)(lds + 2 * K5_TABLE_BYTES);
+	uint8_t *l_scr = lds + 2 * K5_TABLE_BYTES + sizeof(uint64_t) * (7560 + 8);       // 128 bytes
 
 	const FrameRec fr = frames[f];
 	const ModeParams mp = mode_params(fr.mode);
 	const int nsym = mp.segments * 30, ncoded = nsym * mp.arity, cols = ncoded / 40;
 	const cf *sym = data_all + ((size_t)fr.channel * 2 + fr.slot) * MAX_DATA_SYMBOLS;
 	const float mask_flip = fr.bitmask_lsb ? -1.0f : 1.0f;
-	// descramble + soft de-map + de-interleaver push (src/hfdl.c:1008-1019, 378-392)
-	for (int i = lane; i < nsym; i += 64) {
-		const float flip = (scrambler[i % 120] ? -1.0f : 1.0f) * mask_flip;
-		cf x = sym[i];
-		x.x *= flip; x.y *= flip;
-		uint8_t soft[3];
-		psk_soft(mp.arity, x, soft);
-		for (int j = 0; j < mp.arity; j++) {
-			const int k = i * mp.arity + j;
-			const int row = k % 40;
-			int col = (k / 40 - mp.col_shift * k) % cols;
-			if (col < 0) col += cols;
-			table[row * cols + col] = soft[j];
+	l_scr[lane] = lane < 120 ? scrambler[lane] : 0;
+	if (lane + 64 < 120) l_scr[lane + 64] = scrambler[lane + 64];
+	__syncthreads();
+	// descramble + soft de-map + de-interleaver push (src/hfdl.c:1008-1019, 378-392); four symbol loads per lane in flight
+	// (this kernel runs beside the fold, where a dependent global load costs microseconds)
+	for (int base = 0; base < nsym; base += 256) {
+		cf xs[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { const int i = base + u * 64 + lane; xs[u] = i < nsym ? sym[i] : cf{0.f, 0.f}; }
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int i = base + u * 64 + lane;
+			if (i >= nsym) continue;
+			const float flip = (l_scr[i % 120] ? -1.0f : 1.0f) * mask_flip;
+			cf x = xs[u];
+			x.x *= flip; x.y *= flip;
+			uint8_t soft[3];
+			psk_soft(mp.arity, x, soft);
+			for (int j = 0; j < mp.arity; j++) {
+				const int k = i * mp.arity + j;
+				const int row = k % 40;
+				int col = (k / 40 - mp.col_shift * k) % cols;
+				if (col < 0) col += cols;
+				table[row * cols + col] = soft[j];
+			}
 		}
 	}
 	__syncthreads();
@@ -238,7 +251,10 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 	if (slot < 0) return;
 	const int nbits = vin_len / 2, noct = (nbits + 7) / 8;
 	hfdl_gpu_pdu *out = pdus + slot;
-	viterbi27_wave(vin, nbits, decw, out->octets, true);
+	uint8_t *l_oct = table;                    // the de-interleaver table is dead: decoded octets go to LDS first
+	viterbi27_wave(vin, nbits, decw, l_oct, true);
+	__syncthreads();
+	for (int i = lane; i < noct; i += 64) out->octets[i] = l_oct[i];
 	if (lane == 0) {
 		// dispatch_pdu metadata, src/hfdl.c:1058-1074
 		out->channel = fr.channel;
@@ -255,7 +271,7 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 		out->train_bits_total = fr.train_total;
 		int kind = 0;
 		uint32_t hdr_len = 0;
-		out->fcs_status = (uint8_t)pdu_triage(out->octets, (uint32_t)noct, &kind, &hdr_len);   // same lane wrote the octets
+		out->fcs_status = (uint8_t)pdu_triage(l_oct, (uint32_t)noct, &kind, &hdr_len);
 		out->pdu_kind = (uint8_t)kind;
 		out->hdr_len = (uint16_t)hdr_len;
 	}
@@ -281,7 +297,7 @@ static size_t demod_lds_bytes(int cap)
 	return b;
 }
 
-static size_t k5_lds_bytes() { return 2 * (size_t)K5_TABLE_BYTES + sizeof(uint64_t) * (7560 + 8); }
+static size_t k5_lds_bytes() { return 2 * (size_t)K5_TABLE_BYTES + sizeof(uint64_t) * (7560 + 8) + 128; }
 
 static DevTables resolve_tables(const float *d_img, const DemodTables &h)
 {

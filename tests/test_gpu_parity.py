@@ -573,3 +573,42 @@ def test_full_pdu_ring_drops_and_counts(gpu, oracle, monkeypatch):
     assert all(p["octets"][:len(next(iter(sent)))] in sent for p in first)
     assert [p["octets"][:len(late["octets"])] for p in got if p["mode"] == 1] == [late["octets"]]
     fe.close()
+
+
+def test_host_c_program_live_pipe(gpu, oracle):
+    """A source that the front end keeps up with (samples arrive through a pipe, paced at ~4 x real time): the C host then
+    drains after every block instead of lagging one block behind, and must deliver the same PDUs."""
+    import os
+    import subprocess
+    import time
+    fs, cf = 250000, 10_000_000
+    freqs = [9_930_000, 10_037_000, 10_081_500]
+    bursts = synth.plan_traffic(freqs, 6.0, seed=13, dense=True)
+    x = synth.synth_wideband(fs, cf, int(6.0 * fs), bursts, noise_sigma=0.01, seed=13)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "dumphfdl_amd", "hfdl_replay")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "dumphfdl_amd", "host")])
+    proc = subprocess.Popen([exe, "--iq-file", "-", "--sample-rate", str(fs), "--sample-format", "CF32", "--centerfreq", str(cf / 1e3)]
+                            + ["%.3f" % (f / 1e3) for f in freqs], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    raw = x.view(np.float32).tobytes()
+    step = 8 * 28672                                    # one block of this geometry
+    time.sleep(3.0)                                     # let the front end come up (filter design, 3 channels) before pacing matters
+    for off in range(0, len(raw), step):
+        proc.stdin.write(raw[off:off + step])
+        proc.stdin.flush()
+        time.sleep(0.03)
+    proc.stdin.close()
+    out = proc.stdout.read().decode()
+    err = proc.stderr.read().decode()
+    assert proc.wait(timeout=120) == 0, err
+    got = []
+    for line in out.splitlines():
+        if line.startswith("PDU "):
+            kv = dict(t.split("=") for t in line.split()[1:-1])
+            got.append((int(kv["freq"]), int(kv["bit_rate"]), kv["slot"], bytes.fromhex(line.split()[-1])))
+    ora = oracle.Frontend(fs, cf, freqs)
+    n = ora.ddc.input_size
+    for b in range(len(x) // n):
+        ora.push_block(x[b * n:(b + 1) * n])
+    assert sorted(got) == sorted((p["freq"], p["bit_rate"], p["slot"], p["octets"]) for p in ora.pdus) and len(got) == len(bursts)
