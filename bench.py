@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- wideband I/Q Msamples/s (+ HFDL frames/s) of the MI355X HFDL front end at a fixed channel count.
 
-  python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2]
+  python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg4]
 
 One "step" = one block of `input_size` wideband cf32 samples through the WHOLE hot path: overlap assembly, forward
 FFT, per-channel fold + inverse FFT + NCO (fastddc), per-channel demodulator, burst decoder, PDU read-back.
@@ -30,6 +30,9 @@ WORKLOADS = {
     # BASELINE.json configs[2]: 40 Msps synthetic cf32, 256 channels on a 150 kHz grid, 1 MI355X
     "cfg3": dict(fs=40_000_000, centerfreq=15_000_000, nch=256, grid=150_000, blocks=16, seed=3, noise=0.05,
                  name="40 Msps cf32, 256 HFDL channels (BASELINE.json configs[2]; per rank at N>1 = configs[4])"),
+    # BASELINE.json configs[3]: same geometry, every channel carries back-to-back bursts cycling all 8 modes (Viterbi batch stress)
+    "cfg4": dict(fs=40_000_000, centerfreq=15_000_000, nch=256, grid=150_000, blocks=32, seed=4, noise=0.05, dense=True,
+                 name="40 Msps cf32, 256 HFDL channels, burst-dense: back-to-back 300/600/1200/1800 bps single+double-slot bursts (BASELINE.json configs[3])"),
     # BASELINE.json configs[1]: 8 Msps, 32 channels on a 200 kHz grid
     "cfg2": dict(fs=8_000_000, centerfreq=10_000_000, nch=32, grid=200_000, blocks=26, seed=2, noise=0.02,
                  name="8 Msps cf32, 32 HFDL channels (BASELINE.json configs[1])"),
@@ -48,12 +51,28 @@ def make_input(w, geom_input_size, rank, world):
     from dumphfdl_amd import shard
     seed = shard.stream_seed(w["seed"], rank, world)
     nsamp = w["blocks"] * geom_input_size
-    cache = "/tmp/hfdl_bench_%s_seed%d_%d.npy" % (w["fs"], seed, nsamp)
+    cache = "/tmp/hfdl_bench_%s_seed%d_%d%s.npy" % (w["fs"], seed, nsamp, "_dense" if w.get("dense") else "")
     freqs = channel_plan(w)
     dur = nsamp / w["fs"]
     rng = np.random.default_rng(seed)
     bursts = []
     for i, f in enumerate(freqs):
+        if w.get("dense"):
+            # as many bursts as fit the resident stretch, modes cycling 0..7 from a per-channel offset
+            t, k = float(rng.uniform(0.02, 0.2)), 0
+            while True:
+                mode = (i + k) % 8
+                length = synth.burst_symbols_len(mode) / 1800
+                if t + length > dur - 0.05:
+                    if k == 0 and mode >= 4:            # a double-slot burst does not fit any more: try the single-slot one
+                        k += 4
+                        continue
+                    break
+                bursts.append(dict(freq=f, mode=mode, octets=synth.make_pdu(rng, mode), t0=t,
+                                   amp=float(rng.uniform(0.01, 0.03)), cfo=float(rng.uniform(-15, 15))))
+                t += length + float(rng.uniform(0.05, 0.15))
+                k += 1
+            continue
         mode = i % 4
         t0 = float(rng.uniform(0.02, max(0.03, dur - synth.burst_symbols_len(mode) / 1800 - 0.05)))
         bursts.append(dict(freq=f, mode=mode, octets=synth.make_pdu(rng, mode), t0=t0,

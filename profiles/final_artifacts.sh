@@ -5,6 +5,7 @@ mkdir -p $OUT
 cd /root/repo
 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python bench.py --workload cfg2 --no-cpu-baseline > $OUT/bench_cfg2.json 2>> $OUT/bench_cfg3.err
+python bench.py --workload cfg4 --no-cpu-baseline > $OUT/bench_cfg4.json 2>> $OUT/bench_cfg3.err
 python bench.py --host-input --no-cpu-baseline > $OUT/bench_cfg3_host_cf32.json 2>> $OUT/bench_cfg3.err
 python bench.py --host-input --sample-format cs16 --no-cpu-baseline > $OUT/bench_cfg3_host_cs16.json 2>> $OUT/bench_cfg3.err
 cd /tmp && export TMPDIR=/tmp
