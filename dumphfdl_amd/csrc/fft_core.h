@@ -13,7 +13,7 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 // On exit position p of a column holds X[bitrev(p)].  DIR = -1 forward, +1 backward (unnormalised).
 // tw[t] = exp(-2 pi i t / R).
 template <int DIR>
-__device__ void lds_fft_columns(float2 *s, int R, int logR, int pitch, int log_cols, const float2 *__restrict__ tw)
+__device__ void lds_fft_columns(float2 *s, int R, int logR, int pitch, int log_cols, const float2 *tw)
 {
 	const int cols_mask = (1 << log_cols) - 1;
 	int len = R, loglen = logR;

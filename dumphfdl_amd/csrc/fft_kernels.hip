@@ -50,8 +50,10 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass1(const float2 *__restric
 		}
 		sm[e] = v;
 	}
+	float2 *ltw = sm + total;                  // the radix's twiddle table next to the tile: no global load inside the stages
+	for (int t = threadIdx.x; t < p.r1; t += FFT_THREADS) ltw[t] = p.tw1[t];
 	__syncthreads();
-	lds_fft_columns<-1>(sm, p.r1, p.l1, FFT_TILE, FFT_TILE_LOG, p.tw1);
+	lds_fft_columns<-1>(sm, p.r1, p.l1, FFT_TILE, FFT_TILE_LOG, ltw);
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
 		const int k1 = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
 		const int c = c0 + col;
@@ -79,8 +81,10 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass2(float2 *__restrict__ bu
 		}
 		sm[e] = v;
 	}
+	float2 *ltw = sm + total;
+	for (int t = threadIdx.x; t < p.r2; t += FFT_THREADS) ltw[t] = p.tw2[t];
 	__syncthreads();
-	lds_fft_columns<-1>(sm, p.r2, p.l2, FFT_TILE, FFT_TILE_LOG, p.tw2);
+	lds_fft_columns<-1>(sm, p.r2, p.l2, FFT_TILE, FFT_TILE_LOG, ltw);
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
 		const int k2 = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
 		const int cc = cc0 + col;
@@ -111,8 +115,10 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restric
 		}
 		sm[n3 * FFT_TILE + col] = v;
 	}
+	float2 *ltw = sm + total;
+	for (int t = threadIdx.x; t < p.r3; t += FFT_THREADS) ltw[t] = p.tw3[t];
 	__syncthreads();
-	lds_fft_columns<-1>(sm, p.r3, p.l3, FFT_TILE, FFT_TILE_LOG, p.tw3);
+	lds_fft_columns<-1>(sm, p.r3, p.l3, FFT_TILE, FFT_TILE_LOG, ltw);
 	const unsigned half = shifted ? (unsigned)(p.n >> 1) : 0u;
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
 		const int k3 = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
@@ -131,13 +137,14 @@ void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh,
 {
 	const int c1 = (p.n >> p.l1), c2 = p.r1 * p.r3, c3 = p.r1 * p.r2;
 	const dim3 g1((c1 + FFT_TILE - 1) / FFT_TILE), blk(FFT_THREADS);
-	const size_t l1 = (size_t)p.r1 * FFT_TILE * sizeof(float2), l2 = (size_t)p.r2 * FFT_TILE * sizeof(float2);
+	// tile + the radix's twiddle table
+	const size_t l1 = (size_t)p.r1 * (FFT_TILE + 1) * sizeof(float2), l2 = (size_t)p.r2 * (FFT_TILE + 1) * sizeof(float2);
 	if (fmt == SFMT_CS16) hipLaunchKernelGGL(fft_pass1<SFMT_CS16>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
 	else if (fmt == SFMT_CU8) hipLaunchKernelGGL(fft_pass1<SFMT_CU8>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
 	else hipLaunchKernelGGL(fft_pass1<SFMT_CF32>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
 	hipLaunchKernelGGL(fft_pass2, dim3((c2 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), l2, st,
 			work, p);
-	hipLaunchKernelGGL(fft_pass3, dim3((c3 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), p.r3 * FFT_TILE * sizeof(float2), st,
+	hipLaunchKernelGGL(fft_pass3, dim3((c3 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), (size_t)p.r3 * (FFT_TILE + 1) * sizeof(float2), st,
 			(const float2 *)work, out, p, shifted ? 1 : 0, lay);
 }
 
