@@ -149,16 +149,36 @@ struct input_cfg *input_cfg_create(void)
 
 void input_cfg_destroy(struct input_cfg *cfg) { free(cfg); }
 
+static struct input_vtable const *g_vtables[INPUT_TYPE_MAX];
+
+int32_t input_vtable_register(input_type type, struct input_vtable const *vtable)
+{
+	if (type <= INPUT_TYPE_UNDEF || type >= INPUT_TYPE_MAX || vtable == NULL) return -1;
+	if (vtable->create == NULL || vtable->init == NULL || vtable->destroy == NULL || vtable->rx_thread_routine == NULL) return -1;
+	g_vtables[type] = vtable;
+	return 0;
+}
+
+static struct input_vtable const *input_vtable_get(input_type type)
+{
+	if (type <= INPUT_TYPE_UNDEF || type >= INPUT_TYPE_MAX) return NULL;
+	if (g_vtables[type] != NULL) return g_vtables[type];
+	return type == INPUT_TYPE_FILE ? &file_vtable : NULL;          /* SoapySDR: only if the host program registered it */
+}
+
 struct block *input_create(struct input_cfg *cfg)
 {
-	if (cfg == NULL || cfg->type != INPUT_TYPE_FILE) return NULL;     /* SoapySDR slot: not built (no radio on a GPU node) */
-	struct input *in = file_vtable.create(cfg);
+	if (cfg == NULL) return NULL;
+	struct input_vtable const *vt = input_vtable_get(cfg->type);
+	if (vt == NULL) return NULL;
+	struct input *in = vt->create(cfg);
 	if (in == NULL) return NULL;
-	in->vtable = &file_vtable;
+	in->vtable = (struct input_vtable *)vt;
 	in->config = cfg;
 	in->block.producer.type = PRODUCER_SINGLE;
+	in->block.producer.max_tu = 0;
 	in->block.consumer.type = CONSUMER_NONE;
-	in->block.thread_routine = file_vtable.rx_thread_routine;
+	in->block.thread_routine = vt->rx_thread_routine;
 	return &in->block;
 }
 

@@ -97,7 +97,9 @@ size_t hfdl_ring_read(struct hfdl_ring *r, float complex *dst, size_t n);       
 
 /* ------------------------------------------------------------------ inputs (src/input-common.h, input-helpers.h) */
 
-typedef enum { INPUT_TYPE_UNDEF, INPUT_TYPE_FILE, INPUT_TYPE_MAX } input_type;
+/* INPUT_TYPE_SOAPYSDR is the reference's optional radio input (src/input-common.h:8-15, built WITH_SOAPYSDR): this library
+ * carries no SoapySDR code, the slot is filled by the host program with input_vtable_register() */
+typedef enum { INPUT_TYPE_UNDEF, INPUT_TYPE_SOAPYSDR, INPUT_TYPE_FILE, INPUT_TYPE_MAX } input_type;
 typedef enum { SFMT_UNDEF = 0, SFMT_CU8, SFMT_CS16, SFMT_CF32, SFMT_MAX } sample_format;
 
 struct input_cfg {
@@ -127,6 +129,12 @@ struct input {
 	float full_scale;
 	int32_t bytes_per_sample;
 };
+
+/* Plug an input implementation into input_create()'s switch (input_vtable_get, src/input-common.c:12-25): dumphfdl's
+ * soapysdr_input_vtable registers under INPUT_TYPE_SOAPYSDR unchanged -- its rx thread only needs complex_samples_produce()
+ * and the block fields.  Returns 0, or -1 for a type outside the enum / a NULL or incomplete table.  Not in the reference
+ * (which selects at compile time). */
+int32_t input_vtable_register(input_type type, struct input_vtable const *vtable);
 
 struct input_cfg *input_cfg_create(void);
 void          input_cfg_destroy(struct input_cfg *cfg);

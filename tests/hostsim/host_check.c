@@ -1,7 +1,8 @@
 /* host_check.c -- TEST PROGRAM: drives libhfdl_host.so's block / input API the way dumphfdl's main() does, without a GPU.
  *   host_check ring                       ring wrap-around / overrun behaviour
  *   host_check file PATH FMT BUFSIZE OUT  file input -> ring -> this consumer; converted cf32 samples written to OUT
- *   host_check graph                      connect/return-value contract of the block graph and channel slots */
+ *   host_check graph                      connect/return-value contract of the block graph and channel slots
+ *   host_check plugin                     an input registered with input_vtable_register() (the SoapySDR slot) feeds the ring */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -108,12 +109,82 @@ static int check_graph(void)
 	return 0;
 }
 
+/* a stand-in for a radio input: produces a ramp in bursts of max_tu samples, like a SoapySDR rx thread would (src/input-soapysdr.c:226-273) */
+struct ramp_input { struct input input; int total; };
+static struct input *ramp_create(struct input_cfg *cfg) { (void)cfg; struct ramp_input *r = calloc(1, sizeof(*r)); return &r->input; }
+static int32_t ramp_init(struct input *in)
+{
+	in->full_scale = 1.0f; in->bytes_per_sample = 8; in->block.producer.max_tu = 500;
+	((struct ramp_input *)in)->total = 5000;
+	return 0;
+}
+static void ramp_destroy(struct input *in) { free(in); }
+static void *ramp_thread(void *ctx)
+{
+	struct block *block = ctx;
+	struct ramp_input *r = (struct ramp_input *)block;          /* struct input starts with its block */
+	struct circ_buffer *cb = &block->producer.out->circ_buffer;
+	float complex buf[500];
+	for (int done = 0; done < r->total; done += 500) {
+		for (int i = 0; i < 500; i++) buf[i] = (float)(done + i) - (float)(done + i) * I;
+		for (;;) {                                               /* wait for room like file_input_thread does */
+			pthread_mutex_lock(cb->mutex);
+			size_t room = hfdl_ring_space_available(cb->buf);
+			pthread_mutex_unlock(cb->mutex);
+			if (room >= 500) break;
+			usleep(1000);
+		}
+		complex_samples_produce(cb, buf, 500);
+	}
+	block_connection_one2one_shutdown(block->producer.out);
+	block->running = false;
+	return NULL;
+}
+static struct input_vtable const ramp_vtable = { ramp_create, ramp_init, ramp_destroy, ramp_thread };
+
+static int check_plugin(void)
+{
+	struct input_cfg *cfg = input_cfg_create();
+	cfg->type = INPUT_TYPE_SOAPYSDR;
+	cfg->sfmt = SFMT_CF32;
+	cfg->sample_rate = 250000;
+	if (input_create(cfg) != NULL) return 1;                                     /* nothing registered: no such input */
+	if (input_vtable_register(INPUT_TYPE_MAX, &ramp_vtable) == 0) return 2;
+	if (input_vtable_register(INPUT_TYPE_SOAPYSDR, NULL) == 0) return 3;
+	if (input_vtable_register(INPUT_TYPE_SOAPYSDR, &ramp_vtable) != 0) return 4;
+	struct block *in = input_create(cfg);
+	if (in == NULL || input_init(in) < 0) return 5;
+	struct block sink = { .consumer = { .type = CONSUMER_SINGLE, .min_ru = 256 } };
+	if (block_connect_one2one(in, &sink) != 1) return 6;
+	struct circ_buffer *cb = &sink.consumer.in->circ_buffer;
+	if (block_start(in) != 1) return 7;
+	float complex tmp[1024];
+	int seen = 0;
+	for (;;) {
+		pthread_mutex_lock(cb->mutex);
+		while (hfdl_ring_size(cb->buf) == 0 && !block_connection_is_shutdown_signaled(sink.consumer.in)) pthread_cond_wait(cb->cond, cb->mutex);
+		size_t n = hfdl_ring_read(cb->buf, tmp, 1024);
+		int done = n == 0 && block_connection_is_shutdown_signaled(sink.consumer.in);
+		pthread_mutex_unlock(cb->mutex);
+		for (size_t i = 0; i < n; i++, seen++) if (crealf(tmp[i]) != (float)seen || cimagf(tmp[i]) != -(float)seen) return 8;
+		if (done) break;
+	}
+	if (seen != 5000) return 9;
+	while (block_is_running(in)) usleep(1000);
+	block_disconnect_one2one(in, &sink);
+	input_destroy(in);
+	input_cfg_destroy(cfg);
+	printf("plugin ok\n");
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	int rc = 99;
 	if (argc >= 2 && !strcmp(argv[1], "ring")) rc = check_ring();
 	else if (argc >= 6 && !strcmp(argv[1], "file")) rc = check_file(argv[2], argv[3], atoi(argv[4]), argv[5]);
 	else if (argc >= 2 && !strcmp(argv[1], "graph")) rc = check_graph();
+	else if (argc >= 2 && !strcmp(argv[1], "plugin")) rc = check_plugin();
 	if (rc) fprintf(stderr, "host_check %s failed at step %d\n", argc > 1 ? argv[1] : "?", rc);
 	return rc;
 }

@@ -26,6 +26,12 @@ def test_ring_and_overrun(host_check):
     assert "ring ok" in out.stdout
 
 
+def test_input_plugin_slot(host_check):
+    """input_vtable_register(): a host-provided input (the SoapySDR slot) runs through input_create / input_init / block_start."""
+    out = subprocess.run([host_check, "plugin"], capture_output=True, text=True)
+    assert out.returncode == 0 and "plugin ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
 def test_block_graph_contract(host_check):
     out = subprocess.run([host_check, "graph"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
