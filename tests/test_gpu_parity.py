@@ -589,7 +589,8 @@ def test_host_c_program_live_pipe(gpu, oracle):
     exe = os.path.join(root, "dumphfdl_amd", "hfdl_replay")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-C", os.path.join(root, "dumphfdl_amd", "host")])
-    proc = subprocess.Popen([exe, "--iq-file", "-", "--sample-rate", str(fs), "--sample-format", "CF32", "--centerfreq", str(cf / 1e3)]
+    proc = subprocess.Popen([exe, "--iq-file", "-", "--sample-rate", str(fs), "--sample-format", "CF32", "--centerfreq", str(cf / 1e3),
+                             "--statsd-print", "--noise-floor-stats-interval", "1"]
                             + ["%.3f" % (f / 1e3) for f in freqs], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     raw = x.view(np.float32).tobytes()
     step = 8 * 28672                                    # one block of this geometry
@@ -612,3 +613,9 @@ def test_host_c_program_live_pipe(gpu, oracle):
     for b in range(len(x) // n):
         ora.push_block(x[b * n:(b + 1) * n])
     assert sorted(got) == sorted((p["freq"], p["bit_rate"], p["slot"], p["octets"]) for p in ora.pdus) and len(got) == len(bursts)
+    # the noise-floor gauge thread (hfdl_nf_stats_thread_start, src/hfdl.c:1082-1105) reported every channel at least once,
+    # in tenths of -dBFS (with back-to-back bursts the estimate rides between the noise and the burst level)
+    gauges = [l.split() for l in err.splitlines() if l.startswith("STATSD gauge ")]
+    last = {int(g[2].split(".")[0]): int(g[3]) for g in gauges if g[2].endswith(".noise_floor")}     # before the first samples it is the start value
+    assert set(last) == set(freqs), err
+    assert all(50 <= v <= 900 for v in last.values()), last
