@@ -20,6 +20,9 @@
  * All functions return 0 on success or a negative HFDL_GPU_E* code (the reference's constructors
  * return NULL / -1 and xcalloc failure _exit()s: src/util.c:25-33); hfdl_gpu_last_error() gives text.
  * There is no CPU fallback: if no gfx950 device is usable every call fails with HFDL_GPU_ENODEV.
+ *
+ * Threading: a front end is driven by ONE thread at a time (the reference's fft_thread; src/fft.c:30-66); different front
+ * ends -- one per GPU -- are independent.  hfdl_gpu_last_error() is per calling thread.
  */
 #ifndef HFDL_GPU_H
 #define HFDL_GPU_H
@@ -135,7 +138,8 @@ typedef struct {
 	uint32_t pdu_ring_capacity;
 } hfdl_gpu_frontend_counters_t;
 int  hfdl_gpu_frontend_counters(hfdl_gpu_frontend *fe, hfdl_gpu_frontend_counters_t *out);
-/* the HIP stream all kernels of this front end are launched on (hipStream_t as void*) */
+/* the HIP stream the channelizer kernels (forward FFT, fold, inverse FFT) are launched on (hipStream_t as void*); device
+ * input handed to push_block must be complete on, or synchronised with, this stream */
 void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe);
 
 /* per-channel observability: the hot-path StatsD counters and the noise-floor gauge of the reference
