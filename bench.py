@@ -54,6 +54,22 @@ def make_input(w, geom_input_size, rank, world):
     cache = "/tmp/hfdl_bench_%s_seed%d_%d%s.npy" % (w["fs"], seed, nsamp, "_dense" if w.get("dense") else "")
     freqs = channel_plan(w)
     dur = nsamp / w["fs"]
+    bursts = plan_bursts(w, freqs, dur, seed)
+    if os.path.exists(cache):
+        x = np.load(cache, mmap_mode="r")
+        if x.shape == (nsamp,):
+            return np.ascontiguousarray(x), bursts
+    x = synth.synth_wideband(w["fs"], w["centerfreq"], nsamp, bursts, noise_sigma=w["noise"], seed=seed)
+    try:
+        np.save(cache, x)
+    except OSError:
+        pass
+    return x, bursts
+
+
+def plan_bursts(w, freqs, dur, seed):
+    """The traffic of a workload: one single-slot burst per channel, or (dense) as many back-to-back bursts as fit."""
+    from dumphfdl_amd import synth
     rng = np.random.default_rng(seed)
     bursts = []
     for i, f in enumerate(freqs):
@@ -78,16 +94,7 @@ def make_input(w, geom_input_size, rank, world):
         bursts.append(dict(freq=f, mode=mode, octets=synth.make_pdu(rng, mode), t0=t0,
                            amp=float(rng.uniform(0.01, 0.03)),        # ~19..29 dB in-channel SNR
                            cfo=float(rng.uniform(-15, 15))))
-    if os.path.exists(cache):
-        x = np.load(cache, mmap_mode="r")
-        if x.shape == (nsamp,):
-            return np.ascontiguousarray(x), bursts
-    x = synth.synth_wideband(w["fs"], w["centerfreq"], nsamp, bursts, noise_sigma=w["noise"], seed=seed)
-    try:
-        np.save(cache, x)
-    except OSError:
-        pass
-    return x, bursts
+    return bursts
 
 
 def cpu_baseline(w, x, input_size, target_seconds=20.0):

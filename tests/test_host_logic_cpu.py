@@ -202,3 +202,29 @@ def test_pdu_triage_matches_oracle(sim, oracle):
     assert {(0, 0), (0, 1), (2, 2), (1, 1)} <= seen
     good = synth.make_spdu(rng)
     assert oracle.pdu_triage(good)[:2] == (0, 0) and oracle.pdu_triage(good[:40])[0] == 2
+
+
+def test_bench_traffic_plans():
+    """bench.py's synthetic traffic: bursts of a channel never overlap, all end inside the resident stretch, the burst-dense
+    workload cycles all eight modes (BASELINE.json configs[3]) and the plan is a pure function of the seed."""
+    import bench
+    from dumphfdl_amd import synth
+    for name, input_size in (("cfg3", 7340032), ("cfg4", 7340032), ("cfg2", 917504)):
+        w = bench.WORKLOADS[name]
+        freqs = bench.channel_plan(w)
+        assert len(set(freqs)) == w["nch"] and all(abs(f + 1440 - w["centerfreq"]) < 0.48 * w["fs"] for f in freqs)
+        dur = w["blocks"] * input_size / w["fs"]
+        bursts = bench.plan_bursts(w, freqs, dur, w["seed"])
+        again = bench.plan_bursts(w, freqs, dur, w["seed"])
+        assert [(b["freq"], b["mode"], b["t0"], b["octets"]) for b in bursts] == [(b["freq"], b["mode"], b["t0"], b["octets"]) for b in again]
+        by_freq = {}
+        for b in bursts:
+            by_freq.setdefault(b["freq"], []).append(b)
+        assert set(by_freq) == set(freqs)
+        for bl in by_freq.values():
+            bl.sort(key=lambda b: b["t0"])
+            ends = [b["t0"] + synth.burst_symbols_len(b["mode"]) / 1800 for b in bl]
+            assert all(e < dur for e in ends)
+            assert all(bl[i + 1]["t0"] > ends[i] for i in range(len(bl) - 1))
+        modes = {b["mode"] for b in bursts}
+        assert modes == (set(range(8)) if w.get("dense") else set(range(4)))
