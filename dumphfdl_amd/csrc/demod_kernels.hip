@@ -8,6 +8,7 @@
 //     Viterbi mapping: lane = trellis state (64 = one wavefront); the two predecessor metrics arrive by
 //     cross-lane shuffle, the 64 decisions of a trellis step are one __ballot word kept in LDS.
 #include <cstdlib>
+#include <utility>
 #include <vector>
 #include <cstring>
 #include "demod_core.h"
@@ -123,53 +124,176 @@ __global__ __launch_bounds__(64, 5) void demod_kernel(DevTables T, DemodBuffers 
 
 __device__ inline int parity_u32(uint32_t x) { return __popc(x) & 1; }
 
-// K=7 r=1/2 Viterbi over `nbits` trellis steps; vin = 2*nbits soft bytes (LDS or global); decw = nbits words of LDS.
-// out receives ceil(nbits/8) octets: MSB-first as libfec leaves them, or bit-reversed (what dumphfdl dispatches).
-// Lane = trellis state; arithmetic as update_viterbi27_blk's BFLY (src/libfec/viterbi27_port.c:147-160).
-__device__ void viterbi27_wave(const uint8_t *vin, int nbits, uint64_t *decw, uint8_t *out, bool reverse_bits)
+// ---- K=7 r=1/2 Viterbi, one wave per frame, arithmetic of update_viterbi27_blk / chainback_viterbi27
+// (src/libfec/viterbi27_port.c:105-135, 147-221).
+//
+// Both loops are serial chains, so their length in instructions is the decoder's latency (measured with s_memtime: the
+// first version spent 136 cycles per step going forward and 290 per step coming back).
+//  * State metrics stay IN PLACE with rotating labels: at step t the metric of state s lives in lane rotr6(s, t mod 6).  The
+//    predecessors i and i+32 of the states 2i and 2i+1 then sit in the two lanes that differ in bit 5-(t mod 6), and the
+//    same two lanes hold 2i and 2i+1 afterwards: ONE exchange with lane ^ (32 >> t mod 6) per step -- a DPP move on the VALU
+//    for four of the six residues -- instead of two arbitrary lane gathers.
+//  * In a lane the "own" predecessor costs bm and the "other" 510 - bm whatever the parity of the new state, and the libfec
+//    tie rule (decision = path via i+32 strictly cheaper) becomes take_other = (own - other + odd) > 0; decision = take ^ odd.
+//  * The 64 decisions of a step are the compare's own mask; v_writelane parks it in lane (t mod 60) of a register pair and
+//    60 words go to LDS lane-parallel: no exec-masked store in the chain.
+//  * The chainback is scalar code: 64 words per trip are fetched lane-parallel and pulled into SGPRs by v_readlane with a
+//    loop-constant lane, the state register never leaves the SALU, finished octets are parked with v_writelane and stored
+//    64 at a time.
+template <int X> __device__ __forceinline__ uint32_t lane_xor(uint32_t v)
+{
+	if (X == 32) return (uint32_t)__shfl_xor((int)v, 32);
+	if (X == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                         // bit mode: and 0x1f, xor 0x10
+	if (X == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);      // row_ror:8
+	if (X == 4) {
+		const int h = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);                 // row_half_mirror: ^7
+		return (uint32_t)__builtin_amdgcn_update_dpp(0, h, 0x1B, 0xf, 0xf, false);                     // quad_perm [3,2,1,0]: ^3
+	}
+	if (X == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);       // quad_perm [2,3,0,1]
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);                   // quad_perm [1,0,3,2]
+}
+
+// v_writelane_b32 (no clang builtin in this toolchain): lane SLOT of `old` takes the wave-uniform `value`.  On gfx9 a VALU
+// instruction reads one SGPR over the constant bus, so the lane select has to be an inline constant.
+template <int SLOT> __device__ __forceinline__ uint32_t write_lane(uint32_t old, uint32_t value)
+{
+	asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(SLOT));
+	return old;
+}
+
+struct VitLane {                                  // per-lane constants of the six residues
+	uint32_t t0[6], t1[6];                        // branch-table bytes (0 / 255) of the butterfly this lane belongs to
+	int odd[6];                                   // 1 if the lane's new state is odd (its own predecessor is i+32)
+};
+
+// lanes whose bit 5-R is set: the lanes that hold an odd new state after a residue-R step
+template <int R> __device__ __forceinline__ constexpr uint64_t odd_lanes()
+{
+	return R == 0 ? 0xFFFFFFFF00000000ull : R == 1 ? 0xFFFF0000FFFF0000ull : R == 2 ? 0xFF00FF00FF00FF00ull
+		: R == 3 ? 0xF0F0F0F0F0F0F0F0ull : R == 4 ? 0xCCCCCCCCCCCCCCCCull : 0xAAAAAAAAAAAAAAAAull;
+}
+
+// one trellis step of residue R; returns the step's 64 decisions (bit = lane)
+template <int R> __device__ __forceinline__ uint64_t acs_step(uint32_t &metric, uint32_t sj, const VitLane &c)
+{
+	const uint32_t s0 = sj & 255u, s1 = sj >> 8;
+	const uint32_t bm = (c.t0[R] ^ s0) + (c.t1[R] ^ s1);
+	const uint32_t other = lane_xor<(32 >> R)>(metric);
+	const uint32_t cown = metric + bm, coth = other + (510u - bm);
+	const bool take_other = (int32_t)(cown - coth) + c.odd[R] > 0;
+	metric = take_other ? coth : cown;
+	return __ballot(take_other) ^ odd_lanes<R>();
+}
+
+// step J of a 60-step chunk: decisions parked in lane J of (wlo, whi)
+template <int J> __device__ __forceinline__ void chunk_step(uint32_t &metric, uint32_t &wlo, uint32_t &whi, uint32_t pair, const VitLane &c)
+{
+	const uint64_t word = acs_step<J % 6>(metric, (uint32_t)__builtin_amdgcn_readlane((int)pair, J), c);
+	wlo = write_lane<J>(wlo, (uint32_t)word);
+	whi = write_lane<J>(whi, (uint32_t)(word >> 32));
+}
+
+template <int... J> __device__ __forceinline__ void chunk_steps(uint32_t &metric, uint32_t &wlo, uint32_t &whi, uint32_t pair, const VitLane &c,
+		std::integer_sequence<int, J...>)
+{
+	(chunk_step<J>(metric, wlo, whi, pair, c), ...);
+}
+
+// chainback step J of a 48-step trip (wave-uniform values throughout): word of step = lane J of (wlo, whi)
+template <int J> __device__ __forceinline__ void chain_step(uint32_t wlo, uint32_t whi, uint32_t &pos, uint32_t &hi, uint32_t &lo)
+{
+	const uint64_t wj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wlo, J) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)whi, J) << 32);
+	const uint32_t k = (uint32_t)(wj >> pos) & 1u;
+	constexpr uint32_t B = 1u << (J % 6);
+	pos = k ? (pos | B) : (pos & ~B);
+	if (J < 16) hi = (hi << 1) | k; else lo = (lo << 1) | k;
+}
+
+template <int... J> __device__ __forceinline__ void chain_steps(uint32_t wlo, uint32_t whi, uint32_t &pos, uint32_t &hi, uint32_t &lo,
+		std::integer_sequence<int, J...>)
+{
+	(chain_step<J>(wlo, whi, pos, hi, lo), ...);
+}
+
+__device__ __forceinline__ uint32_t rotl6(uint32_t x, int k) { return k ? ((x << k) | (x >> (6 - k))) & 63u : x; }
+__device__ __forceinline__ uint32_t rotr6(uint32_t x, int k) { return k ? ((x >> k) | (x << (6 - k))) & 63u : x; }
+
+__host__ __device__ constexpr size_t viterbi_lds_bytes(int nbits) { return sizeof(uint64_t) * ((size_t)nbits + 8); }
+
+// vin = 2*nbits soft bytes (LDS or global); decw = viterbi_lds_bytes(nbits) of LDS.  out receives ceil(nbits/8) octets:
+// MSB-first as libfec leaves them, or bit-reversed (what dumphfdl dispatches).
+__device__ __forceinline__ void viterbi27_wave(const uint8_t *vin, int nbits, uint64_t *decw, uint8_t *out, bool reverse_bits)
 {
 	const int lane = threadIdx.x;
-	const int i = lane >> 1, odd = lane & 1;
-	const uint32_t t0 = parity_u32((2u * i) & 0x6d) ? 255u : 0u;
-	const uint32_t t1 = parity_u32((2u * i) & 0x4f) ? 255u : 0u;
-	uint32_t metric = lane == 0 ? 0u : 63u;           // init_viterbi27(vp, 0)
-	// 64 trellis steps per trip: every lane fetches the soft pair of one step, the serial loop then takes them with
-	// v_readlane (the step index is wave-uniform), so no memory latency sits on the add-compare-select chain
-	for (int base = 0; base < nbits; base += 64) {
-		const int tt = base + lane;
-		const uint32_t pair = tt < nbits ? ((uint32_t)vin[2 * tt] | ((uint32_t)vin[2 * tt + 1] << 8)) : 0u;
-		const int lim = nbits - base < 64 ? nbits - base : 64;
-		for (int j = 0; j < lim; j++) {
-			const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)pair, j);
-			const uint32_t s0 = sj & 255u, s1 = sj >> 8;
-			const uint32_t bm = (t0 ^ s0) + (t1 ^ s1);
-			const uint32_t lo = (uint32_t)__shfl((int)metric, i), hi = (uint32_t)__shfl((int)metric, i + 32);
-			const uint32_t a = lo + (odd ? 510u - bm : bm);
-			const uint32_t b = hi + (odd ? bm : 510u - bm);
-			const bool pick = (int32_t)(a - b) > 0;
-			metric = pick ? b : a;
-			const uint64_t word = __ballot(pick);
-			if (lane == 0) decw[base + j] = word;
-		}
+	VitLane c;
+#pragma unroll
+	for (int r = 0; r < 6; r++) {
+		const uint32_t n = rotl6((uint32_t)lane, (r + 1) % 6), i = n >> 1;      // new state held by this lane after a residue-r step
+		c.t0[r] = parity_u32((2u * i) & 0x6d) ? 255u : 0u;
+		c.t1[r] = parity_u32((2u * i) & 0x4f) ? 255u : 0u;
+		c.odd[r] = (lane >> (5 - r)) & 1;
 	}
+	uint32_t metric = lane == 0 ? 0u : 63u;           // init_viterbi27(vp, 0)
+#ifdef HFDL_VIT_DEBUG
+	const unsigned long long dbg0 = __builtin_amdgcn_s_memtime();
+#endif
+	// 60 trellis steps per trip: every lane fetches the soft pair of one step, the serial loop takes them with v_readlane
+	for (int base = 0; base < nbits; base += 60) {
+		const int tt = base + lane;
+		const uint32_t pair = (lane < 60 && tt < nbits) ? ((uint32_t)vin[2 * tt] | ((uint32_t)vin[2 * tt + 1] << 8)) : 0u;
+		const int lim = nbits - base < 60 ? nbits - base : 60;
+		uint32_t wlo = 0, whi = 0;
+		if (lim == 60) {                                 // every HFDL frame size is a multiple of 60
+			chunk_steps(metric, wlo, whi, pair, c, std::make_integer_sequence<int, 60>());
+		} else {                                         // ragged end of an arbitrary nbits: same steps, generic slot select
+#define HFDL_ACS(R) if (j + R < lim) { const uint64_t wd = acs_step<R>(metric, (uint32_t)__builtin_amdgcn_readlane((int)pair, j + R), c); \
+			if (lane == j + R) { wlo = (uint32_t)wd; whi = (uint32_t)(wd >> 32); } }
+			for (int j = 0; j < lim; j += 6) { HFDL_ACS(0) HFDL_ACS(1) HFDL_ACS(2) HFDL_ACS(3) HFDL_ACS(4) HFDL_ACS(5) }
+#undef HFDL_ACS
+		}
+		if (lane < lim) decw[base + lane] = ((uint64_t)whi << 32) | wlo;
+	}
+#ifdef HFDL_VIT_DEBUG
+	const unsigned long long dbg1 = __builtin_amdgcn_s_memtime();
+#endif
 	__syncthreads();
-	// chainback_viterbi27 with the "d += 6" offset (words past the end were never written: read as 0).  The state register is
-	// wave-uniform; 64 decision words per trip are fetched lane-parallel and picked with v_readlane.
-	uint32_t reg = 0;
-	for (int top = nbits - 1; top >= 0; top -= 64) {
-		const int mine = top - lane;
-		const uint64_t w = (mine >= 0 && mine + 6 < nbits) ? decw[mine + 6] : 0ull;
-		const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32);
-		const int lim = top + 1 < 64 ? top + 1 : 64;
-		for (int j = 0; j < lim; j++) {
-			const int idx = top - j;
-			const uint64_t wj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wlo, j)
-				| ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)whi, j) << 32);
-			const uint32_t k = (uint32_t)(wj >> (reg >> 2)) & 1u;
+	// chainback with the "d += 6" offset: bit idx comes from the word of step idx+6 (words past the end read as 0).  The
+	// decision of state s at step t sits in bit rotr6(s, (t+1) mod 6); that rotated state register `pos` changes in ONE bit per
+	// step (bit (6 - (t+1) mod 6) mod 6 takes the decoded bit), so it is never shifted or rotated.
+	const int noct = (nbits + 7) >> 3;
+	uint32_t pos = 0;
+	int idx = nbits - 1;
+	{	// head: single steps until idx = 47 (mod 48); covers a ragged top octet and any nbits
+		uint32_t reg = 0;
+		for (; idx >= 0 && idx % 48 != 47; idx--) {
+			const int tt = idx + 6;
+			uint64_t w = 0;
+			if (tt < nbits) w = decw[tt];
+			const uint32_t wl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w), wh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
+			const uint32_t k = (uint32_t)((((uint64_t)wh << 32) | wl) >> pos) & 1u;
+			const int b = (6 - (tt + 1) % 6) % 6;
+			pos = (pos & ~(1u << b)) | (k << b);
 			reg = (reg >> 1) | (k << 7);
 			if ((idx & 7) == 0 && lane == 0) out[idx >> 3] = reverse_bits ? (uint8_t)(__brev(reg) >> 24) : (uint8_t)reg;
 		}
 	}
+	// body: 48 steps per trip (a multiple of 6 and of 8: bit index and octet boundaries are compile-time), scalar code
+	for (; idx >= 47; idx -= 48) {
+		const int mine = idx - lane + 6;
+		const uint64_t w = (lane < 48 && mine < nbits) ? decw[mine] : 0ull;
+		uint32_t hi = 0, lo = 0;
+		chain_steps((uint32_t)w, (uint32_t)(w >> 32), pos, hi, lo, std::make_integer_sequence<int, 48>());
+		// bit n of (hi:lo) = decoded bit idx-47+n: octet L of the trip is byte L, already in dumphfdl's (bit-reversed) order
+		if (lane < 6) {
+			uint32_t v = (lane < 4 ? lo >> (8 * lane) : hi >> (8 * (lane - 4))) & 255u;
+			if (!reverse_bits) v = __brev(v) >> 24;
+			const int o = ((idx - 47) >> 3) + lane;
+			if (o < noct) out[o] = (uint8_t)v;
+		}
+	}
+#ifdef HFDL_VIT_DEBUG
+	if (lane == 0 && blockIdx.x == 0) printf("viterbi nbits %d forward %llu chainback %llu cycles\n", nbits, dbg1 - dbg0, (unsigned long long)__builtin_amdgcn_s_memtime() - dbg1);
+#endif
 }
 
 constexpr int K5_TABLE_BYTES = 15360;      // >= 168*30*3 coded bits, 256-aligned
@@ -186,7 +310,7 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 	uint8_t *table = lds;
 	uint8_t *vin = lds + K5_TABLE_BYTES;
 	uint64_t *decw = (uint64_t *)(lds + 2 * K5_TABLE_BYTES);
-	uint8_t *l_scr = lds + 2 * K5_TABLE_BYTES + sizeof(uint64_t) * (7560 + 8);       // 128 bytes
+	uint8_t *l_scr = lds + 2 * K5_TABLE_BYTES + viterbi_lds_bytes(7560);             // 128 bytes
 
 	const FrameRec fr = frames[f];
 	const ModeParams mp = mode_params(fr.mode);
@@ -297,7 +421,7 @@ static size_t demod_lds_bytes(int cap)
 	return b;
 }
 
-static size_t k5_lds_bytes() { return 2 * (size_t)K5_TABLE_BYTES + sizeof(uint64_t) * (7560 + 8) + 128; }
+static size_t k5_lds_bytes() { return 2 * (size_t)K5_TABLE_BYTES + viterbi_lds_bytes(7560) + 128; }
 
 static DevTables resolve_tables(const float *d_img, const DemodTables &h)
 {
@@ -488,7 +612,7 @@ void Demod::release()
 int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out)
 {
 	const size_t in_bytes = (size_t)nframes * 2 * nbits, out_bytes = (size_t)nframes * ((nbits + 7) / 8);
-	const size_t lds = sizeof(uint64_t) * ((size_t)nbits + 8);
+	const size_t lds = viterbi_lds_bytes(nbits);
 	if (lds > 160 * 1024) return HFDL_GPU_ERANGE;
 	DevBuf d_in, d_out;
 	D_TRY(d_in.alloc(in_bytes));
