@@ -228,3 +228,28 @@ def test_bench_traffic_plans():
             assert all(bl[i + 1]["t0"] > ends[i] for i in range(len(bl) - 1))
         modes = {b["mode"] for b in bursts}
         assert modes == (set(range(8)) if w.get("dense") else set(range(4)))
+
+
+def test_abi_argument_checks_need_no_device():
+    """Every front-end entry point rejects a NULL handle / NULL outputs with HFDL_GPU_EINVAL before touching HIP (the
+    reference ASSERTs its arguments: src/fft.c:31, src/hfdl.c:648); the error text is per calling thread."""
+    import ctypes as C
+    from dumphfdl_amd import frontend as F
+    L = F.load()
+    EINVAL = -1
+    n = C.c_int32(0)
+    buf = (F.Pdu * 4)()
+    assert L.hfdl_gpu_frontend_poll_pdus(None, buf, 4, C.byref(n)) == EINVAL
+    assert L.hfdl_gpu_frontend_poll_pdus_ready(None, buf, 4, C.byref(n), 1) == EINVAL
+    assert L.hfdl_gpu_frontend_counters(None, C.byref(F.FrontendCounters())) == EINVAL
+    assert L.hfdl_gpu_frontend_all_channel_stats(None, None, 0, C.byref(n)) == EINVAL
+    assert L.hfdl_gpu_frontend_channel_stats(None, 0, C.byref(F.ChannelStats())) == EINVAL
+    assert L.hfdl_gpu_frontend_push_block(None, None, 0, 0) == EINVAL
+    assert L.hfdl_gpu_frontend_push_block_raw(None, None, 0, 0, 0) == EINVAL
+    assert L.hfdl_gpu_frontend_sync(None) == EINVAL
+    assert L.hfdl_gpu_frontend_input_done(None) == EINVAL
+    assert L.hfdl_gpu_frontend_enable_taps(None, 0) == EINVAL
+    assert L.hfdl_gpu_frontend_reset_timers(None, 0) == EINVAL
+    assert b"null" in L.hfdl_gpu_last_error()
+    L.hfdl_gpu_frontend_destroy(None)                      # like free(NULL)
+    assert L.hfdl_gpu_frontend_stream(None) is None
