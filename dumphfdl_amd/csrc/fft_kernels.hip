@@ -7,6 +7,7 @@
 // LDS, runs an in-place radix-4 DIF (result bit-reversed, undone on the way out) and applies the
 // inter-pass twiddle while storing.  Global accesses are 128-byte runs (16 adjacent columns of cf32);
 // the overlap history and the fftshift are index remaps on the first load / last store, never a pass.
+#include <hip/hip_ext.h>
 #include "kernels.h"
 #include "fft_core.h"
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restric
 }
 
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
-		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay)
+		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay, hipEvent_t done)
 {
 	const int c1 = (p.n >> p.l1), c2 = p.r1 * p.r3, c3 = p.r1 * p.r2;
 	const dim3 g1((c1 + FFT_TILE - 1) / FFT_TILE), blk(FFT_THREADS);
@@ -144,7 +145,7 @@ void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh,
 	else hipLaunchKernelGGL(fft_pass1<SFMT_CF32>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
 	hipLaunchKernelGGL(fft_pass2, dim3((c2 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), l2, st,
 			work, p);
-	hipLaunchKernelGGL(fft_pass3, dim3((c3 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), (size_t)p.r3 * (FFT_TILE + 1) * sizeof(float2), st,
+	hipExtLaunchKernelGGL(fft_pass3, dim3((c3 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), (size_t)p.r3 * (FFT_TILE + 1) * sizeof(float2), st, nullptr, done, 0,
 			(const float2 *)work, out, p, shifted ? 1 : 0, lay);
 }
 

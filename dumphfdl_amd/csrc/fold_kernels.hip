@@ -10,6 +10,7 @@
 // issues 1 KiB dwordx4 runs; each spectrum value is loaded once and multiplied into both channels' tap streams.
 // blockIdx -> (column half, slice, pair): the dispatcher puts block b on XCD b mod 8, so every XCD's L2 only ever
 // sees 1/8 of the spectrum (two slices x one column half), shared by all channels.
+#include <hip/hip_ext.h>
 #include "kernels.h"
 #include "fft_core.h"
 
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel_generic(const float2
 	}
 }
 
-void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st)
+void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st,
+		hipEvent_t start, hipEvent_t stop)
 {
 	const dim3 block(FOLD_THREADS);
 	const size_t cs4 = (size_t)g.tap_chan_stride >> 1, rs4 = (size_t)g.tap_row_stride >> 1;     // in float4
@@ -147,9 +149,11 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 	const int pairs = g.nch / 2, odd = g.nch & 1;
 	// channel pairs first; an odd last channel gets its own single-channel launch
 #define FOLD_LAUNCH(U, CS, NC, GROUPS) do { \
-	if ((GROUPS) > 0) hipLaunchKernelGGL((fold_kernel<U, true, 1, CS, NC>), dim3((unsigned)((GROUPS) * g.slices * CS)), block, 0, st, \
+	if ((GROUPS) > 0) hipExtLaunchKernelGGL((fold_kernel<U, true, 1, CS, NC>), dim3((unsigned)((GROUPS) * g.slices * CS)), block, 0, st, \
+		start, odd ? nullptr : stop, 0, \
 		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, cs4, rs4, g.m, g.slices, g.rows_per_slice, 0); \
-	if (odd) hipLaunchKernelGGL((fold_kernel<U, true, 1, CS, 1>), dim3((unsigned)(g.slices * CS)), block, 0, st, \
+	if (odd) hipExtLaunchKernelGGL((fold_kernel<U, true, 1, CS, 1>), dim3((unsigned)(g.slices * CS)), block, 0, st, \
+		(GROUPS) > 0 ? nullptr : start, stop, 0, \
 		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, cs4, rs4, g.m, g.slices, g.rows_per_slice, g.nch - 1); } while (0)
 	// Variants measured on cfg3 (profiles/r01_experiments.md).  What pays: non-temporal tap loads (+7 %) and TWO channels per
 	// workgroup sharing every spectrum load (+14 %: halves the L2->L1 spectrum traffic, which equals the HBM tap traffic
@@ -164,7 +168,7 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 		default: break;
 		}
 	}
-	hipLaunchKernelGGL(fold_kernel_generic, dim3((unsigned)(g.nch * g.slices)), block, 0, st, taps, spectrum, partial, (size_t)g.tap_chan_stride, (size_t)g.tap_row_stride, g.m, g.slices, g.rows_per_slice);
+	hipExtLaunchKernelGGL(fold_kernel_generic, dim3((unsigned)(g.nch * g.slices)), block, 0, st, start, stop, 0, taps, spectrum, partial, (size_t)g.tap_chan_stride, (size_t)g.tap_row_stride, g.m, g.slices, g.rows_per_slice);
 #undef FOLD_LAUNCH
 }
 
@@ -243,13 +247,13 @@ __global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__
 }
 
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
-		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st)
+		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st, hipEvent_t done)
 {
 	int logm = 0;
 	while ((1 << logm) < g.m) logm++;
 	size_t lds = sizeof(float2) * ((size_t)g.m + (size_t)g.outs + 1);
 	if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)ifft_nco_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(IFFT_THREADS), lds, st, partial, cc, nco, tw_m, chan_out, out_count, g, logm);
+	hipExtLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(IFFT_THREADS), (unsigned)lds, st, nullptr, done, 0, partial, cc, nco, tw_m, chan_out, out_count, g, logm);
 }
 
 }  // namespace hfdl

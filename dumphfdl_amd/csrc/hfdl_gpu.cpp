@@ -405,10 +405,14 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 {
 	const Geometry &g = fe->geo;
 	const int buf = (int)(fe->blocks & 1);
-	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->d_spec, true, fe->stream);
-	if (fe->pending_demod_buf >= 0) {
-		if (!fe->ev_fft) HIP_TRY(hipEventCreateWithFlags(&fe->ev_fft, hipEventDisableTiming));
-		HIP_TRY(hipEventRecord(fe->ev_fft, fe->stream));
+	// The events other streams (and the bench's fold timer) wait for ride on the kernel dispatches themselves
+	// (hipExtLaunchKernelGGL start / stop events): a separate hipEventRecord is one more barrier packet in the queue, ~5 us
+	// of idle machine each (profiles/r01_experiments.md).
+	const bool pend = fe->pending_demod_buf >= 0;
+	if (pend && !fe->ev_fft) HIP_TRY(hipEventCreateWithFlags(&fe->ev_fft, hipEventDisableTiming));
+	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->d_spec, true, fe->stream,
+			FftOutLayout(), pend ? fe->ev_fft : nullptr);
+	if (pend) {
 		int rc = flush_pending_demod(fe, true);
 		if (rc) return rc;
 	}
@@ -417,17 +421,14 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 		std::pair<hipEvent_t, hipEvent_t> e;
 		HIP_TRY(hipEventCreate(&e.first));
 		HIP_TRY(hipEventCreate(&e.second));
-		HIP_TRY(hipEventRecord(e.first, fe->stream));
-		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
-		HIP_TRY(hipEventRecord(e.second, fe->stream));
+		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream, e.first, e.second);
 		fe->ev.push_back(e);
 	} else {
 		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
 	}
 	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_demod[buf], 0));       // chan_out[buf] is free once demod(k-2) has read it
-	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_tw_m, fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream);
+	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_tw_m, fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream, fe->ev_chan[buf]);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(fe->ev_chan[buf], fe->stream));
 	fe->blocks++;
 	fe->last_buf = buf;
 	if (buf_out) *buf_out = buf;

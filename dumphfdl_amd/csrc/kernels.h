@@ -56,10 +56,12 @@ enum { SFMT_CF32 = 0, SFMT_CS16 = 1, SFMT_CU8 = 2 };
 // output index i of the transform is stored at (i >> row_log) * row_stride + (i & (2^row_log - 1)); row_log = 0: contiguous
 struct FftOutLayout { int row_log = 0; int64_t row_stride = 0; };
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
-		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay = FftOutLayout());
-void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st);
+		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay = FftOutLayout(), hipEvent_t done = nullptr);
+// optional events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL): no separate barrier packets in the queue
+void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st,
+		hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
-		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st);
+		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st, hipEvent_t done = nullptr);
 int stream_read_variants();
 void launch_stream_read(int variant, const float2 *src, size_t bytes, float *sink, hipStream_t st);
 
