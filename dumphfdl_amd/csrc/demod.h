@@ -17,9 +17,10 @@ struct Demod {
 	ChanState *d_states = nullptr;
 	float2 *d_data = nullptr;               // [nch][2][5040] equalised data symbols
 	FrameRec *d_frames = nullptr;
-	int *d_counts = nullptr;                // [0] frames queued this block, [1] pdus produced, [2] pdus dropped, [3] pdus taken by the host
+	int *d_counts = nullptr;                // [1] pdus produced, [2] pdus dropped, [3] pdus taken by the host, [4],[5] frames queued (even / odd block)
 	int *h_snap = nullptr;                  // pinned [2][4]: d_counts as of the end of the block that used buffer 0 / 1
 	uint32_t taken = 0, dropped = 0;
+	uint64_t launches = 0;
 	hfdl_gpu_pdu *d_pdus = nullptr;
 	int32_t *d_freqs = nullptr;
 	int pdu_cap = 0;

@@ -29,6 +29,7 @@ struct DemodBuffers {
 	cf *data;
 	FrameRec *frames;
 	int *counts;
+	int *frame_count;           // this block's frames-queued counter (two, used alternately: see Demod::enqueue_block)
 	int frame_cap;
 	cf *tap_rs, *tap_mf, *tap_sym;
 	float *tap_lvl;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(64, 5) void demod_kernel(DevTables T, DemodBuffers 
 	BlockIo io;
 	io.rs = rs; io.agc = agc; io.mf = mf; io.lvl = lvl; io.cap = B.cap;
 	io.data = B.data + (size_t)c * 2 * MAX_DATA_SYMBOLS;
-	io.frames = B.frames; io.frame_count = B.counts; io.frame_cap = B.frame_cap;
+	io.frames = B.frames; io.frame_count = B.frame_count; io.frame_cap = B.frame_cap;
 	io.channel = c;
 	if (B.tap_rs) {
 		io.tap_resampled = B.tap_rs + (size_t)c * B.cap; io.tap_mf = B.tap_mf + (size_t)c * B.cap;
@@ -298,13 +299,14 @@ __device__ __forceinline__ void viterbi27_wave(const uint8_t *vin, int nbits, ui
 
 constexpr int K5_TABLE_BYTES = 15360;      // >= 168*30*3 coded bits, 256-aligned
 
-__global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__restrict__ frames, int *counts, int frame_cap,
+__global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__restrict__ frames, int *counts, const int *nframes_ptr, int *stale_count, int frame_cap,
 		const cf *__restrict__ data_all, const uint8_t *__restrict__ scrambler, const int32_t *__restrict__ freqs,
 		hfdl_gpu_pdu *__restrict__ pdus, int pdu_cap)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const int f = blockIdx.x, lane = threadIdx.x;
-	int nframes = counts[0];
+	int nframes = *nframes_ptr;
+	if (f == 0 && lane == 0 && stale_count) *stale_count = 0;      // the other block's counter: its decoder finished before this launch began
 	if (nframes > frame_cap) nframes = frame_cap;
 	if (f >= nframes) return;
 	uint8_t *table = lds;
@@ -471,8 +473,8 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	D_TRY(hipMalloc(&d_data, sizeof(float2) * (size_t)nch * 2 * MAX_DATA_SYMBOLS));
 	D_TRY(hipMemsetAsync(d_data, 0, sizeof(float2) * (size_t)nch * 2 * MAX_DATA_SYMBOLS, st));
 	D_TRY(hipMalloc(&d_frames, sizeof(FrameRec) * (size_t)nch));
-	D_TRY(hipMalloc(&d_counts, sizeof(int) * 4));
-	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int) * 4, st));
+	D_TRY(hipMalloc(&d_counts, sizeof(int) * 8));
+	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int) * 8, st));
 	D_TRY(hipHostMalloc((void **)&h_snap, sizeof(int) * 8, hipHostMallocDefault));
 	std::memset(h_snap, 0, sizeof(int) * 8);
 	taken = 0; dropped = 0;
@@ -505,14 +507,17 @@ int Demod::enqueue_block(const float2 *chan_out, const int *out_count, int buf, 
 	DemodPriv *pv = priv_of(this);
 	if (!pv) return HFDL_GPU_EINVAL;
 	DemodBuffers B;
-	B.states = d_states; B.data = (cf *)d_data; B.frames = d_frames; B.counts = d_counts; B.frame_cap = nch;
+	// frames queued by the demodulator of this block: counter 4 + parity; the burst decoder of this block zeroes the OTHER
+	// one (consumed by the previous block's decoder, next used by the next block's demodulator) -- no memset launch per block
+	const int par = (int)(launches++ & 1);      // alternates per demodulator launch (not per block: channelize-only blocks launch none)
+	int *fc = d_counts + 4 + par, *fc_other = d_counts + 4 + (par ^ 1);
+	B.states = d_states; B.data = (cf *)d_data; B.frames = d_frames; B.counts = d_counts; B.frame_count = fc; B.frame_cap = nch;
 	const bool tw = taps_on && taps_enabled;
 	B.tap_rs = tw ? (cf *)d_tap_rs : nullptr; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
 	B.cap = cap;
 	hipLaunchKernelGGL(demod_kernel, dim3((unsigned)nch), dim3(64), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
-	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)d_frames, d_counts, nch,
+	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)d_frames, d_counts, fc, fc_other, nch,
 			(const cf *)d_data, pv->t.scrambler, (const int32_t *)d_freqs, d_pdus, pdu_cap);
-	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int), st));
 	// what the ring holds once this block is done, for a host that collects without draining the pipeline
 	D_TRY(hipMemcpyAsync(h_snap + 4 * (buf & 1), d_counts, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
 	D_TRY(hipGetLastError());
@@ -649,7 +654,7 @@ int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const i
 		f.sample_index = (uint64_t)i;
 	}
 	DevBuf d_scr, d_fr, d_data, d_counts, d_freqs, d_pdus;
-	int counts[4] = { nframes, 0, 0, 0 };
+	int counts[8] = { 0, 0, 0, 0, nframes, 0, 0, 0 };
 	D_TRY(d_scr.alloc(128));
 	D_TRY(hipMemcpy(d_scr.p, h.scrambler, 120, hipMemcpyHostToDevice));
 	D_TRY(d_fr.alloc(sizeof(FrameRec) * fr.size()));
@@ -663,7 +668,7 @@ int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const i
 	D_TRY(d_pdus.alloc(sizeof(hfdl_gpu_pdu) * (size_t)nframes));
 	int rc = set_big_lds((const void *)burst_decode_kernel, k5_lds_bytes());
 	if (rc) return rc;
-	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nframes), dim3(64), k5_lds_bytes(), nullptr, d_fr.as<const FrameRec>(), d_counts.as<int>(),
+	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nframes), dim3(64), k5_lds_bytes(), nullptr, d_fr.as<const FrameRec>(), d_counts.as<int>(), d_counts.as<int>() + 4, (int *)nullptr,
 			nframes, d_data.as<const cf>(), d_scr.as<const uint8_t>(), d_freqs.as<const int32_t>(), d_pdus.as<hfdl_gpu_pdu>(), nframes);
 	D_TRY(hipDeviceSynchronize());
 	D_TRY(hipGetLastError());

@@ -383,8 +383,9 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 // evenly, and the fold time is the good one every time.  A sync / poll launches a held-back demodulator at once.
 static int launch_demod(hfdl_gpu_frontend *fe, int buf, bool after_fft)
 {
+	// the forward FFT of the next block follows this block's inverse FFT on stream A, so its event covers ev_chan too
 	if (after_fft) HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_fft, 0));
-	HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
+	else HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
 	int rc = fe->demod.enqueue_block(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b);
 	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_b));
