@@ -599,6 +599,7 @@ def test_host_c_program_live_pipe(gpu, oracle):
         proc.stdin.write(raw[off:off + step])
         proc.stdin.flush()
         time.sleep(0.03)
+    time.sleep(2.2)                                     # source idle, program still running: the 1 s gauge thread reports the settled values
     proc.stdin.close()
     out = proc.stdout.read().decode()
     err = proc.stderr.read().decode()
