@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- wideband I/Q Msamples/s (+ HFDL frames/s) of the MI355X HFDL front end at a fixed channel count.
 
-  python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg4]
+  python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg4] [--shard streams|channels]
 
 One "step" = one block of `input_size` wideband cf32 samples through the WHOLE hot path: overlap assembly, forward
 FFT, per-channel fold + inverse FFT + NCO (fastddc), per-channel demodulator, burst decoder, PDU read-back.
-The synthetic input is resident in HBM before the timed region.  For N > 1 the driver launches one rank per GPU;
-every rank owns an independent wideband stream with the same channel count (BASELINE.json config 5, channels /
-streams sharded, no data-path collective); `value` is the whole-job aggregate.
+`value` is measured with the synthetic input resident in HBM before the timed region.  For N > 1 the driver launches one
+rank per GPU; with --shard streams (default) every rank owns an independent wideband stream with the same channel count
+(BASELINE.json configs[4], weak scaling); with --shard channels all ranks ingest the SAME stream and each decodes a
+round-robin subset of its channels (SURVEY.md 8e, strong scaling).  No data-path collective either way.
 
 The JSON line carries, next to the driver's contract fields:
-  roofline      the fold kernel (spectrum x per-channel filter, >99% of the block's algorithmic bytes), timed with
-                HIP events on the front end's own stream; bytes = SURVEY.md section 8(d) canonical model
-  cpu_baseline  the plain-C oracle (a restatement -- FFTW / liquid-dsp are not installable here) timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+  roofline        the fold kernel (spectrum x per-channel filter, >99% of the block's algorithmic bytes), timed with
+                  HIP events on the front end's own stream; bytes = SURVEY.md section 8(d) canonical model
+  host_ram_input  the same workload fed from page-locked HOST memory (SURVEY.md 8(d) "input pre-loaded in host RAM"):
+                  PCIe-inclusive, never `value`
+  host_path       the same workload through the C host library (file input -> block graph -> GPU front end ->
+                  pdu_decoder_queue_push), i.e. what a dumphfdl user gets (dumphfdl_amd/hfdl_replay --bench)
+  fec             trellis steps/s: demanded by the run, and the burst decoder's own capacity on a resident batch
+  parity          same-run gate: the channels the CPU baseline decodes, decoded by the GPU from the same blocks --
+                  channelizer error RMS / signal RMS and the (freq, sample_index, mode, octets) multisets
+  cpu_baseline    the plain-C oracle built with the reference's release flags, timed on this box's host cores on a
+                  bounded sample of the same workload (rank 0, N = 1 only)
 """
 import argparse
+import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,6 +48,7 @@ WORKLOADS = {
                  name="8 Msps cf32, 32 HFDL channels (BASELINE.json configs[1])"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+NBITS = [540, 1080, 2160, 3240, 1260, 2520, 5040, 7560]      # decoded bits = trellis steps per frame, mode 0..7 (src/hfdl.c:81-138)
 
 
 def channel_plan(w):
@@ -45,11 +56,11 @@ def channel_plan(w):
     return [int(cf + (i - nch // 2) * grid + grid // 2 - 1440) for i in range(nch)]
 
 
-def make_input(w, geom_input_size, rank, world):
+def make_input(w, geom_input_size, rank, world, shard_mode="streams"):
     """Seeded synthetic wideband stream: one single-slot burst per channel (modes cycle 300/600/1200/1800 bps) + AWGN."""
     from dumphfdl_amd import synth
     from dumphfdl_amd import shard
-    seed = shard.stream_seed(w["seed"], rank, world)
+    seed = shard.stream_seed(w["seed"], rank, world) if shard_mode == "streams" else w["seed"]
     nsamp = w["blocks"] * geom_input_size
     cache = "/tmp/hfdl_bench_%s_seed%d_%d%s.npy" % (w["fs"], seed, nsamp, "_dense" if w.get("dense") else "")
     freqs = channel_plan(w)
@@ -61,7 +72,9 @@ def make_input(w, geom_input_size, rank, world):
             return np.ascontiguousarray(x), bursts
     x = synth.synth_wideband(w["fs"], w["centerfreq"], nsamp, bursts, noise_sigma=w["noise"], seed=seed)
     try:
-        np.save(cache, x)
+        tmp = cache + ".%d.tmp.npy" % os.getpid()
+        np.save(tmp, x)
+        os.replace(tmp, cache)
     except OSError:
         pass
     return x, bursts
@@ -97,10 +110,91 @@ def plan_bursts(w, freqs, dur, seed):
     return bursts
 
 
-def cpu_baseline(w, x, input_size, target_seconds=20.0):
-    """Time the oracle (plain-C restatement of the reference path, one worker thread per channel like the reference)
-    on this host: C_s channels of the same geometry, a few blocks; scale the per-channel part to the full channel count."""
+def pdu_key(p):
+    return (p["freq"], p["sample_index"], p["mode"], p["octets"].hex())
+
+
+def matches_sent(p, bursts_by_freq):
+    return any(p["octets"][:len(b["octets"])] == b["octets"] and p["mode"] == b["mode"] for b in bursts_by_freq.get(p["freq"], ()))
+
+
+def probe_cpu_libs():
+    """say whether the reference's CPU libraries exist on this box (src/fft_fftw.c:22-41 binds FFTW3f)."""
+    found = {}
+    for key, names in (("fftw3f", ("libfftw3f.so.3", "libfftw3f.so")), ("liquid", ("libliquid.so", "libliquid.so.1"))):
+        found[key] = None
+        for n in names:
+            try:
+                ctypes.CDLL(n)
+                found[key] = n
+                break
+            except OSError:
+                continue
+    return found
+
+
+def fftw_forward_seconds(n, name, reps=3):
+    """csdr_make_fft_c2c + csdr_fft_execute as the reference drives FFTW (src/fft_fftw.c:22-41): FFTW_ESTIMATE plan, 1 thread."""
+    L = ctypes.CDLL(name)
+    L.fftwf_plan_dft_1d.restype = ctypes.c_void_p
+    L.fftwf_plan_dft_1d.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint]
+    L.fftwf_execute.argtypes = [ctypes.c_void_p]
+    L.fftwf_destroy_plan.argtypes = [ctypes.c_void_p]
+    a = (np.random.default_rng(0).standard_normal(2 * n).astype(np.float32)).view(np.complex64)
+    b = np.empty_like(a)
+    plan = L.fftwf_plan_dft_1d(n, a.ctypes.data, b.ctypes.data, -1, 1 << 6)      # FFTW_FORWARD, FFTW_ESTIMATE
+    L.fftwf_execute(plan)
+    t0 = time.time()
+    for _ in range(reps):
+        L.fftwf_execute(plan)
+    dt = (time.time() - t0) / reps
+    L.fftwf_destroy_plan(plan)
+    return dt
+
+
+def parity_gate(w, x, input_size, hf, dev_index, cores, max_seconds=25.0):
+    """Same-run parity: the channel subset the CPU baseline decodes, pushed through a fresh GPU front end
+    and through the strict oracle block by block from the start of the stream.  Returns the measured channelizer error and
+    whether the decoded PDU multisets are identical."""
     from oracle import pyoracle
+    from dumphfdl_amd import frontend as F
+    pyoracle.select_build("strict")
+    freqs = channel_plan(w)
+    cs = min(len(freqs), cores)
+    sel = freqs[:: max(1, len(freqs) // cs)][:cs]
+    ora = pyoracle.Frontend(w["fs"], w["centerfreq"], sel, nthreads=cores)
+    fe = hf.Frontend(w["fs"], w["centerfreq"], sel, device=dev_index)
+    fe.enable_taps(False)
+    nblk_max = len(x) // input_size
+    t0, nblk, worst = time.time(), 0, 0.0
+    check = sorted(set([0, cs // 2, cs - 1]))
+    while nblk < nblk_max and (nblk < 2 or time.time() - t0 < max_seconds):
+        blk = np.ascontiguousarray(x[nblk * input_size:(nblk + 1) * input_size])
+        fe.push_block(blk)
+        ora.push_block(blk, nthreads=cores)
+        if nblk in (0, 1) or nblk % 5 == 0:
+            for c in check:
+                a = fe.read_tap(F.TAP_CHAN_OUT, c).astype(np.complex128)
+                b = ora.channel_view(c)["chan_out"].astype(np.complex128)
+                worst = max(worst, float(np.sqrt(np.mean(np.abs(a - b) ** 2) / max(np.mean(np.abs(b) ** 2), 1e-300))))
+        nblk += 1
+    got = sorted(pdu_key(p) for p in fe.poll_pdus(16384))
+    want = sorted(pdu_key(p) for p in ora.pdus)
+    fe.close()
+    ora.close()
+    return dict(channels=cs, blocks=nblk, oracle_build="strict (-O3 -ffp-contract=off, no fast-math; bit-pinned parts see tests/golden)",
+                chan_out_rel_rms=worst, chan_out_rel_rms_limit=1e-4, chan_out_within_limit=bool(worst <= 1e-4),
+                gpu_pdus=len(got), cpu_pdus=len(want), pdu_multisets_identical=bool(got == want),
+                compared="(freq, sample_index, mode, octets) of every PDU both sides dispatched on these channels and blocks")
+
+
+def cpu_baseline(w, x, input_size, target_seconds=20.0):
+    """Time the oracle (plain-C restatement of the reference path, one worker thread per channel like the reference, built
+    with the reference's release flags) on this host: C_s channels of the same geometry, a few blocks; the per-channel part
+    is scaled to the full channel count."""
+    from oracle import pyoracle
+    libs = probe_cpu_libs()
+    pyoracle.select_build("fast")
     cores = max(1, min(os.cpu_count() or 1, 64))
     freqs = channel_plan(w)
     cs = min(len(freqs), cores)
@@ -112,7 +206,7 @@ def cpu_baseline(w, x, input_size, target_seconds=20.0):
     fe.push_block(x[:input_size], nthreads=cores)
     nblk, t_all, t_fft = 0, 0.0, 0.0
     L = pyoracle.lib()
-    import ctypes as C
+    C = ctypes
     spec = np.empty(fe.ddc.fft_size, np.complex64)
     buf = np.zeros(fe.ddc.fft_size, np.complex64)
     while nblk < 2 or (t_all < target_seconds / 2 and nblk < w["blocks"] - 1):
@@ -126,27 +220,105 @@ def cpu_baseline(w, x, input_size, target_seconds=20.0):
         nblk += 1
     per_blk, fft_blk = t_all / nblk, t_fft / nblk
     chan_blk = max(per_blk - fft_blk, 1e-9)          # cs channels on `cores` threads
-    full = fft_blk + chan_blk * (len(freqs) / cs)
+    fft_used, fft_kind = fft_blk, "oracle radix-4 FFT, 1 thread"
+    if libs["fftw3f"]:
+        try:
+            fft_used, fft_kind = fftw_forward_seconds(fe.ddc.fft_size, libs["fftw3f"]), "FFTW3f (%s), FFTW_ESTIMATE, 1 thread" % libs["fftw3f"]
+        except Exception as e:            # the probe is best effort: the restated FFT stays the fallback
+            fft_kind += " (FFTW found but unusable: %s)" % e
+    full = fft_used + chan_blk * (len(freqs) / cs)
     frames = len(fe.pdus)
+    fft_size = fe.ddc.fft_size
     fe.close()
+    pyoracle.select_build("strict")
     return dict(value=input_size / full / 1e6, unit="Msamples/s", cores=cores, kind="port",
-                sample="oracle (C restatement; FFTW/liquid-dsp binaries unavailable): %d of %d channels x %d blocks of %d samples on %d "
-                       "threads, %.2f s/block measured (forward FFT %.2f s), channel part scaled x%.1f to %d channels; init %.1f s untimed; %d PDUs"
-                       % (cs, len(freqs), nblk, input_size, cores, per_blk, fft_blk, len(freqs) / cs, len(freqs), t_init, frames))
+                fftw_found=libs["fftw3f"], liquid_found=libs["liquid"],
+                build="gcc -O3 -DNDEBUG -ffast-math (the reference's cmake Release flags, CMakeLists.txt:12-15, src/CMakeLists.txt:39-42)",
+                forward_fft="%s: %.3f s per %d-point block -- the shared forward FFT is single-threaded and DOMINATES the CPU block time "
+                            "(FFT-bound); the per-channel part runs on all threads" % (fft_kind, fft_used, fft_size),
+                sample="oracle (C restatement; dlopen probe: FFTW3f %s, liquid-dsp %s): %d of %d channels x %d blocks of %d samples on %d "
+                       "threads, %.3f s/block measured (forward FFT %.3f s on 1 thread, channel part %.3f s), channel part scaled x%.1f to %d channels; "
+                       "init %.1f s untimed; %d PDUs decoded in the sample"
+                       % ("found" if libs["fftw3f"] else "not found", "found" if libs["liquid"] else "not found",
+                          cs, len(freqs), nblk, input_size, cores, per_blk, fft_blk, chan_blk, len(freqs) / cs, len(freqs), t_init, frames))
+
+
+def fec_capacity(hf, dev_index):
+    """The burst decoder on its own: a resident batch of the longest frames (mode 7: 7560 trellis steps, 15120 coded bits),
+    one wavefront per frame, kernel time from HIP events (libfec work unit: src/libfec/viterbi27_port.c:166-221)."""
+    from dumphfdl_amd import frontend as F
+    rng = np.random.default_rng(1)
+    nframes, nbits = 1024, 7560
+    soft = rng.integers(0, 256, (nframes, 2 * nbits), dtype=np.uint8)
+    hf.viterbi27(soft[:8], nbits, device=dev_index)            # first launch: code load, LDS attribute
+    hf.viterbi27(soft, nbits, device=dev_index)
+    ms = F.last_stage_ms()
+    out = dict(viterbi_kernel_frames=nframes, viterbi_kernel_ms=ms,
+               viterbi_kernel_trellis_steps_per_s=(nframes * nbits / (ms * 1e-3)) if ms > 0 else None,
+               viterbi_kernel_acs_per_s=(nframes * nbits * 64 / (ms * 1e-3)) if ms > 0 else None)
+    return out
+
+
+def host_path_leg(w, x, freqs, fmt="CF32", dev_index=0, seconds_cap=120):
+    """The C host library end to end (what a dumphfdl user runs): a raw I/Q file in page cache -> file input -> block graph
+    -> GPU front-end block -> pdu_decoder_queue_push.  hfdl_replay --bench prints one JSON object with its own clock."""
+    exe = os.path.join(ROOT, "dumphfdl_amd", "hfdl_replay")
+    if not os.path.exists(exe):
+        return dict(error="dumphfdl_amd/hfdl_replay not built")
+    path = "/dev/shm/hfdl_bench_%d.%s" % (os.getpid(), fmt.lower())
+    try:
+        if fmt == "CS16":
+            np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16).tofile(path)
+        else:
+            x.view(np.float32).tofile(path)
+        cmd = [exe, "--bench", "--iq-file", path, "--sample-rate", str(w["fs"]), "--sample-format", fmt, "--device", str(dev_index),
+               "--centerfreq", "%.3f" % (w["centerfreq"] / 1e3)] + ["%.3f" % (f / 1e3) for f in freqs]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=seconds_cap)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not line:
+            return dict(error="hfdl_replay --bench failed (rc %d): %s" % (out.returncode, out.stderr[-300:]))
+        r = json.loads(line[-1])
+        r["sample_format"] = fmt
+        return r
+    except Exception as e:
+        return dict(error=str(e))
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+
+def traffic_record(workload):
+    """HBM bytes per fold launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs, corrected as the
+    MI355X guide prescribes): a bench run cannot collect counters itself, so the line names where the figure comes from."""
+    tfile = os.path.join(ROOT, "profiles", "fold_traffic_%s.json" % workload)
+    if not os.path.exists(tfile):
+        return None, None
+    try:
+        t = json.load(open(tfile))
+        return t.get("hbm_bytes_per_launch"), dict(file="profiles/fold_traffic_%s.json" % workload, measured_at_commit=t.get("measured_at_commit"),
+                                                  collected_by=t.get("command"), note="replayed from that file, not observed by this run")
+    except Exception:
+        return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256, help="timed blocks (one step = one block of input_size samples through the whole path); 256 blocks of the 40 Msps geometry = 0.75 s, so pipeline fill and drain stay below 1 %")
+    ap.add_argument("--steps", type=int, default=256, help="timed blocks (one step = one block of input_size samples through the whole path); 256 blocks of the 40 Msps geometry = 0.75 s")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and the same-run parity gate")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip host_ram_input / host_path / fec (profiling runs)")
     ap.add_argument("--host-input", action="store_true",
-                    help="feed the blocks from page-locked HOST memory (PCIe-inclusive rate; never the headline value)")
+                    help="feed the TIMED blocks from page-locked HOST memory (PCIe-inclusive rate; then `value` is not the headline figure)")
     ap.add_argument("--sample-format", default="cf32", choices=["cf32", "cs16"], help="with --host-input: raw format pushed over PCIe")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / final reduction at N > 1 (nccl = RCCL; gloo for a 1-GPU smoke of the N>1 path)")
+    ap.add_argument("--shard", default="streams", choices=["streams", "channels"],
+                    help="N > 1: independent stream per rank (weak scaling, BASELINE configs[4]) or ONE stream with its channels split round-robin over the ranks (strong scaling, SURVEY 8e)")
+    ap.add_argument("--dump-pdus", default=None, help="write this rank's PDU keys (freq, sample_index, mode, octets) to PATH.rankR.json")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
 
@@ -167,21 +339,27 @@ def main():
             dist.init_process_group("gloo")
             red_device = "cpu"
     import dumphfdl_amd as hf
+    from dumphfdl_amd import shard
+    from dumphfdl_amd import frontend as F
 
-    freqs = channel_plan(w)
+    all_freqs = channel_plan(w)
+    freqs = shard.shard_channels(all_freqs, rank, world) if args.shard == "channels" else all_freqs
     t0 = time.time()
     fe = hf.Frontend(w["fs"], w["centerfreq"], freqs, device=dev_index)
     g = fe.geometry
     fe.enable_taps(False)            # per-stage debug taps (DATADUMPS analogue) are a test facility, not part of the path
     t_create = time.time() - t0
     t0 = time.time()
-    x, bursts = make_input(w, g.input_size, rank, world)
+    x, bursts = make_input(w, g.input_size, rank, world, args.shard)
+    my_seed = shard.stream_seed(w["seed"], rank, world) if args.shard == "streams" else w["seed"]
     t_gen = time.time() - t0
     nblocks = len(x) // g.input_size
-    if args.host_input:
-        import ctypes
-        from dumphfdl_amd import frontend as F
-        if args.sample_format == "cs16":
+    bursts_by_freq = {}
+    for b in bursts:
+        bursts_by_freq.setdefault(b["freq"], []).append(b)
+
+    def host_feed(fmt_name):
+        if fmt_name == "cs16":
             raw = np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16)
             fmt, bps = F.SFMT_CS16, 4
         else:
@@ -189,7 +367,11 @@ def main():
         hbuf = hf.host_alloc(raw.nbytes)
         ctypes.memmove(hbuf, raw.ctypes.data, raw.nbytes)
         hptrs = [hbuf + bps * b * g.input_size for b in range(nblocks)]
-        push = lambda i: fe.push_host_ptr(hptrs[i], fmt)
+        return hbuf, (lambda i: fe.push_host_ptr(hptrs[i], fmt))
+
+    hbuf = None
+    if args.host_input:
+        hbuf, push = host_feed(args.sample_format)
         dev = None
     else:
         dev = torch.from_numpy(x.view(np.float32)).cuda()          # resident in HBM before the timed region
@@ -202,69 +384,111 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_run(push_fn, steps, first_step):
+        step = first_step
+        raw = []
+        t_start = time.perf_counter()
+        for i in range(steps):
+            push_fn(step % nblocks); step += 1
+            if i % 256 == 255 and i + 1 < steps:      # long runs: empty the device PDU ring now and then, pipeline kept running
+                raw.append(fe.poll_pdus_raw(16384, max_in_flight=1))
+        raw.append(fe.poll_pdus_raw(16384))     # sync + device->host of every PDU struct produced by the timed blocks (what the C host gets)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t_start, raw, step
+
     step = 0
     for _ in range(args.warmup):
         push(step % nblocks); step += 1
     fe.poll_pdus()
     fe.reset_timers(True)
     barrier()
-    t0 = time.perf_counter()
-    raw = []
-    for i in range(args.steps):
-        push(step % nblocks); step += 1
-        if i % 256 == 255 and i + 1 < args.steps:      # long runs: empty the device PDU ring now and then, pipeline kept running
-            raw.append(fe.poll_pdus_raw(16384, max_in_flight=1))
-    raw.append(fe.poll_pdus_raw(16384))     # sync + device->host of every PDU struct produced by the timed blocks (what the C host gets)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, raw, step = timed_run(push, args.steps, step)
     pdus = [p for buf, n in raw for p in fe.pdus_to_dicts(buf, n)]     # Python-side unpacking for the checks below: not part of the path
     npdus = len(pdus)
     fold_ms, fold_n = fe.fold_time_ms()
-    stream_gbs = fe.stream_read_probe() if rank == 0 else None       # after the timed region: the board's own read ceiling
+    period_ms = fe.step_period_ms()
     barrier()
-    from dumphfdl_amd import shard
-    elapsed_max, total_samples, total_pdus = shard.reduce_job(elapsed, args.steps * g.input_size, npdus, dist, device=red_device)
+    good = sum(1 for p in pdus if matches_sent(p, bursts_by_freq))
+    trellis = sum(NBITS[p["mode"]] for p in pdus)
+    my_samples = args.steps * g.input_size
+    if args.shard == "channels" and rank != 0:
+        my_samples = 0                               # ONE stream: its samples count once
+    elapsed_max, total_samples, total_pdus = shard.reduce_job(elapsed, my_samples, npdus, dist, device=red_device)
+    total_good, total_trellis = shard.reduce_sums([good, trellis], dist, device=red_device)
+    seeds = shard.gather_ints(my_seed, dist, device=red_device)
+    if args.dump_pdus:
+        json.dump(sorted(pdu_key(p) for p in pdus), open("%s.rank%d.json" % (args.dump_pdus, rank), "w"))
+
+    # ---- extra legs (untimed with respect to `value`; rank 0 at N = 1)
+    extra = {}
+    solo = world == 1 and rank == 0
+    if solo and not args.no_extra_legs and not args.host_input:
+        hbuf, hpush = host_feed("cf32")
+        k2 = min(args.steps, 96)
+        for i in range(4):
+            hpush(i % nblocks)
+        fe.poll_pdus()
+        el2, raw2, _ = timed_run(hpush, k2, 4)
+        extra["host_ram_input"] = dict(value=k2 * g.input_size / el2 / 1e6, unit="Msamples/s", steps=k2, ms_per_step=el2 / k2 * 1e3,
+                                       path="cf32 blocks in page-locked host RAM -> hfdl_gpu_frontend_push_block (copy stream, two HBM staging "
+                                            "buffers) -> same kernels; PCIe-inclusive",
+                                       pcie_GBs=k2 * g.input_size * 8 / el2 / 1e9, pdus=sum(n for _, n in raw2))
+    stream_gbs = fe.stream_read_probe() if rank == 0 else None       # after the timed regions: the board's own read ceiling
+    if solo and not args.no_extra_legs:
+        extra["fec"] = fec_capacity(hf, dev_index)
 
     if rank == 0:
-        good = sum(1 for p in pdus if any(p["octets"][:len(b["octets"])] == b["octets"] for b in bursts if b["freq"] == p["freq"]))
         samples = total_samples
         # B = 8*input_size + C*8*N + C*8*(post_input_size/post_decimation) algorithmic bytes per block
         alg_bytes = 8 * g.input_size + g.channels * 8 * g.fft_size + g.channels * 8 * (g.post_input_size // g.post_decimation)
         fold_avg_ms = fold_ms / max(fold_n, 1)
         achieved = alg_bytes / (fold_avg_ms * 1e-3) / 1e9 if fold_n else None
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "fold_traffic_%s.json" % args.workload)
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = traffic_record(args.workload)
+        par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, g.channels)) if args.shard == "streams" else \
+              ("ONE %d-channel stream, channels round-robin over %d GPUs (%d on rank 0), every GPU ingests the same block; no collectives"
+               % (len(all_freqs), world, g.channels))
         out = {
             "metric": "wideband I/Q Msamples/s (cf32 ingest -> decoded HFDL PDUs) at fixed channel count",
             "value": samples / elapsed_max / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if not args.host_input else "synthetic, fed from page-locked host memory as %s (PCIe-inclusive)" % args.sample_format,
-            "config": {"workload": w["name"], "sample_rate": w["fs"], "channels": g.channels, "fft_size": g.fft_size,
+            "higher_is_better": True, "scaling": "weak" if args.shard == "streams" else "strong", "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic, resident in HBM before the timed region" if not args.host_input
+                    else "synthetic, fed from page-locked host memory as %s (PCIe-inclusive)" % args.sample_format,
+            "config": {"workload": w["name"], "sample_rate": w["fs"], "channels": len(all_freqs) if args.shard == "channels" else g.channels,
+                       "channels_rank0": g.channels, "fft_size": g.fft_size,
                        "fft_inv_size": g.fft_inv_size, "block_samples": g.input_size, "resident_blocks": nblocks,
-                       "parallelism": "1 independent %d-channel stream per GPU, no collectives" % g.channels},
+                       "stream_seeds": seeds, "shard": args.shard, "parallelism": par},
             "frames_per_s": total_pdus / elapsed_max, "pdus_in_timed_region": total_pdus,
-            "pdus_rank0_matching_sent_payload": good,
+            "pdus_matching_sent_payload": total_good,
             "pdus_rank0_fcs_good_on_device": sum(1 for p in pdus if p["fcs_status"] == 0),
+            # fill / drain kept visible at any --steps: the steady-state period comes from the fold launches' own start events
+            "steady_state_ms_per_step": period_ms,
+            "fill_drain_ms": max(0.0, elapsed * 1e3 - period_ms * args.steps) if period_ms else None,
+            "trellis_steps_per_s_in_run": total_trellis / elapsed_max,
             "roofline": {"bound": "hbm", "kernel": "fold_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n,
                          "literal_bytes_per_launch": 16 * g.fft_size * (g.channels + 1),      # SURVEY 8(d) secondary figure
                          "stream_read_GBs": stream_gbs,
-                         "frac_of_stream_read": (achieved / stream_gbs) if (achieved and stream_gbs) else None},
+                         "frac_of_stream_read": (achieved / stream_gbs) if (achieved and stream_gbs) else None,
+                         "whole_step_frac": (alg_bytes / (period_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if period_ms else None},
             "setup_s": {"frontend_create": round(t_create, 2), "input_synthesis": round(t_gen, 2)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            fe.close()
-            del dev
+        out.update(extra)
+        fe.close()
+        del dev
+        if hbuf:
+            hf.host_free(hbuf)
+        if solo and not args.no_extra_legs:
+            out["host_path"] = host_path_leg(w, x, all_freqs, "CF32", dev_index)
+        if solo and not args.no_cpu_baseline:
+            cores = max(1, min(os.cpu_count() or 1, 64))
+            out["parity"] = parity_gate(w, x, g.input_size, hf, dev_index, cores)
             out["cpu_baseline"] = cpu_baseline(w, x, g.input_size)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

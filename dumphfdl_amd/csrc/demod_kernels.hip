@@ -410,9 +410,35 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(const uint8_t *__rest
 	viterbi27_wave(soft + (size_t)f * 2 * nbits, nbits, (uint64_t *)lds, out + (size_t)f * ((nbits + 7) / 8), false);
 }
 
+// stage kernels behind hfdl_gpu_crc16_ccitt / hfdl_gpu_pdu_triage: the device functions burst_decode_kernel runs on every PDU
+__global__ void crc16_kernel(const uint8_t *__restrict__ data, uint32_t len, uint32_t crc_init, uint32_t *__restrict__ out)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) *out = crc16_ccitt_step(data, len, (uint16_t)crc_init);
+}
+
+__global__ void pdu_triage_kernel(const uint8_t *__restrict__ octets, const int32_t *__restrict__ lens, int npdus, int stride,
+		uint8_t *__restrict__ fcs_status, uint8_t *__restrict__ kind, uint16_t *__restrict__ hdr_len)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= npdus) return;
+	int k = 0;
+	uint32_t hl = 0;
+	fcs_status[i] = (uint8_t)pdu_triage(octets + (size_t)i * stride, (uint32_t)lens[i], &k, &hl);
+	kind[i] = (uint8_t)k;
+	hdr_len[i] = (uint16_t)hl;
+}
+
 // ---------------------------------------------------------------- host side
 
 #define D_TRY(expr) do { if ((expr) != hipSuccess) return HFDL_GPU_EHIP; } while (0)
+
+// HIP events on the null stream around a stage entry point's launch (kernel time without the copies)
+struct KernelTimer {
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	explicit KernelTimer(bool on) { if (on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void)hipEventRecord(e0, nullptr); }
+	double stop() { float ms = 0; if (e0 && e1) { (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); } return ms; }
+	~KernelTimer() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
 
 static size_t demod_lds_bytes(int cap)
 {
@@ -524,23 +550,24 @@ int Demod::enqueue_block(const float2 *chan_out, const int *out_count, int buf, 
 	return 0;
 }
 
-// copy ring entries [taken, produced) to the host, at most `max`; every entry below `produced` is complete
+// copy ring entries [taken, produced) to the host, at most `max`; every entry below `produced` is complete.
+// `produced` may be an OLDER snapshot than `taken` (a draining poll followed by a snapshot poll with no push in between):
+// the difference is taken as signed, so a stale snapshot yields nothing instead of wrapping.
 int Demod::take(unsigned produced, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st)
 {
-	unsigned have = produced - taken;
+	*n = 0;
+	const int32_t avail = (int32_t)(produced - taken);
+	if (avail <= 0 || max <= 0) return 0;
+	if (!out) return HFDL_GPU_EINVAL;              // a NULL buffer never discards PDUs
+	unsigned have = (unsigned)avail;
 	if (have > (unsigned)pdu_cap) have = (unsigned)pdu_cap;
-	const unsigned want = max < 0 ? 0u : (unsigned)max;
-	const unsigned cnt = have < want ? have : want;
-	if (cnt > 0 && out) {
-		const unsigned first = taken % (unsigned)pdu_cap;
-		const unsigned run = cnt < (unsigned)pdu_cap - first ? cnt : (unsigned)pdu_cap - first;
-		D_TRY(hipMemcpy(out, d_pdus + first, sizeof(hfdl_gpu_pdu) * run, hipMemcpyDeviceToHost));
-		if (cnt > run) D_TRY(hipMemcpy(out + run, d_pdus, sizeof(hfdl_gpu_pdu) * (cnt - run), hipMemcpyDeviceToHost));
-	}
-	if (cnt > 0) {
-		taken += cnt;
-		D_TRY(hipMemsetD32Async((hipDeviceptr_t)(d_counts + 3), (int)taken, 1, st));    // ordered after the blocks already queued
-	}
+	const unsigned cnt = have < (unsigned)max ? have : (unsigned)max;
+	const unsigned first = taken % (unsigned)pdu_cap;
+	const unsigned run = cnt < (unsigned)pdu_cap - first ? cnt : (unsigned)pdu_cap - first;
+	D_TRY(hipMemcpy(out, d_pdus + first, sizeof(hfdl_gpu_pdu) * run, hipMemcpyDeviceToHost));
+	if (cnt > run) D_TRY(hipMemcpy(out + run, d_pdus, sizeof(hfdl_gpu_pdu) * (cnt - run), hipMemcpyDeviceToHost));
+	taken += cnt;
+	D_TRY(hipMemsetD32Async((hipDeviceptr_t)(d_counts + 3), (int)taken, 1, st));    // ordered after the blocks already queued
 	*n = (int32_t)cnt;
 	return 0;
 }
@@ -614,7 +641,7 @@ void Demod::release()
 	priv = nullptr;
 }
 
-int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out)
+int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out, double *kernel_ms)
 {
 	const size_t in_bytes = (size_t)nframes * 2 * nbits, out_bytes = (size_t)nframes * ((nbits + 7) / 8);
 	const size_t lds = viterbi_lds_bytes(nbits);
@@ -626,15 +653,51 @@ int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uin
 	D_TRY(hipMemset(d_out.p, 0, out_bytes));
 	int rc = set_big_lds((const void *)viterbi_batch_kernel, lds);
 	if (rc) return rc;
+	KernelTimer tm(kernel_ms != nullptr);
 	hipLaunchKernelGGL(viterbi_batch_kernel, dim3((unsigned)nframes), dim3(64), lds, nullptr, d_in.as<const uint8_t>(), nbits, d_out.as<uint8_t>());
+	if (kernel_ms) *kernel_ms = tm.stop();
 	D_TRY(hipDeviceSynchronize());
 	D_TRY(hipGetLastError());
 	D_TRY(hipMemcpy(out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
 	return 0;
 }
 
+int demod_crc16(const uint8_t *data, uint32_t len, uint16_t crc_init, uint16_t *crc)
+{
+	DevBuf d_in, d_out;
+	D_TRY(d_in.alloc(len));
+	D_TRY(d_out.alloc(sizeof(uint32_t)));
+	if (len) D_TRY(hipMemcpy(d_in.p, data, len, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(crc16_kernel, dim3(1), dim3(64), 0, nullptr, d_in.as<const uint8_t>(), len, (uint32_t)crc_init, d_out.as<uint32_t>());
+	D_TRY(hipDeviceSynchronize());
+	D_TRY(hipGetLastError());
+	uint32_t v = 0;
+	D_TRY(hipMemcpy(&v, d_out.p, sizeof(v), hipMemcpyDeviceToHost));
+	*crc = (uint16_t)v;
+	return 0;
+}
+
+int demod_pdu_triage_batch(const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride, uint8_t *fcs_status, uint8_t *kind, uint16_t *hdr_len)
+{
+	DevBuf d_oct, d_lens, d_fcs, d_kind, d_hl;
+	const size_t n = (size_t)npdus;
+	D_TRY(d_oct.alloc(n * (size_t)stride));
+	D_TRY(d_lens.alloc(n * sizeof(int32_t)));
+	D_TRY(d_fcs.alloc(n)); D_TRY(d_kind.alloc(n)); D_TRY(d_hl.alloc(n * sizeof(uint16_t)));
+	D_TRY(hipMemcpy(d_oct.p, octets, n * (size_t)stride, hipMemcpyHostToDevice));
+	D_TRY(hipMemcpy(d_lens.p, lens, n * sizeof(int32_t), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(pdu_triage_kernel, dim3((unsigned)((npdus + 63) / 64)), dim3(64), 0, nullptr, d_oct.as<const uint8_t>(), d_lens.as<const int32_t>(),
+			npdus, stride, d_fcs.as<uint8_t>(), d_kind.as<uint8_t>(), d_hl.as<uint16_t>());
+	D_TRY(hipDeviceSynchronize());
+	D_TRY(hipGetLastError());
+	D_TRY(hipMemcpy(fcs_status, d_fcs.p, n, hipMemcpyDeviceToHost));
+	D_TRY(hipMemcpy(kind, d_kind.p, n, hipMemcpyDeviceToHost));
+	D_TRY(hipMemcpy(hdr_len, d_hl.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+	return 0;
+}
+
 int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const int32_t *bitmask_lsb, int32_t nframes,
-		uint8_t *octets, int32_t *lens)
+		uint8_t *octets, int32_t *lens, double *kernel_ms)
 {
 	DemodTables h;
 	build_demod_tables(h, 0.6912f);
@@ -668,8 +731,10 @@ int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const i
 	D_TRY(d_pdus.alloc(sizeof(hfdl_gpu_pdu) * (size_t)nframes));
 	int rc = set_big_lds((const void *)burst_decode_kernel, k5_lds_bytes());
 	if (rc) return rc;
+	KernelTimer tm(kernel_ms != nullptr);
 	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nframes), dim3(64), k5_lds_bytes(), nullptr, d_fr.as<const FrameRec>(), d_counts.as<int>(), d_counts.as<int>() + 4, (int *)nullptr,
 			nframes, d_data.as<const cf>(), d_scr.as<const uint8_t>(), d_freqs.as<const int32_t>(), d_pdus.as<hfdl_gpu_pdu>(), nframes);
+	if (kernel_ms) *kernel_ms = tm.stop();
 	D_TRY(hipDeviceSynchronize());
 	D_TRY(hipGetLastError());
 	std::vector<hfdl_gpu_pdu> out((size_t)nframes);

@@ -1,0 +1,453 @@
+// demod_logic.h -- per-channel HFDL demodulator: state, modem, PDU triage and the framer FSM (gfx950 device code).
+//
+// The lane-independent part of the body of hfdl_decoder_thread after fastddc_inv_cc (reference src/hfdl.c:676-892):
+// everything here is one wave-uniform recurrence per channel -- M-PSK slicer / soft de-mapper, Costas adjust, preamble
+// correlator, framer / sampler state machine, resets, FCS / header triage.  The lane-parallel block loop that drives it is
+// demod_core.h.  Plain C++ expressions only (no DPP, no LDS): written once, for the device; the two host-side users are
+// Demod::init (initial channel state) and the burst-decode batch entry point (mode table).
+// tests/hostsim compiles this file with g++ behind a few shims it defines itself (test harness, never shipped).
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#define HFDL_FN __device__ inline
+#define HFDL_HD __host__ __device__ inline
+
+namespace hfdl {
+
+struct cf { float x, y; };
+
+constexpr int D_RS_NPFB = 256, D_RS_TAPS = 14, D_SS_NPFB = 16, D_SS_TAPS = 18, D_EQ = 15, D_MF = 19;
+constexpr int MAX_DATA_SYMBOLS = 168 * 30;
+
+// framer constants, src/hfdl.c:29-46
+constexpr int A_LEN = 127, M1_LEN = 127, M2_LEN = 15, T_LEN = 15, DATA_FRAME_LEN = 30;
+constexpr int SINGLE_SLOT_FRAME_LEN = 448 + (2 * 127 + 127 + 15 + 9 * 15) + 72 * 45;
+enum { SAMPLER_BITS = 1, SAMPLER_SYMBOLS = 2, SAMPLER_SKIP = 3 };
+enum { FR_A1 = 1, FR_A2, FR_M1, FR_M2_SKIP, FR_EQ_TRAIN, FR_DATA_1, FR_DATA_2 };
+
+// mode table, src/hfdl.c:81-138: {bits/symbol, data segments, code-rate denominator, interleaver column shift}
+struct ModeParams { int arity, segments, code_rate, col_shift; };
+HFDL_HD ModeParams mode_params(int m)
+{
+	ModeParams p;
+	p.arity = (m & 3) == 0 ? 1 : (m & 3);
+	p.segments = (m & 4) ? 168 : 72;
+	p.code_rate = (m & 3) == 0 ? 4 : 2;
+	p.col_shift = (m & 4) ? 23 : 17;
+	return p;
+}
+
+struct ChanScalars {
+	uint32_t rs_phase;
+	float agc_g, agc_y2;
+	float ss_rate, ss_del, ss_tau, ss_bf, ss_q, ss_qhat, ss_v1;
+	int32_t ss_b, ss_head;
+	uint32_t ss_decim;
+	float phi, dphi, err;
+	float eq_x2sum;
+	uint32_t eq_count;
+	int32_t eq_full, eq_head;
+	uint64_t bits_hi, bits_lo;
+	int32_t training_n, data_n, use_data, data_slot;
+	uint64_t symbol_cnt, sample_cnt, pdu_sample_index;
+	int32_t s_state, fr_state, data_arity, cur_arity, symbols_wanted, search_retries;
+	int32_t eq_train_seq_cnt, data_segment_cnt, train_total, train_bad, T_idx, M1;
+	uint32_t bitmask, symsync_out_idx, nf_clk;
+	float frame_symbol_cnt, freq_err_hz, signal_level, noise_floor;
+	// observability: the per-channel StatsD counters of the reference's hot path (src/hfdl.c:818,828,840; doc/STATSD_METRICS.md)
+	uint32_t cnt_a2_found, cnt_m1_found, cnt_m1_not_found, cnt_frames;
+	uint32_t ev_flags;             // EV_*: resets that happened inside on_symbol(), for the register-resident device windows
+};
+enum { EV_SS_RESET = 1, EV_EQ_RESET = 2 };
+
+struct ChanArrays {
+	cf rs_hist[D_RS_TAPS - 1];     // [0] = most recent channelizer sample of the previous block
+	cf mf_hist[D_MF - 1];          // [0] = most recent AGC output of the previous block
+	cf ss_mf[D_SS_TAPS], ss_dmf[D_SS_TAPS];   // circular, ss_head = newest
+	cf eq_w[D_EQ], eq_buf[D_EQ];   // eq_buf circular, eq_head = oldest
+	float eq_x2[D_EQ];
+	cf training[T_LEN];
+};
+
+struct ChanState { ChanScalars s; ChanArrays a; };
+
+// what a finished frame hands to the burst decoder (K5)
+struct FrameRec {
+	int32_t channel, slot, mode, bitmask_lsb;
+	float freq_err_hz, signal_level, noise_floor;
+	int32_t train_bad, train_total, pad;
+	uint64_t sample_index;
+};
+
+// constant tables as the kernels see them
+struct DemodConst {
+	const float *rs_h;             // [256][14]
+	uint32_t rs_step;
+	const float *mf;               // [19]
+	const float *ss_mf, *ss_dmf;   // [16][18]  (the kernel stages these in LDS)
+	float lf_b0, lf_a1, ss_rate_adj;
+	const float *eq_h0;            // [15]
+	uint64_t a_hi, a_lo;
+	const uint64_t *m1_hi, *m1_lo; // [8]
+	const float *corr_tab;         // [128]: 2.0f * m / 127.0f - 1.0f for m matching bits (the reference's expression, src/hfdl.c:781)
+};
+
+// per-block scratch (LDS) and outputs (global)
+struct BlockIo {
+	cf *rs, *agc, *mf;             // scratch [cap]
+	float *lvl;                    // scratch [cap]
+	int cap;
+	cf *data;                      // global [2][MAX_DATA_SYMBOLS] of this channel
+	FrameRec *frames;              // global queue
+	int *frame_count;
+	int frame_cap;
+	// optional stage taps (global, this channel), null when disabled
+	cf *tap_resampled, *tap_mf, *tap_symbols;
+	float *tap_level;
+	int *tap_counts;               // [2]: resampled count, symbol count
+	int channel;
+};
+
+HFDL_HD void chan_state_init(ChanState &st, const float *eq_h0)
+{
+	ChanScalars &s = st.s;
+	ChanArrays &a = st.a;
+	char *p = (char *)&st;
+	for (unsigned i = 0; i < sizeof(ChanState); i++) p[i] = 0;
+	s.agc_g = 1.0f; s.agc_y2 = 1.0f;          // agc_crcf_create + reset
+	s.noise_floor = 1.0f;                     // src/hfdl.c:490
+	s.ss_rate = 1.5f; s.ss_del = 1.5f;        // k / k_out = 3 / 2
+	for (int i = 0; i < D_EQ; i++) { a.eq_w[i].x = eq_h0[i]; a.eq_w[i].y = 0.f; }
+	// framer_reset, src/hfdl.c:974-991
+	s.fr_state = FR_A1; s.symbols_wanted = 1; s.cur_arity = 1; s.s_state = SAMPLER_BITS;
+}
+
+// ---------------- modem (liquid-dsp semantics, see oracle/fec_restated.c for the cited restatement) ----------------
+
+HFDL_FN uint32_t gray_enc(uint32_t b) { return b ^ (b >> 1); }
+HFDL_FN uint32_t gray_dec(uint32_t g) { uint32_t b = g; while (g >>= 1) b ^= g; return b; }
+
+HFDL_FN cf psk_point(int arity, uint32_t sym)
+{
+	cf y;
+	if (arity == 1) { y.x = sym ? -1.0f : 1.0f; y.y = 0.0f; return y; }
+	const uint32_t M = 1u << arity;
+	const float alpha = (float)M_PI / (float)M;
+	const float ang = (float)gray_dec(sym) * 2 * alpha;
+	y.x = cosf(ang); y.y = sinf(ang);
+	return y;
+}
+
+HFDL_FN uint32_t psk_slice(int arity, cf x, float *phase_error)
+{
+	uint32_t sym;
+	cf xh;
+	if (arity == 1) {
+		sym = (x.x > 0) ? 0 : 1;
+		xh.x = sym ? -1.0f : 1.0f; xh.y = 0.0f;
+	} else {
+		const uint32_t M = 1u << arity;
+		const float alpha = (float)M_PI / (float)M;
+		float theta = atan2f(x.y, x.x);
+		theta -= (float)M_PI * (1.0f - 1.0f / (float)M);
+		if (theta < -(float)M_PI) theta += 2 * (float)M_PI;
+		uint32_t s = 0;
+		float v = theta;
+		for (int k = arity - 1; k >= 0; k--) {
+			const float ref = (float)(1u << k) * alpha;
+			s <<= 1;
+			if (v > 0) { s |= 1; v -= ref; } else { v += ref; }
+		}
+		sym = gray_enc(s);
+		xh = psk_point(arity, sym);
+	}
+	if (phase_error) *phase_error = x.y * xh.x - x.x * xh.y;
+	return sym;
+}
+
+HFDL_FN uint8_t soft_clamp(float v)
+{
+	int s = (int)(v + 127);
+	return (uint8_t)(s > 255 ? 255 : (s < 0 ? 0 : s));
+}
+
+// modem_demodulate_soft: 255 = confident '1', soft[0] = MSB of the symbol
+HFDL_FN void psk_soft(int arity, cf x, uint8_t *soft)
+{
+	if (arity == 1) {
+		const float llr = -2.0f * x.x * 4.0f;
+		soft[0] = soft_clamp(llr * 16);
+		return;
+	}
+	const uint32_t sym = psk_slice(arity, x, nullptr);
+	if (arity == 2) { soft[0] = (sym & 2) ? 255 : 0; soft[1] = (sym & 1) ? 255 : 0; return; }
+	const uint32_t M = 1u << arity;
+	const float gamma = 1.2f * (float)M;
+	float d0[3], d1[3];
+	cf c = psk_point(arity, sym);
+	float er = x.x - c.x, ei = x.y - c.y;
+	float d = er * er + ei * ei;
+	for (int k = 0; k < arity; k++) {
+		if ((sym >> (arity - k - 1)) & 1) { d0[k] = 4.0f; d1[k] = d; } else { d0[k] = d; d1[k] = 4.0f; }
+	}
+	const uint32_t lin = gray_dec(sym);
+	for (int nb = 0; nb < 2; nb++) {
+		const uint32_t ns = gray_enc((lin + (nb ? 1 : M - 1)) % M);
+		c = psk_point(arity, ns);
+		er = x.x - c.x; ei = x.y - c.y;
+		d = er * er + ei * ei;
+		for (int k = 0; k < arity; k++) {
+			if ((ns >> (arity - k - 1)) & 1) { if (d < d1[k]) d1[k] = d; } else { if (d < d0[k]) d0[k] = d; }
+		}
+	}
+	for (int k = 0; k < arity; k++) soft[k] = soft_clamp(((d0[k] - d1[k]) * gamma) * 16);
+}
+
+// ---------------- PDU header triage: FCS = CRC-16/X-25 over the header, stored low octet first ----------------
+// hfdl_pdu_fcs_check (src/pdu.c:68-79), header length rules of mpdu_parse (src/mpdu.c:56-79) and spdu_parse (src/spdu.c:12,55-62)
+
+// crc16_ccitt(data, len, crc_init) of src/crc.c:4-47 (reflected polynomial 0x8408; the reference walks a 256-entry table,
+// this is the same recurrence bit by bit -- no table to stage, and it runs once per PDU on one lane)
+HFDL_FN uint16_t crc16_ccitt_step(const uint8_t *p, uint32_t len, uint16_t crc_init)
+{
+	uint32_t crc = crc_init;
+	for (uint32_t i = 0; i < len; i++) {
+		crc ^= p[i];
+		for (int b = 0; b < 8; b++) crc = (crc & 1u) ? (crc >> 1) ^ 0x8408u : crc >> 1;
+	}
+	return (uint16_t)crc;
+}
+
+// the FCS as hfdl_pdu_fcs_check computes it (src/pdu.c:69): init 0xFFFF, final XOR 0xFFFF = CRC-16/X-25
+HFDL_FN uint16_t crc16_x25(const uint8_t *p, uint32_t len)
+{
+	return (uint16_t)(crc16_ccitt_step(p, len, 0xFFFFu) ^ 0xFFFFu);
+}
+
+// returns fcs status (0 good, 1 bad, 2 too short); kind: 0 SPDU, 1 MPDU downlink, 2 MPDU uplink
+HFDL_FN int pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hdr_len_out)
+{
+	uint32_t hdr_len;
+	if ((buf[0] & 1u) == 0) {
+		*kind = 0;
+		hdr_len = 64;
+		*hdr_len_out = hdr_len;
+		if (len < 66) return 2;
+	} else if (buf[0] & 0x2u) {
+		*kind = 1;
+		hdr_len = 6 + ((buf[0] >> 2) & 0xFu);
+	} else {
+		*kind = 2;
+		const uint32_t aircraft_cnt = ((buf[0] & 0x70u) >> 4) + 1;
+		hdr_len = 2;
+		for (uint32_t i = 0; i < aircraft_cnt; i++) {
+			if (len < hdr_len + 2) { *hdr_len_out = hdr_len; return 2; }
+			hdr_len += 2 + (buf[hdr_len + 1] >> 4);
+		}
+	}
+	*hdr_len_out = hdr_len;
+	if (len < hdr_len + 2) return 2;
+	const uint16_t rx = (uint16_t)(buf[hdr_len] | (buf[hdr_len + 1] << 8));
+	return rx == crc16_x25(buf, hdr_len) ? 0 : 1;
+}
+
+HFDL_FN void symsync_reset(ChanScalars &s, ChanArrays &a)
+{
+	// symsync_crcf_reset clears the matched-filter window only
+	for (int i = 0; i < D_SS_TAPS; i++) { a.ss_mf[i].x = 0.f; a.ss_mf[i].y = 0.f; }
+	s.ss_rate = 1.5f; s.ss_del = 1.5f;
+	s.ss_b = 0; s.ss_bf = 0.f; s.ss_tau = 0.f; s.ss_q = 0.f; s.ss_qhat = 0.f;
+	s.ss_decim = 0; s.ss_v1 = 0.f;
+	s.ev_flags |= EV_SS_RESET;
+}
+
+HFDL_FN void eq_reset(ChanScalars &s, ChanArrays &a, const float *eq_h0)
+{
+	for (int i = 0; i < D_EQ; i++) {
+		a.eq_w[i].x = eq_h0[i]; a.eq_w[i].y = 0.f;
+		a.eq_buf[i].x = 0.f; a.eq_buf[i].y = 0.f;
+		a.eq_x2[i] = 0.f;
+	}
+	s.eq_x2sum = 0.f; s.eq_count = 0; s.eq_full = 0; s.eq_head = 0;
+	s.ev_flags |= EV_EQ_RESET;
+}
+
+HFDL_FN void framer_reset(ChanScalars &s, ChanArrays &a, const float *eq_h0)      // src/hfdl.c:968-991
+{
+	s.fr_state = FR_A1;
+	s.symbols_wanted = 1;
+	s.search_retries = 0;
+	s.cur_arity = 1;
+	s.train_total = s.train_bad = 0;
+	s.T_idx = 0;
+	s.use_data = 0;
+	eq_reset(s, a, eq_h0);
+	s.data_n = 0;
+	s.training_n = 0;
+	symsync_reset(s, a);
+	s.s_state = SAMPLER_BITS;
+	s.bitmask = 0;
+}
+
+HFDL_FN int bits_correlate(uint64_t hi, uint64_t lo, uint64_t thi, uint64_t tlo)
+{
+	return 127 - __popcll((hi ^ thi) & 0x7FFFFFFFFFFFFFFFull) - __popcll(lo ^ tlo);
+}
+
+HFDL_FN float t_symbol(int idx)          // T = 0x9AF, bit 14 first; BPSK 0 -> +1
+{
+	if (idx > 14) idx = 14;
+	return ((0x9AFu >> (14 - idx)) & 1u) ? -1.0f : 1.0f;
+}
+
+// everything after the equaliser for one on-time symbol: src/hfdl.c:737-891
+HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, cf sym, float level)
+{
+	float perr;
+	uint32_t bits = psk_slice(s.cur_arity, sym, &perr);
+	{   // costas_cccf_adjust, :276-281
+		const float e = 0.5f * (fabsf(perr + 1.0f) - fabsf(perr - 1.0f));
+		s.err = e;
+		s.phi += 0.1f * e;
+		s.dphi += (0.047f * 0.1f * 0.1f) * e;
+	}
+	s.symbol_cnt++;
+	if (s.symbol_cnt >= (uint64_t)(13 * SINGLE_SLOT_FRAME_LEN) && s.fr_state == FR_A1) {
+		s.symbol_cnt = 0;
+		s.dphi = s.phi = 0.0f;
+		symsync_reset(s, a);
+	}
+	if (s.s_state == SAMPLER_BITS) {
+		bits ^= s.bitmask;
+		for (int b = 0; b < s.cur_arity; b++, bits >>= 1) {
+			s.bits_hi = ((s.bits_hi << 1) | (s.bits_lo >> 63)) & 0x7FFFFFFFFFFFFFFFull;
+			s.bits_lo = (s.bits_lo << 1) | (bits & 1u);
+		}
+	} else if (s.s_state == SAMPLER_SYMBOLS) {
+		if (s.use_data) {
+			if (s.data_n < MAX_DATA_SYMBOLS) {
+				if (threadIdx.x == 0) io.data[s.data_slot * MAX_DATA_SYMBOLS + s.data_n] = sym;
+				s.data_n++;
+			}
+		} else if (s.training_n < T_LEN) {
+			a.training[s.training_n] = sym;
+			s.training_n++;
+		}
+	}
+	if (s.fr_state > FR_A1) {
+		s.signal_level = (s.signal_level * s.frame_symbol_cnt + level) / (s.frame_symbol_cnt + 1.0f);
+		s.frame_symbol_cnt += 1.0f;
+	}
+	if (s.symbols_wanted > 1) { s.symbols_wanted--; return; }
+
+	switch (s.fr_state) {
+	case FR_A1: {
+		const float corr = T.corr_tab[bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo)];
+		if (fabsf(corr) > 0.36f) {
+			s.bitmask = corr > 0.f ? 0u : ~0u;
+			s.signal_level = level;
+			s.frame_symbol_cnt = 1.0f;
+			s.symbols_wanted = A_LEN;
+			s.search_retries = 0;
+			s.fr_state = FR_A2;
+		}
+		break; }
+	case FR_A2: {
+		const float corr = T.corr_tab[bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo)];
+		if (fabsf(corr) > 0.3f) {
+			s.cnt_a2_found++;                    // statsd "demod.preamble.A2_found"
+			s.pdu_sample_index = s.sample_cnt;
+			s.freq_err_hz = (float)((double)(s.dphi * 1800) / (2.0 * M_PI));
+			s.symbols_wanted = M1_LEN;
+			s.search_retries = 0;
+			s.fr_state = FR_M1;
+		} else if (++s.search_retries >= 3) {
+			framer_reset(s, a, T.eq_h0);
+		}
+		break; }
+	case FR_M1: {
+		float best = 0.f;
+		int best_idx = -1;
+		for (int m = 0; m < 8; m++) {
+			const float corr = fabsf(T.corr_tab[bits_correlate(s.bits_hi, s.bits_lo, T.m1_hi[m], T.m1_lo[m])]);
+			if (corr > best) { best = corr; best_idx = m; }
+		}
+		if (fabsf(best) > 0.3f) {
+			const ModeParams mp = mode_params(best_idx);
+			s.cnt_m1_found++;                    // "demod.preamble.M1_found"
+			s.data_segment_cnt = mp.segments;
+			s.data_arity = mp.arity;
+			s.M1 = best_idx;
+			s.symbols_wanted = M2_LEN;
+			s.search_retries = 0;
+			s.fr_state = FR_M2_SKIP;
+			s.s_state = SAMPLER_SKIP;
+		} else {
+			s.cnt_m1_not_found++;                // "demod.preamble.errors.M1_not_found"
+			framer_reset(s, a, T.eq_h0);
+		}
+		break; }
+	case FR_M2_SKIP:
+		s.training_n = 0;
+		s.symbols_wanted = T_LEN;
+		s.eq_train_seq_cnt = 9;
+		s.fr_state = FR_EQ_TRAIN;
+		s.s_state = SAMPLER_SYMBOLS;
+		break;
+	case FR_EQ_TRAIN: {
+		// compute_train_bit_error_cnt, :952-966
+		uint32_t seq = 0;
+		for (int i = 0; i < T_LEN; i++) {
+			uint32_t bit = (a.training[i].x > 0) ? 0u : 1u;
+			bit ^= (s.bitmask & 1u);
+			seq = (seq << 1) | bit;
+		}
+		s.train_total += T_LEN;
+		s.train_bad += __popc(0x9AFu ^ seq);
+		s.training_n = 0;
+		if (s.eq_train_seq_cnt > 1) {
+			s.eq_train_seq_cnt--;
+			s.symbols_wanted = T_LEN;
+			s.T_idx = 0;
+		} else if (s.data_segment_cnt > 0) {
+			s.symbols_wanted = DATA_FRAME_LEN / 2;
+			s.fr_state = FR_DATA_1;
+			s.cur_arity = s.data_arity;
+			s.use_data = 1;
+		} else {
+			// end of frame: queue it for the burst decoder (decode_user_data + dispatch_pdu, :993-1080)
+			if (threadIdx.x == 0) {
+				const int slot = atomicAdd(io.frame_count, 1);
+				if (slot < io.frame_cap) {
+					FrameRec fr;
+					fr.channel = io.channel; fr.slot = s.data_slot; fr.mode = s.M1; fr.bitmask_lsb = (int32_t)(s.bitmask & 1u);
+					fr.freq_err_hz = s.freq_err_hz; fr.signal_level = s.signal_level; fr.noise_floor = s.noise_floor;
+					fr.train_bad = s.train_bad; fr.train_total = s.train_total; fr.pad = 0;
+					fr.sample_index = s.pdu_sample_index;
+					io.frames[slot] = fr;
+				}
+			}
+			s.data_slot ^= 1;
+			s.cnt_frames++;
+			framer_reset(s, a, T.eq_h0);
+			s.symbol_cnt = 0;
+		}
+		break; }
+	case FR_DATA_1:
+		s.symbols_wanted = DATA_FRAME_LEN / 2;
+		s.fr_state = FR_DATA_2;
+		break;
+	case FR_DATA_2:
+		s.data_segment_cnt--;
+		s.cur_arity = 1;
+		s.use_data = 0;
+		s.fr_state = FR_EQ_TRAIN;
+		s.eq_train_seq_cnt = 1;
+		s.symbols_wanted = T_LEN;
+		s.T_idx = 0;
+		break;
+	}
+}
+
+}  // namespace hfdl

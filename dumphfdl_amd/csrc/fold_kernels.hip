@@ -181,6 +181,45 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 // wave 0 runs it while the other 15 waves sum the fold slices out of HBM; all 16 then share the inverse FFT.
 constexpr int IFFT_THREADS = 1024;
 
+// decimating_shift_addition_cc's phasor recurrence (src/libcsdr_gpl.c:48-66): fp32, no contraction, seeded from the carried
+// starting phase with double-precision cos / sin rounded to float exactly as the reference's `float cosphi = cos(...)`.
+// One thread runs it (it is a serial chain); ph[i] is the phasor that multiplies output i.
+__device__ __forceinline__ void nco_phasor_run(float2 *ph, int cnt, float starting_phase, float cd, float sd)
+{
+	float cphi = (float)cos((double)starting_phase), sphi = (float)sin((double)starting_phase);
+	for (int i = 0; i < cnt; i++) {
+		ph[i] = make_float2(cphi, sphi);
+		const float c0 = cphi, s0 = sphi;
+		cphi = __fsub_rn(__fmul_rn(c0, cd), __fmul_rn(s0, sd));
+		sphi = __fadd_rn(__fmul_rn(s0, cd), __fmul_rn(c0, sd));
+	}
+}
+
+// output[k] = input[i] * e^{j phi_k}, the reference's expression term for term (:54-57)
+__device__ __forceinline__ float2 nco_rotate(float2 p, float2 v)
+{
+	return make_float2(__fsub_rn(__fmul_rn(p.x, v.x), __fmul_rn(p.y, v.y)), __fadd_rn(__fmul_rn(p.y, v.x), __fmul_rn(p.x, v.y)));
+}
+
+// carried state after a block of `cnt` outputs (:67-72): remainder of the decimation stride, phase advanced in double and
+// wrapped to (-pi, pi], stored as float
+__device__ __forceinline__ void nco_advance(NcoState &st, int cnt, int q, int input_size, float rate)
+{
+	const int last = st.decimation_remain + q * cnt;
+	st.decimation_remain = last - input_size;
+	const double phase = (double)st.starting_phase + (double)rate * M_PI * (double)cnt;
+	float fp = (float)phase;
+	while ((double)fp > M_PI) fp = (float)((double)fp - 2 * M_PI);
+	while ((double)fp < -M_PI) fp = (float)((double)fp + 2 * M_PI);
+	st.starting_phase = fp;
+	st.output_size = cnt;
+}
+
+__device__ __forceinline__ int nco_output_count(const NcoState &st, int input_size, int q)
+{
+	return st.decimation_remain < input_size ? (input_size - st.decimation_remain + q - 1) / q : 0;
+}
+
 __global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__restrict__ partial, const ChanConst *__restrict__ cc,
 		NcoState *__restrict__ nco, const float2 *__restrict__ tw, float2 *__restrict__ chan_out, int *__restrict__ out_count,
 		Geometry g, int logm)
@@ -192,20 +231,9 @@ __global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__
 	const int m = g.m, mask = m - 1;
 	NcoState st = nco[c];
 	const int q = g.post;
-	int cnt = 0;
-	if (st.decimation_remain < g.post_input_size) cnt = (g.post_input_size - st.decimation_remain + q - 1) / q;
+	const int cnt = nco_output_count(st, g.post_input_size, q);
 	if (threadIdx.x < 64) {
-		if (threadIdx.x == 0) {
-			// decimating_shift_addition_cc's phasor recurrence, fp32, no contraction (src/libcsdr_gpl.c:46-66)
-			float cphi = (float)cos((double)st.starting_phase), sphi = (float)sin((double)st.starting_phase);
-			const float cd = k.nco_cosdelta, sd = k.nco_sindelta;
-			for (int i = 0; i < cnt; i++) {
-				ph[i] = make_float2(cphi, sphi);
-				float c0 = cphi, s0 = sphi;
-				cphi = __fsub_rn(__fmul_rn(c0, cd), __fmul_rn(s0, sd));
-				sphi = __fadd_rn(__fmul_rn(s0, cd), __fmul_rn(c0, sd));
-			}
-		}
+		if (threadIdx.x == 0) nco_phasor_run(ph, cnt, st.starting_phase, k.nco_cosdelta, k.nco_sindelta);
 	} else {
 		const int h0 = (int)(((long long)g.n - k.offsetbin + m / 2) % m);
 		const float2 *pc = partial + (size_t)c * g.slices * (size_t)m;
@@ -228,22 +256,35 @@ __global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__
 		const int idx = g.scrap + st.decimation_remain + q * i;
 		float2 v = sm[(int)(__brev((unsigned)idx) >> (32 - logm))];
 		v.x = __fdiv_rn(v.x, norm); v.y = __fdiv_rn(v.y, norm);
-		const float2 p = ph[i];
-		o[i] = make_float2(__fsub_rn(__fmul_rn(p.x, v.x), __fmul_rn(p.y, v.y)),
-				__fadd_rn(__fmul_rn(p.y, v.x), __fmul_rn(p.x, v.y)));
+		o[i] = nco_rotate(ph[i], v);
 	}
 	if (threadIdx.x == 0) {
-		int last = st.decimation_remain + q * cnt;
-		st.decimation_remain = last - g.post_input_size;
-		double phase = (double)st.starting_phase + (double)k.nco_rate * M_PI * (double)cnt;
-		float fp = (float)phase;
-		while ((double)fp > M_PI) fp = (float)((double)fp - 2 * M_PI);
-		while ((double)fp < -M_PI) fp = (float)((double)fp + 2 * M_PI);
-		st.starting_phase = fp;
-		st.output_size = cnt;
+		nco_advance(st, cnt, q, g.post_input_size, k.nco_rate);
 		nco[c] = st;
 		out_count[c] = cnt;      // per-buffer copy: the demodulator of this block may run while the next block updates nco[]
 	}
+}
+
+// the NCO / decimator stage on its own (stage entry point hfdl_gpu_nco_decimate): the same device functions the channelizer
+// kernel above runs after its inverse FFT, one workgroup, phasors through a global scratch buffer
+__global__ __launch_bounds__(IFFT_THREADS) void nco_decimate_kernel(const float2 *__restrict__ in, int input_size, float cd, float sd, float rate,
+		int q, NcoState *__restrict__ state, float2 *__restrict__ ph, float2 *__restrict__ out)
+{
+	NcoState st = *state;
+	const int cnt = nco_output_count(st, input_size, q);
+	if (threadIdx.x == 0) nco_phasor_run(ph, cnt, st.starting_phase, cd, sd);
+	__syncthreads();
+	for (int i = threadIdx.x; i < cnt; i += IFFT_THREADS) out[i] = nco_rotate(ph[i], in[st.decimation_remain + q * i]);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		nco_advance(st, cnt, q, input_size, rate);
+		*state = st;
+	}
+}
+
+void launch_nco_decimate(const float2 *in, int input_size, float cd, float sd, float rate, int q, NcoState *state, float2 *ph, float2 *out, hipStream_t st)
+{
+	hipLaunchKernelGGL(nco_decimate_kernel, dim3(1), dim3(IFFT_THREADS), 0, st, in, input_size, cd, sd, rate, q, state, ph, out);
 }
 
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,

@@ -3,10 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <complex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "../../include/hfdl_gpu.h"
@@ -31,6 +33,18 @@ static int fail(int code, const char *fmt, ...)
 	return fail(HFDL_GPU_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 extern "C" const char *hfdl_gpu_last_error(void) { return g_err; }
+
+// kernel time of the last stage-level entry point called by this thread (HIP events around its launches, copies excluded)
+static thread_local double g_stage_ms = 0.0;
+extern "C" double hfdl_gpu_last_stage_ms(void) { return g_stage_ms; }
+
+// brackets the launches of a stage entry point with events on the null stream
+struct StageTimer {
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	StageTimer() { g_stage_ms = 0.0; if (hipEventCreate(&e0) != hipSuccess) e0 = nullptr; if (hipEventCreate(&e1) != hipSuccess) e1 = nullptr; if (e0) (void)hipEventRecord(e0, nullptr); }
+	void stop() { if (e0 && e1) { (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1); float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) g_stage_ms = ms; } }
+	~StageTimer() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
 
 extern "C" int hfdl_gpu_device_count(void)
 {
@@ -123,6 +137,8 @@ struct hfdl_gpu_frontend {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 	double fold_ms = 0;
 	int64_t fold_launches = 0;
+	hipEvent_t ev_first_fold = nullptr;  // start of the first timed fold since reset_timers: anchor of the steady-state step period
+	double span_ms = 0;                 // first timed fold start -> last timed fold start
 	uint64_t blocks = 0;
 	FftOutLayout tap_layout;
 	int pending_demod_buf = -1;         // block whose demodulator launch is held back until the next forward FFT is queued
@@ -143,6 +159,7 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_stage_ready[i], fe->ev_stage_free[i] }) if (e) (void)hipEventDestroy(e);
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	if (fe->ev_fft) (void)hipEventDestroy(fe->ev_fft);
+	if (fe->ev_first_fold) (void)hipEventDestroy(fe->ev_first_fold);
 	fe->demod.release();
 	fe->fft.release();
 	void *ptrs[] = { fe->d_hist[0], fe->d_hist[1], fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_out[0], fe->d_chan_out[1], fe->d_tw_m,
@@ -312,6 +329,7 @@ extern "C" int hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_
 	g->fft_size = p.n; g->fft_inv_size = p.m; g->input_size = p.input_size;
 	g->post_input_size = p.post_input_size; g->scrap = p.scrap;
 	g->outputs_per_block = p.post_input_size / p.post;
+	g->max_outputs_per_block = (p.post_input_size + p.post - 1) / p.post;
 	g->channels = fe->geo.nch; g->fold_slices = fe->geo.slices;
 	g->transition_bw = fe->tbw;
 	g->resamp_rate = (float)(1800 * 3) / ((float)fe->sample_rate / (float)fe->decimation);
@@ -330,18 +348,42 @@ extern "C" int hfdl_gpu_plan_geometry(int32_t decimation, float transition_bw, h
 	g->fft_size = p.n; g->fft_inv_size = p.m; g->input_size = p.input_size;
 	g->post_input_size = p.post_input_size; g->scrap = p.scrap;
 	g->outputs_per_block = p.post_input_size / p.post;
+	g->max_outputs_per_block = (p.post_input_size + p.post - 1) / p.post;
 	g->transition_bw = transition_bw;
 	return 0;
+}
+
+// page-locked ranges handed out by hfdl_gpu_host_alloc(): only these are left to the DMA engine after push_block returns
+static std::mutex g_pinned_lock;
+static std::vector<std::pair<const char *, size_t>> g_pinned;
+
+static bool is_library_pinned(const void *p, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_pinned_lock);
+	for (auto &r : g_pinned)
+		if ((const char *)p >= r.first && (const char *)p + bytes <= r.first + r.second) return true;
+	return false;
 }
 
 extern "C" int hfdl_gpu_host_alloc(void **ptr, size_t bytes)
 {
 	if (!ptr || !bytes) return fail(HFDL_GPU_EINVAL, "bad arguments");
 	HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+	std::lock_guard<std::mutex> lk(g_pinned_lock);
+	g_pinned.emplace_back((const char *)*ptr, bytes);
 	return 0;
 }
 
-extern "C" void hfdl_gpu_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
+extern "C" void hfdl_gpu_host_free(void *ptr)
+{
+	if (!ptr) return;
+	{
+		std::lock_guard<std::mutex> lk(g_pinned_lock);
+		for (size_t i = 0; i < g_pinned.size(); i++)
+			if (g_pinned[i].first == (const char *)ptr) { g_pinned.erase(g_pinned.begin() + (long)i); break; }
+	}
+	(void)hipHostFree(ptr);
+}
 
 extern "C" void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe) { return fe ? (void *)fe->stream : nullptr; }
 
@@ -369,6 +411,9 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 	HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_stage_free[sb], 0));     // stream A finished reading this buffer two blocks ago
 	HIP_TRY(hipMemcpyAsync(fe->d_stage[sb], iq, sample_bytes(fmt) * nsamples, hipMemcpyHostToDevice, fe->stream_c));
 	HIP_TRY(hipEventRecord(fe->ev_stage_ready[sb], fe->stream_c));
+	// a buffer this library did not allocate may be reused by the caller as soon as we return (include/hfdl_gpu.h): do not
+	// rely on the runtime staging pageable memory synchronously -- wait for the copy (the kernels of the previous block keep running)
+	if (!is_library_pinned(iq, sample_bytes(fmt) * nsamples)) HIP_TRY(hipStreamSynchronize(fe->stream_c));
 	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_stage_ready[sb], 0));
 	*dev = fe->d_stage[sb];
 	*stage_idx = sb;
@@ -476,7 +521,14 @@ static int drain_events(hfdl_gpu_frontend *fe)
 		HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
 		fe->fold_ms += ms;
 		fe->fold_launches++;
-		(void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+		if (!fe->ev_first_fold) {
+			fe->ev_first_fold = e.first;            // kept until the next reset
+		} else {
+			HIP_TRY(hipEventElapsedTime(&ms, fe->ev_first_fold, e.first));
+			fe->span_ms = ms;
+			(void)hipEventDestroy(e.first);
+		}
+		(void)hipEventDestroy(e.second);
 	}
 	fe->ev.clear();
 	return 0;
@@ -508,6 +560,8 @@ extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
 	fe->fold_ms = 0; fe->fold_launches = 0; fe->timing = enable != 0;
+	if (fe->ev_first_fold) { (void)hipEventDestroy(fe->ev_first_fold); fe->ev_first_fold = nullptr; }
+	fe->span_ms = 0;
 	return 0;
 }
 
@@ -553,9 +607,19 @@ extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *tot
 	return 0;
 }
 
+extern "C" int hfdl_gpu_frontend_step_period_ms(hfdl_gpu_frontend *fe, double *period_ms)
+{
+	if (!fe || !period_ms) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	*period_ms = fe->fold_launches > 1 ? fe->span_ms / (double)(fe->fold_launches - 1) : 0.0;
+	return 0;
+}
+
 extern "C" int hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n)
 {
 	if (!fe || !n) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (!out && max > 0) return fail(HFDL_GPU_EINVAL, "null PDU buffer with max = %d", max);
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
 	rc = fe->demod.collect(out, max, n, fe->stream_b);
@@ -566,6 +630,7 @@ extern "C" int hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *
 extern "C" int hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n, int32_t max_in_flight)
 {
 	if (!fe || !n) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (!out && max > 0) return fail(HFDL_GPU_EINVAL, "null PDU buffer with max = %d", max);
 	if (max_in_flight <= 0) return hfdl_gpu_frontend_poll_pdus(fe, out, max, n);
 	*n = 0;
 	// leave the newest block running: wait for the one before it and take what the ring held when that one finished
@@ -672,7 +737,9 @@ extern "C" int hfdl_gpu_fft_forward(int device, const float *in, float *out, int
 	HIP_TRY(d_work.alloc(bytes));
 	HIP_TRY(d_out.alloc(bytes));
 	HIP_TRY(hipMemcpy(d_in.p, in, bytes, hipMemcpyHostToDevice));
+	StageTimer tm;
 	launch_fft_forward(plan.p.p, nullptr, d_in.p, SFMT_CF32, 0, nullptr, d_work.as<float2>(), d_out.as<float2>(), shifted != 0, nullptr);
+	tm.stop();
 	HIP_TRY(hipDeviceSynchronize());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpy(out, d_out.p, bytes, hipMemcpyDeviceToHost));
@@ -684,7 +751,8 @@ extern "C" int hfdl_gpu_viterbi27(int device, const uint8_t *soft, int32_t nbits
 	if (!soft || !out || nbits <= 0 || nframes <= 0) return fail(HFDL_GPU_EINVAL, "bad arguments");
 	int rc = select_device(device);
 	if (rc) return rc;
-	rc = demod_viterbi_batch(soft, nbits, nframes, out);
+	g_stage_ms = 0.0;
+	rc = demod_viterbi_batch(soft, nbits, nframes, out, &g_stage_ms);
 	if (rc) return fail(rc, "viterbi batch failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;
 }
@@ -696,7 +764,61 @@ extern "C" int hfdl_gpu_burst_decode(int device, const float *symbols, const int
 	for (int i = 0; i < nframes; i++) if (modes[i] < 0 || modes[i] > 7) return fail(HFDL_GPU_EINVAL, "mode out of range");
 	int rc = select_device(device);
 	if (rc) return rc;
-	rc = demod_burst_decode_batch(symbols, modes, bitmask_lsb, nframes, octets, lens);
+	g_stage_ms = 0.0;
+	rc = demod_burst_decode_batch(symbols, modes, bitmask_lsb, nframes, octets, lens, &g_stage_ms);
 	if (rc) return fail(rc, "burst decode failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
+// decimating_shift_addition_init + decimating_shift_addition_cc (src/libcsdr_gpl.c:26-74) on the device: the NCO / decimator
+// tail of the channelizer kernel as a stage of its own, state carried by the caller exactly like the reference's status struct
+extern "C" int hfdl_gpu_nco_decimate(int device, const float *in, int32_t input_size, float rate, int32_t decimation,
+		int32_t *decimation_remain, float *starting_phase, float *out, int32_t *output_size)
+{
+	if (!in || !decimation_remain || !starting_phase || !out || !output_size || input_size <= 0 || decimation <= 0 || *decimation_remain < 0)
+		return fail(HFDL_GPU_EINVAL, "bad arguments");
+	int rc = select_device(device);
+	if (rc) return rc;
+	float r = rate * (float)decimation;        // decimating_shift_addition_init -> shift_addition_init, fp32 products as written there
+	r *= 2;
+	const float sd = (float)std::sin(r * M_PI), cd = (float)std::cos(r * M_PI);
+	NcoState st{};
+	st.decimation_remain = *decimation_remain; st.starting_phase = *starting_phase;
+	const size_t max_out = ((size_t)input_size + (size_t)decimation - 1) / (size_t)decimation;
+	DevBuf d_in, d_out, d_ph, d_st;
+	HIP_TRY(d_in.alloc(sizeof(float2) * (size_t)input_size));
+	HIP_TRY(d_out.alloc(sizeof(float2) * max_out));
+	HIP_TRY(d_ph.alloc(sizeof(float2) * max_out));
+	HIP_TRY(d_st.alloc(sizeof(NcoState)));
+	HIP_TRY(hipMemcpy(d_in.p, in, sizeof(float2) * (size_t)input_size, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_st.p, &st, sizeof(st), hipMemcpyHostToDevice));
+	launch_nco_decimate(d_in.as<const float2>(), input_size, cd, sd, r, decimation, d_st.as<NcoState>(), d_ph.as<float2>(), d_out.as<float2>(), nullptr);
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpy(&st, d_st.p, sizeof(st), hipMemcpyDeviceToHost));
+	if (st.output_size > 0) HIP_TRY(hipMemcpy(out, d_out.p, sizeof(float2) * (size_t)st.output_size, hipMemcpyDeviceToHost));
+	*decimation_remain = st.decimation_remain; *starting_phase = st.starting_phase; *output_size = st.output_size;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_crc16_ccitt(int device, const uint8_t *data, uint32_t len, uint16_t crc_init, uint16_t *crc)
+{
+	if (!crc || (!data && len)) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	int rc = select_device(device);
+	if (rc) return rc;
+	rc = demod_crc16(data, len, crc_init, crc);
+	if (rc) return fail(rc, "crc16 failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
+extern "C" int hfdl_gpu_pdu_triage(int device, const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride,
+		uint8_t *fcs_status, uint8_t *pdu_kind, uint16_t *hdr_len)
+{
+	if (!octets || !lens || !fcs_status || !pdu_kind || !hdr_len || npdus <= 0 || stride <= 0) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	for (int i = 0; i < npdus; i++) if (lens[i] < 1 || lens[i] > stride) return fail(HFDL_GPU_EINVAL, "PDU %d: length %d outside 1..%d", i, lens[i], stride);
+	int rc = select_device(device);
+	if (rc) return rc;
+	rc = demod_pdu_triage_batch(octets, lens, npdus, stride, fcs_status, pdu_kind, hdr_len);
+	if (rc) return fail(rc, "pdu triage failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;
 }

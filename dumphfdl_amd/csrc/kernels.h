@@ -62,6 +62,8 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 		hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
 		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st, hipEvent_t done = nullptr);
+void launch_nco_decimate(const float2 *in, int input_size, float cosdelta, float sindelta, float rate, int decimation,
+		NcoState *state, float2 *phasor_scratch, float2 *out, hipStream_t st);
 int stream_read_variants();
 void launch_stream_read(int variant, const float2 *src, size_t bytes, float *sink, hipStream_t st);
 

@@ -23,7 +23,7 @@ class Geometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "sample_rate", "decimation", "pre_decimation", "post_decimation", "taps_length", "overlap_length",
         "fft_size", "fft_inv_size", "input_size", "post_input_size", "scrap", "outputs_per_block",
-        "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float)]
+        "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float), ("max_outputs_per_block", C.c_int32)]
 
 
 class Pdu(C.Structure):
@@ -57,8 +57,8 @@ EXPORTS = [
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
-    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe",
-    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode",
+    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
+    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
 
@@ -105,6 +105,12 @@ def load():
     L.hfdl_gpu_fft_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
     L.hfdl_gpu_viterbi27.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.hfdl_gpu_burst_decode.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.hfdl_gpu_frontend_step_period_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.hfdl_gpu_last_stage_ms.restype = C.c_double
+    L.hfdl_gpu_nco_decimate.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                        C.c_void_p, C.POINTER(C.c_int32)]
+    L.hfdl_gpu_crc16_ccitt.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint16, C.POINTER(C.c_uint16)]
+    L.hfdl_gpu_pdu_triage.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -255,6 +261,11 @@ class Frontend:
         _check(load().hfdl_gpu_frontend_fold_time_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def step_period_ms(self):
+        v = C.c_double(0)
+        _check(load().hfdl_gpu_frontend_step_period_ms(self._h, C.byref(v)))
+        return v.value
+
     def stream_read_probe(self):
         v = C.c_double(0)
         _check(load().hfdl_gpu_frontend_stream_read_probe(self._h, C.byref(v)))
@@ -300,3 +311,36 @@ def burst_decode(symbol_list, modes, bitmask_lsb=None, device=0):
     lens = np.zeros(n, np.int32)
     _check(load().hfdl_gpu_burst_decode(device, _p(sym), _p(modes), _p(bm), n, _p(octets), _p(lens)))
     return [bytes(octets[i, :lens[i]]) for i in range(n)]
+
+
+def last_stage_ms():
+    return load().hfdl_gpu_last_stage_ms()
+
+
+def nco_decimate(x, rate, decimation, decimation_remain=0, starting_phase=0.0, device=0):
+    """decimating_shift_addition_cc on the device; returns (out, decimation_remain, starting_phase) -- feed the state back in."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    out = np.zeros((len(x) + decimation - 1) // decimation, np.complex64)
+    rem, ph, n = C.c_int32(decimation_remain), C.c_float(starting_phase), C.c_int32(0)
+    _check(load().hfdl_gpu_nco_decimate(device, _p(x), len(x), rate, decimation, C.byref(rem), C.byref(ph), _p(out), C.byref(n)))
+    return out[:n.value].copy(), rem.value, ph.value
+
+
+def crc16_ccitt(data, crc_init=0xFFFF, device=0):
+    a = np.frombuffer(bytes(data), np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+    crc = C.c_uint16(0)
+    _check(load().hfdl_gpu_crc16_ccitt(device, _p(a), len(data), crc_init, C.byref(crc)))
+    return crc.value
+
+
+def pdu_triage(pdus, device=0):
+    """pdus: list of bytes -> list of (fcs_status, pdu_kind, hdr_len) computed on the device."""
+    n = len(pdus)
+    stride = max(len(p) for p in pdus)
+    octets = np.zeros((n, stride), np.uint8)
+    for i, p in enumerate(pdus):
+        octets[i, :len(p)] = np.frombuffer(bytes(p), np.uint8)
+    lens = np.array([len(p) for p in pdus], np.int32)
+    fcs, kind, hl = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint16)
+    _check(load().hfdl_gpu_pdu_triage(device, _p(octets), _p(lens), n, stride, _p(fcs), _p(kind), _p(hl)))
+    return [(int(fcs[i]), int(kind[i]), int(hl[i])) for i in range(n)]

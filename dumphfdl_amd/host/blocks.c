@@ -1,4 +1,5 @@
 /* blocks.c -- thread-per-block dataflow runtime with the reference's interface (src/block.c:55-193). */
+#include <stdbool.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <unistd.h>
@@ -41,10 +42,32 @@ int32_t block_connect_one2one(struct block *source, struct block *sink)
 	if (!source || !sink || source->producer.type != PRODUCER_SINGLE || sink->consumer.type != CONSUMER_SINGLE ||
 			source->producer.max_tu == 0) return 0;
 	struct block_connection *c = hfdl_xcalloc(1, sizeof(*c));
-	c->circ_buffer.buf = hfdl_ring_create(ring_size_for(source->producer.max_tu, sink->consumer.min_ru));
+	size_t cap = ring_size_for(source->producer.max_tu, sink->consumer.min_ru);
+	size_t blk = hfdl_frontend_block_samples(sink);
+	if (blk > 0) {
+		/* The consumer is the GPU front end: page-locked storage, a whole number of its blocks long, so that every block it
+		 * takes is one contiguous run it can DMA from in place (4 blocks: one in flight, three for the producer to run ahead).
+		 * If the producer is the library's own file input, the ring carries the file's RAW samples (cs16 / cu8 / cf32) and the
+		 * conversion of src/input-helpers.c:33-78 happens on the device; any other producer gets the cf32 ring
+		 * complex_samples_produce() expects. */
+		size_t nblk = (cap + blk - 1) / blk;
+		if (nblk < 4) nblk = 4;
+		c->circ_buffer.buf = hfdl_ring_create_ex(nblk * blk, hfdl_file_input_raw_format(source), 1);
+	} else {
+		c->circ_buffer.buf = hfdl_ring_create(cap);
+	}
 	c->circ_buffer.cond = hfdl_xcalloc(1, sizeof(pthread_cond_t));
 	c->circ_buffer.mutex = hfdl_xcalloc(1, sizeof(pthread_mutex_t));
-	if (pthread_cond_init(c->circ_buffer.cond, NULL) || pthread_mutex_init(c->circ_buffer.mutex, NULL)) return 0;
+	bool cond_ok = pthread_cond_init(c->circ_buffer.cond, NULL) == 0;
+	bool mutex_ok = cond_ok && pthread_mutex_init(c->circ_buffer.mutex, NULL) == 0;
+	if (!mutex_ok) {                 /* release the half-built connection */
+		if (cond_ok) pthread_cond_destroy(c->circ_buffer.cond);
+		hfdl_ring_destroy(c->circ_buffer.buf);
+		free(c->circ_buffer.cond);
+		free(c->circ_buffer.mutex);
+		free(c);
+		return 0;
+	}
 	source->producer.out = sink->consumer.in = c;
 	return 1;
 }
@@ -54,6 +77,8 @@ void block_disconnect_one2one(struct block *source, struct block *sink)
 	if (!source || !sink || source->producer.out != sink->consumer.in || source->producer.out == NULL) return;
 	struct block_connection *c = source->producer.out;
 	hfdl_ring_destroy(c->circ_buffer.buf);
+	pthread_cond_destroy(c->circ_buffer.cond);
+	pthread_mutex_destroy(c->circ_buffer.mutex);
 	free(c->circ_buffer.cond);
 	free(c->circ_buffer.mutex);
 	free(c);
@@ -70,8 +95,15 @@ int32_t block_connect_one2many(struct block *source, size_t sink_count, struct b
 	c->shared_buffer.buf = NULL;
 	c->shared_buffer.data_ready = hfdl_xcalloc(1, sizeof(pthread_barrier_t));
 	c->shared_buffer.consumers_ready = hfdl_xcalloc(1, sizeof(pthread_barrier_t));
-	if (pthread_barrier_init(c->shared_buffer.data_ready, NULL, (unsigned)sink_count + 1) ||
-			pthread_barrier_init(c->shared_buffer.consumers_ready, NULL, (unsigned)sink_count + 1)) return 0;
+	bool b1 = pthread_barrier_init(c->shared_buffer.data_ready, NULL, (unsigned)sink_count + 1) == 0;
+	bool b2 = b1 && pthread_barrier_init(c->shared_buffer.consumers_ready, NULL, (unsigned)sink_count + 1) == 0;
+	if (!b2) {
+		if (b1) pthread_barrier_destroy(c->shared_buffer.data_ready);
+		free(c->shared_buffer.data_ready);
+		free(c->shared_buffer.consumers_ready);
+		free(c);
+		return 0;
+	}
 	source->producer.out = c;
 	int32_t made = 0;
 	for (size_t i = 0; i < sink_count; i++) { sinks[i]->consumer.in = c; made++; }

@@ -9,6 +9,7 @@
 #include <stdbool.h>
 #include <unistd.h>
 #include <pthread.h>
+#include <time.h>
 #include "hfdl_host.h"
 #include "hfdl_gpu.h"
 #include "host_internal.h"
@@ -196,6 +197,31 @@ static void push_pdu(const hfdl_gpu_pdu *p, const struct timeval *t0)
 	pdu_decoder_queue_push(m, octet_string_new(copy, (size_t)p->len), 0);
 }
 
+static struct hfdl_run_stats g_run;
+static pthread_mutex_t g_run_lock = PTHREAD_MUTEX_INITIALIZER;
+
+void hfdl_frontend_run_stats(struct hfdl_run_stats *out)
+{
+	pthread_mutex_lock(&g_run_lock);
+	*out = g_run;
+	pthread_mutex_unlock(&g_run_lock);
+}
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static int gpu_format_of(int ring_fmt)
+{
+	return ring_fmt == SFMT_CS16 ? HFDL_GPU_SFMT_CS16 : ring_fmt == SFMT_CU8 ? HFDL_GPU_SFMT_CU8 : HFDL_GPU_SFMT_CF32;
+}
+
+/* The front-end thread.  A block never gets copied on the host: the ring in front of this block is page-locked and a whole
+ * number of blocks long (block_connect_one2one), so each block is handed to the GPU where it lies -- raw cs16 / cu8 samples
+ * included, which the device converts -- and its slot goes back to the producer once the DMA has read it. */
 static void *frontend_thread(void *ctx)
 {
 	struct block *block = ctx;
@@ -203,8 +229,7 @@ static void *frontend_thread(void *ctx)
 	struct circ_buffer *ring = &block->consumer.in->circ_buffer;
 	struct block_connection *down = block->producer.out;
 	hfdl_gpu_frontend *fe = NULL;
-	float complex *stage[2] = { NULL, NULL };
-	bool stage_pinned = true;
+	void *bounce = NULL;                    /* only for a ring whose blocks are not contiguous (never one made by this library) */
 	hfdl_gpu_pdu *pdus = NULL;
 	hfdl_gpu_channel_stats *stats = NULL;
 	const int32_t max_pdus = 1024;
@@ -220,14 +245,6 @@ static void *frontend_thread(void *ctx)
 	} else {
 		hfdl_gpu_frontend_geometry(fe, &fb->geo);
 		hfdl_gpu_frontend_enable_taps(fe, 0);
-		/* two page-locked staging blocks: block k+1 is read from the ring and copied while block k computes */
-		for (int i = 0; i < 2; i++)
-			if (hfdl_gpu_host_alloc((void **)&stage[i], sizeof(float complex) * (size_t)fb->geo.input_size) != 0) stage_pinned = false;
-		if (!stage_pinned)
-			for (int i = 0; i < 2; i++) {
-				if (stage[i]) hfdl_gpu_host_free(stage[i]);
-				stage[i] = hfdl_xcalloc((size_t)fb->geo.input_size, sizeof(float complex));
-			}
 		pdus = hfdl_xcalloc((size_t)max_pdus, sizeof(*pdus));
 		stats = hfdl_xcalloc(nch, sizeof(*stats));
 	}
@@ -235,7 +252,10 @@ static void *frontend_thread(void *ctx)
 	struct timeval t0;
 	gettimeofday(&t0, NULL);
 	const size_t need = ok ? (size_t)fb->geo.input_size : 1;
-	uint64_t k = 0;
+	const size_t elem = hfdl_ring_elem_size(ring->buf);
+	const int gfmt = gpu_format_of(hfdl_ring_format(ring->buf));
+	uint64_t k = 0, npdus = 0;
+	double t_first = 0, t_last = 0;
 	for (;;) {
 		pthread_mutex_lock(ring->mutex);
 		/* shutdown is honoured only when there is not a whole block left, so buffered samples are flushed (src/fft.c:39-48) */
@@ -243,12 +263,17 @@ static void *frontend_thread(void *ctx)
 			if (block_connection_is_shutdown_signaled(block->consumer.in)) { pthread_mutex_unlock(ring->mutex); goto shutdown; }
 			pthread_cond_wait(ring->cond, ring->mutex);
 		}
-		float complex *blk = stage[k & 1];
-		if (ok) hfdl_ring_read(ring->buf, blk, need); else hfdl_ring_read(ring->buf, (float complex[1]){0}, 1);
-		const bool backlog = hfdl_ring_size(ring->buf) >= need;      /* another whole block is already waiting */
+		const void *blk = ok ? hfdl_ring_peek(ring->buf, 0, need) : NULL;
+		if (ok && blk == NULL) {                    /* a block that wraps around the end of a foreign ring: one copy */
+			if (bounce == NULL) bounce = hfdl_xcalloc(need, sizeof(float complex));
+			hfdl_ring_read(ring->buf, bounce, need);
+		}
+		if (!ok) hfdl_ring_drop(ring->buf, hfdl_ring_size(ring->buf));
+		const bool backlog = hfdl_ring_size(ring->buf) >= 2 * need || (blk == NULL && hfdl_ring_size(ring->buf) >= need);   /* another whole block is already waiting */
 		pthread_mutex_unlock(ring->mutex);
 		if (!ok) continue;
-		if (hfdl_gpu_frontend_push_block(fe, (const float *)blk, need, 0) != 0) {
+		if (k == 0) t_first = now_s();
+		if (hfdl_gpu_frontend_push_block_raw(fe, blk ? blk : bounce, need, blk ? gfmt : HFDL_GPU_SFMT_CF32, 0) != 0) {
 			fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
 			do_exit = 1;
 			ok = 0;
@@ -256,13 +281,23 @@ static void *frontend_thread(void *ctx)
 		}
 		k++;
 		/* Keeping up with the source (live radio): wait for this block and deliver its PDUs at once.  Behind (file
-		 * replay, catching up): leave it running and collect the previous block, so the next ring read and copy overlap it.
-		 * Either way the other staging block is free again: its copy finished before the block now complete started. */
+		 * replay, catching up): leave it running and collect the previous block, so the producer's reads and the copy of
+		 * this block overlap it. */
 		int32_t n = 0;
 		do {
 			if (hfdl_gpu_frontend_poll_pdus_ready(fe, pdus, max_pdus, &n, backlog ? 1 : 0) != 0) break;
 			for (int32_t i = 0; i < n; i++) push_pdu(&pdus[i], &t0);
+			npdus += (uint64_t)n;
 		} while (n == max_pdus);
+		/* the DMA engine has read the block (it started as soon as the staging buffer of two blocks ago was free, and ran
+		 * beside the kernels of the previous block): give the slot back to the producer */
+		if (blk != NULL) {
+			hfdl_gpu_frontend_input_done(fe);
+			pthread_mutex_lock(ring->mutex);
+			hfdl_ring_drop(ring->buf, need);
+			pthread_mutex_unlock(ring->mutex);
+			pthread_cond_signal(ring->cond);
+		}
 		publish_counters(fe, stats, (int32_t)nch);
 	}
 shutdown:
@@ -271,17 +306,31 @@ shutdown:
 		do {                                                             /* drain what the lagging collection left behind */
 			if (hfdl_gpu_frontend_poll_pdus(fe, pdus, max_pdus, &n) != 0) break;
 			for (int32_t i = 0; i < n; i++) push_pdu(&pdus[i], &t0);
+			npdus += (uint64_t)n;
 		} while (n == max_pdus);
+		t_last = now_s();
 		publish_counters(fe, stats, (int32_t)nch);
+		pthread_mutex_lock(&g_run_lock);
+		g_run.blocks = k; g_run.samples = k * (uint64_t)need; g_run.pdus = npdus;
+		g_run.seconds = k ? t_last - t_first : 0.0;
+		g_run.bytes_per_sample = (int32_t)elem; g_run.channels = (int32_t)nch; g_run.block_samples = (int32_t)need;
+		g_run.zero_copy = hfdl_ring_is_pinned(ring->buf);
+		pthread_mutex_unlock(&g_run_lock);
 	}
 	block_connection_one2many_shutdown(down);
 	if (fe) hfdl_gpu_frontend_destroy(fe);
-	for (int i = 0; i < 2; i++) if (stage[i]) { if (stage_pinned) hfdl_gpu_host_free(stage[i]); else free(stage[i]); }
+	free(bounce);
 	free(pdus);
 	free(stats);
 	free(freqs);
 	block->running = false;
 	return NULL;
+}
+
+size_t hfdl_frontend_block_samples(const struct block *sink)
+{
+	if (sink == NULL || sink->thread_routine != frontend_thread) return 0;
+	return (size_t)container_of(sink, struct gpu_fft_block, block)->geo.input_size;
 }
 
 struct block *fft_create(int32_t decimation, float transition_bw)

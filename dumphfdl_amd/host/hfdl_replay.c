@@ -2,7 +2,13 @@
  * I/Q file, with the protocol parsers replaced by the library's printing pdu_decoder_queue_push().
  *
  *   hfdl_replay --iq-file FILE --sample-rate HZ --sample-format CF32|CS16|CU8 --centerfreq KHZ [--device N]
- *               [--statsd-print] [--noise-floor-stats-interval S] FREQ_KHZ...
+ *               [--statsd-print] [--noise-floor-stats-interval S] [--shard R/W] [--bench] [--loop N] FREQ_KHZ...
+ *
+ * --shard R/W   single-stream multi-GPU mode: this process decodes channels R, R+W, R+2W, ... of the list on
+ *               its --device; W processes fed the same file cover all channels, no communication between them.
+ * --bench       PDUs are counted instead of printed and one JSON line reports Msamples/s of the whole host path
+ *               (file in page cache -> input block -> ring -> GPU front end -> pdu_decoder_queue_push), create time excluded.
+ * --loop N      replay the file N times back to back (bench runs longer than the file).
  *
  * --statsd-print stands in for dumphfdl's src/statsd.c: the strong statsd_* hooks below print one "STATSD" line per
  * counter total at exit and one per noise-floor gauge as it arrives (metric names as in doc/STATSD_METRICS.md).
@@ -13,7 +19,31 @@
 #include <unistd.h>
 #include "hfdl_host.h"
 
-static int statsd_print;
+static int statsd_print, bench_mode;
+static unsigned long long bench_pdus, bench_octets;
+
+/* In --bench mode this strong definition replaces the library's printing default: count and free (ownership is ours,
+ * src/pdu.c:37-43, 171-172).  Otherwise print the same line as the library's default so the output stays comparable. */
+void pdu_decoder_queue_push(struct metadata *metadata, struct octet_string *pdu, uint32_t flags)
+{
+	(void)flags;
+	if (metadata == NULL || pdu == NULL) return;
+	if (bench_mode) {
+		bench_pdus++;
+		bench_octets += pdu->len;
+	} else {
+		struct hfdl_pdu_metadata *hm = (struct hfdl_pdu_metadata *)metadata;      /* metadata is its first member */
+		printf("PDU freq=%d bit_rate=%d slot=%c freq_err=%.2f rssi=%.1f nf=%.1f ts=%ld.%06ld len=%zu ",
+				hm->freq, hm->bit_rate, hm->slot, hm->freq_err_hz, hm->rssi, hm->noise_floor,
+				(long)metadata->rx_timestamp.tv_sec, (long)metadata->rx_timestamp.tv_usec, pdu->len);
+		for (size_t i = 0; i < pdu->len; i++) printf("%02x", pdu->buf[i]);
+		printf("\n");
+		fflush(stdout);
+	}
+	octet_string_destroy(pdu);
+	metadata->vtable->destroy(metadata);
+}
+
 static struct tally { int32_t freq; unsigned a2, m1, m1_missing; } tallies[4096];
 static int ntallies;
 
@@ -46,7 +76,7 @@ int main(int argc, char **argv)
 	cfg->type = INPUT_TYPE_FILE;
 	double centerfreq_khz = -1;
 	int32_t freqs[4096];
-	int nfreq = 0;
+	int nfreq = 0, shard_rank = 0, shard_world = 1;
 	for (int i = 1; i < argc; i++) {
 		if (!strcmp(argv[i], "--iq-file") && i + 1 < argc) cfg->source = argv[++i];
 		else if (!strcmp(argv[i], "--sample-rate") && i + 1 < argc) cfg->sample_rate = atoi(argv[++i]);
@@ -55,6 +85,14 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "--read-buffer-size") && i + 1 < argc) cfg->read_buffer_size = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--device") && i + 1 < argc) hfdl_frontend_set_device(atoi(argv[++i]));
 		else if (!strcmp(argv[i], "--statsd-print")) statsd_print = 1;
+		else if (!strcmp(argv[i], "--bench")) bench_mode = 1;
+		else if (!strcmp(argv[i], "--loop") && i + 1 < argc) hfdl_file_input_set_loops(atoi(argv[++i]));
+		else if (!strcmp(argv[i], "--shard") && i + 1 < argc) {
+			if (sscanf(argv[++i], "%d/%d", &shard_rank, &shard_world) != 2 || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) {
+				fprintf(stderr, "--shard wants RANK/WORLD with 0 <= RANK < WORLD\n");
+				return 1;
+			}
+		}
 		else if (!strcmp(argv[i], "--noise-floor-stats-interval") && i + 1 < argc) hfdl_nf_stats_set_interval(atoi(argv[++i]));
 		else if (argv[i][0] != '-' && nfreq < 4096) freqs[nfreq++] = (int32_t)(1e3 * atof(argv[i]));     /* kHz -> Hz, src/main.c:197-212 */
 		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
@@ -69,6 +107,12 @@ int main(int argc, char **argv)
 		cfg->centerfreq = lo + (hi - lo) / 2;
 	} else {
 		cfg->centerfreq = (int32_t)(1e3 * centerfreq_khz);
+	}
+	if (shard_world > 1) {           /* round-robin channel partition; the centre frequency above is the whole list's, shared by all shards */
+		int kept = 0;
+		for (int i = 0; i < nfreq; i++) if (i % shard_world == shard_rank) freqs[kept++] = freqs[i];
+		nfreq = kept;
+		if (nfreq == 0) { fprintf(stderr, "shard %d/%d holds no channel\n", shard_rank, shard_world); return 1; }
 	}
 	struct block *input = input_create(cfg);
 	if (input == NULL || input_init(input) < 0) { fprintf(stderr, "Unable to initialize input\n"); return 1; }
@@ -88,6 +132,16 @@ int main(int argc, char **argv)
 	if (hfdl_nf_stats_thread_start(channels, nfreq) < 0) return 1;             /* src/main.c:777-783 */
 	while (block_is_running(input) || block_is_running(fft) || block_set_is_any_running((size_t)nfreq, channels)) usleep(20000);
 	hfdl_print_summary();
+	if (bench_mode) {
+		struct hfdl_run_stats rs;
+		hfdl_frontend_run_stats(&rs);
+		printf("{\"tool\": \"hfdl_replay --bench\", \"value\": %.3f, \"unit\": \"Msamples/s\", \"samples\": %llu, \"blocks\": %llu, \"seconds\": %.6f, "
+				"\"pdus\": %llu, \"pdu_octets\": %llu, \"channels\": %d, \"block_samples\": %d, \"bytes_per_sample_over_pcie\": %d, \"zero_copy_ring\": %s, "
+				"\"shard\": \"%d/%d\", \"path\": \"file (page cache) -> file input (parallel pread into the page-locked ring) -> GPU front-end block -> pdu_decoder_queue_push\"}\n",
+				rs.seconds > 0 ? (double)rs.samples / rs.seconds / 1e6 : 0.0, (unsigned long long)rs.samples, (unsigned long long)rs.blocks, rs.seconds,
+				bench_pdus, bench_octets, rs.channels, rs.block_samples, rs.bytes_per_sample, rs.zero_copy ? "true" : "false", shard_rank, shard_world);
+		fflush(stdout);
+	}
 	if (statsd_print)
 		for (int i = 0; i < ntallies; i++)
 			fprintf(stderr, "STATSD counter %d A2_found=%u M1_found=%u M1_not_found=%u\n", tallies[i].freq, tallies[i].a2, tallies[i].m1, tallies[i].m1_missing);

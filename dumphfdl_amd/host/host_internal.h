@@ -17,4 +17,20 @@ struct hfdl_channel_slot {
 };
 size_t hfdl_channels_on_connection(struct block_connection *conn, struct hfdl_channel_slot **out, size_t max);
 
+/* ring extensions (ring.c): raw-sample elements, page-locked storage, in-place producer / consumer access */
+struct hfdl_ring *hfdl_ring_create_ex(size_t capacity, int fmt, int want_pinned);
+size_t hfdl_ring_capacity(const struct hfdl_ring *r);
+size_t hfdl_ring_elem_size(const struct hfdl_ring *r);
+int    hfdl_ring_format(const struct hfdl_ring *r);
+int    hfdl_ring_is_pinned(const struct hfdl_ring *r);
+size_t hfdl_ring_write_acquire(struct hfdl_ring *r, void **ptr);
+size_t hfdl_ring_write_commit(struct hfdl_ring *r, size_t bytes);
+void   hfdl_ring_discard_partial(struct hfdl_ring *r);
+const void *hfdl_ring_peek(const struct hfdl_ring *r, size_t offset, size_t n);
+size_t hfdl_ring_drop(struct hfdl_ring *r, size_t n);
+
+/* what block_connect_one2one() asks its two ends (0 / SFMT_CF32 for blocks that are not the library's own) */
+size_t hfdl_frontend_block_samples(const struct block *sink);      /* input_size if `sink` is the GPU front-end block, else 0 */
+int    hfdl_file_input_raw_format(const struct block *source);     /* the file's sample_format if `source` is the file input, else SFMT_CF32 */
+
 #define container_of(ptr, type, member) ((type *)((char *)(ptr) - offsetof(type, member)))

@@ -31,3 +31,24 @@ def reduce_job(elapsed_s, samples, pdus, dist=None, device="cpu"):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), int(c[0].item()), int(c[1].item())
+
+
+def reduce_sums(values, dist=None, device="cpu"):
+    """Sum each of `values` (ints) over the ranks."""
+    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [int(v) for v in values]
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]
+
+
+def gather_ints(value, dist=None, device="cpu"):
+    """One int per rank, in rank order, on every rank (a one-hot sum: no object collectives needed on RCCL)."""
+    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [int(value)]
+    import torch
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]

@@ -16,6 +16,9 @@
  *   fft_destroy / hfdl_channel_destroy             src/fft.h:32, src/hfdl.h:13          -> hfdl_gpu_frontend_destroy
  *   csdr_fft_execute(fwd)+fft_swap_sides           src/fft_fftw.c:39-41, src/fastddc.c:102 -> hfdl_gpu_fft_forward
  *   update_viterbi27_blk + chainback_viterbi27     src/libfec/fec.h:19-20               -> hfdl_gpu_burst_decode / hfdl_gpu_viterbi27
+ *   decimating_shift_addition_init / _cc           src/libcsdr_gpl.h:43-44, src/libcsdr_gpl.c:26-74 -> hfdl_gpu_nco_decimate
+ *   crc16_ccitt                                    src/crc.h, src/crc.c:4-47            -> hfdl_gpu_crc16_ccitt
+ *   hfdl_pdu_fcs_check + header length rules       src/pdu.c:68-79, src/mpdu.c:56-79, src/spdu.c:55-62 -> hfdl_gpu_pdu_triage
  *
  * All functions return 0 on success or a negative HFDL_GPU_E* code (the reference's constructors
  * return NULL / -1 and xcalloc failure _exit()s: src/util.c:25-33); hfdl_gpu_last_error() gives text.
@@ -62,6 +65,9 @@ typedef struct {
 	int32_t fold_slices;             /* alias-row slices per channel in the fold kernel */
 	float   transition_bw;
 	float   resamp_rate;             /* 5400 / (fs / decimation) */
+	int32_t max_outputs_per_block;   /* ceil(post_input_size / post_decimation): what a block can emit when the carried
+	                                    decimation remainder is non-zero (post_input_size not a multiple of post_decimation);
+	                                    size HFDL_GPU_TAP_CHAN_OUT buffers from this */
 } hfdl_gpu_geometry;
 
 /* one decoded PDU: what dispatch_pdu() hands to pdu_decoder_queue_push (src/hfdl.c:1058-1080,
@@ -105,8 +111,9 @@ int  hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_geometry *
 /* Enqueue one block: exactly geometry.input_size new complex samples (interleaved I,Q float32).  Asynchronous.
  * on_device != 0: `iq` is a device pointer that stays valid until the next sync.
  * on_device == 0: the host -> device copy runs on its own stream into one of two staging buffers, so the copy of block
- *   k+1 overlaps the kernels of block k.  A pageable buffer may be reused as soon as the call returns; a page-locked
- *   one (hfdl_gpu_host_alloc) only after hfdl_gpu_frontend_input_done() / _sync() / _poll_pdus(). */
+ *   k+1 overlaps the kernels of block k.  A buffer from hfdl_gpu_host_alloc() (page-locked) is read by DMA after the call
+ *   returns: reuse it only after hfdl_gpu_frontend_input_done() / _sync() / _poll_pdus().  Any other host buffer (pageable,
+ *   or registered by the caller) is waited for inside the call and may be reused as soon as it returns. */
 int  hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
 /* wait until every host -> device input copy enqueued so far has finished (the kernels keep running) */
 int  hfdl_gpu_frontend_input_done(hfdl_gpu_frontend *fe);
@@ -120,7 +127,8 @@ int  hfdl_gpu_frontend_push_block_raw(hfdl_gpu_frontend *fe, const void *raw, si
 /* run only the channelizer part of a block (forward FFT + fold + inverse FFT + NCO); for stage parity/bench */
 int  hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
 int  hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe);
-/* Collect PDUs produced by all blocks enqueued so far (implies a sync). Returns count in *n. */
+/* Collect PDUs produced by all blocks enqueued so far (implies a sync). Returns count in *n.  `out` must hold `max`
+ * entries; out == NULL with max > 0 is HFDL_GPU_EINVAL (nothing is discarded), max == 0 just syncs. */
 int  hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n);
 /* Same without draining the pipeline: with max_in_flight = 1 the newest block keeps running; the call waits only for
  * the block before it and returns what had been decoded when that one finished (nothing until two blocks were pushed).
@@ -161,7 +169,7 @@ int  hfdl_gpu_frontend_all_channel_stats(hfdl_gpu_frontend *fe, hfdl_gpu_channel
 enum {
 	HFDL_GPU_TAP_SPECTRUM = 1,       /* cf32[fft_size], fftshifted forward FFT (shared.buf after src/fft.c:59) */
 	HFDL_GPU_TAP_FILTER = 2,         /* cf32[fft_size], filtertaps_fft of `channel` */
-	HFDL_GPU_TAP_CHAN_OUT = 3,       /* cf32[outputs_per_block], fastddc_inv_cc output of `channel` */
+	HFDL_GPU_TAP_CHAN_OUT = 3,       /* cf32[<= max_outputs_per_block], fastddc_inv_cc output of `channel` */
 	HFDL_GPU_TAP_RESAMPLED = 4,      /* cf32[n], msresamp output of the last block */
 	HFDL_GPU_TAP_MF_OUT = 5,         /* cf32[n], AGC + matched filter output of the last block */
 	HFDL_GPU_TAP_SYMBOLS = 6,        /* cf32[n], equalised on-time symbols of the last block */
@@ -177,6 +185,9 @@ int  hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel
 /* timing of the dominant kernel (fold) measured with HIP events on the front end's stream */
 int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
 int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
+/* steady-state period of one block: (start of the last timed fold launch - start of the first) / (launches - 1), free of
+ * the pipeline fill before the first block and the demodulator / burst-decoder drain after the last */
+int  hfdl_gpu_frontend_step_period_ms(hfdl_gpu_frontend *fe, double *period_ms);
 /* what the board's HBM delivers to a read-only streaming kernel with the fold's access pattern (reads the resident taps) */
 int  hfdl_gpu_frontend_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_per_s);
 
@@ -190,6 +201,23 @@ int  hfdl_gpu_viterbi27(int device, const uint8_t *soft, int32_t nbits, int32_t 
  * bitmask bit per frame; octets = nframes * HFDL_GPU_PDU_MAX_OCTETS, lens[nframes] */
 int  hfdl_gpu_burst_decode(int device, const float *symbols, const int32_t *modes, const int32_t *bitmask_lsb,
 		int32_t nframes, uint8_t *octets, int32_t *lens);
+
+/* decimating_shift_addition_cc(input, output, input_size, decimating_shift_addition_init(rate, decimation), decimation, status)
+ * (src/libcsdr_gpl.c:26-74): out[k] = in[remain + decimation k] e^{j phi_k} with the reference's fp32 phasor recurrence; the
+ * status fields (*decimation_remain, *starting_phase) are read and updated, *output_size receives k.  `out` holds
+ * ceil(input_size / decimation) complex samples.  This is the device code the channelizer runs after its inverse FFT. */
+int  hfdl_gpu_nco_decimate(int device, const float *in, int32_t input_size, float rate, int32_t decimation,
+		int32_t *decimation_remain, float *starting_phase, float *out, int32_t *output_size);
+/* crc16_ccitt(data, len, crc_init) of src/crc.c:4-47, computed by the device function the burst decoder checks every FCS with */
+int  hfdl_gpu_crc16_ccitt(int device, const uint8_t *data, uint32_t len, uint16_t crc_init, uint16_t *crc);
+/* header triage of `npdus` decoded PDUs, PDU i = octets[i * stride .. + lens[i]): fcs_status[i] = HFDL_GPU_FCS_*,
+ * pdu_kind[i] = HFDL_GPU_KIND_*, hdr_len[i] = octets covered by the FCS (what burst decoding fills into hfdl_gpu_pdu) */
+int  hfdl_gpu_pdu_triage(int device, const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride,
+		uint8_t *fcs_status, uint8_t *pdu_kind, uint16_t *hdr_len);
+
+/* kernel time in ms of the last hfdl_gpu_fft_forward / _viterbi27 / _burst_decode call made by this thread (HIP events
+ * around the launch; allocation and host <-> device copies excluded) */
+double hfdl_gpu_last_stage_ms(void);
 
 const char *hfdl_gpu_last_error(void);
 int  hfdl_gpu_device_count(void);

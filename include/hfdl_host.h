@@ -182,6 +182,19 @@ void statsd_gauge_per_channel_set(int32_t freq, char *gauge, size_t value);
 /* GPU selection for the front end created by the next fft_create() (default 0); not in the reference */
 void          hfdl_frontend_set_device(int device);
 
+/* What the front-end thread did, readable once its block has stopped running (not in the reference; hfdl_replay --bench):
+ * seconds runs from the first block handed to the GPU to the last PDU handed to pdu_decoder_queue_push(). */
+struct hfdl_run_stats {
+	uint64_t blocks, samples, pdus;
+	double seconds;
+	int32_t bytes_per_sample;        /* of the samples as they crossed PCIe: 8 cf32, 4 cs16, 2 cu8 (converted on the device) */
+	int32_t channels, block_samples;
+	int32_t zero_copy;               /* 1: blocks were DMA'd straight out of the page-locked input ring */
+};
+void          hfdl_frontend_run_stats(struct hfdl_run_stats *out);
+/* replay a regular input file this many times back to back (default 1); not in the reference */
+void          hfdl_file_input_set_loops(int loops);
+
 /* ------------------------------------------------------------------ downstream hand-off (src/pdu.h, metadata.h, util.h) */
 
 struct metadata_vtable;

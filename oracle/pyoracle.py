@@ -44,12 +44,26 @@ class TapsView(C.Structure):
 SINK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Pdu))
 
 
+_build_kind = "strict"
+
+
+def select_build(kind):
+    """"strict" (default: -ffp-contract=off, no fast-math -- the build every parity check uses) or "fast" (the reference's
+    release flags, -O3 -ffast-math: bench.py's cpu_baseline timing only).  Close every Frontend / Channel made with the
+    previous build before switching: their handles belong to the library that made them."""
+    global _build_kind, _lib
+    assert kind in ("strict", "fast")
+    if kind != _build_kind:
+        _build_kind, _lib = kind, None
+
+
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+    name = "liboracle.so" if _build_kind == "strict" else "liboracle_fast.so"
+    so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in ("csdr_restated.c", "fec_restated.c", "channel_restated.c", "hfdl_oracle.h")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, name], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src"):
         ref = os.path.join(_HERE, "_ref", "libhfdl_ref.so")
         if force or not os.path.exists(ref):

@@ -2,12 +2,15 @@
  *   host_check ring                       ring wrap-around / overrun behaviour
  *   host_check file PATH FMT BUFSIZE OUT  file input -> ring -> this consumer; converted cf32 samples written to OUT
  *   host_check graph                      connect/return-value contract of the block graph and channel slots
- *   host_check plugin                     an input registered with input_vtable_register() (the SoapySDR slot) feeds the ring */
+ *   host_check plugin                     an input registered with input_vtable_register() (the SoapySDR slot) feeds the ring
+ *   host_check direct PATH FMT OUT LOOPS  file input -> ring in front of the GPU front-end block (fft_create(), never started):
+ *                                         the ring carries the file's RAW samples, this consumer takes them in place */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 #include "hfdl_host.h"
+#include "host_internal.h"       /* the in-place ring accessors the front-end block uses (library-private) */
 
 static int check_ring(void)
 {
@@ -68,6 +71,54 @@ static int check_file(const char *path, const char *fmt, int bufsize, const char
 	while (block_is_running(in)) usleep(1000);
 	struct input *ip = (struct input *)in;
 	printf("samples %zu max_tu %zu bytes_per_sample %d full_scale %.3f\n", total, in->producer.max_tu, ip->bytes_per_sample, ip->full_scale);
+	return 0;
+}
+
+static int check_direct(const char *path, const char *fmt, const char *out_path, int loops)
+{
+	struct input_cfg *cfg = input_cfg_create();
+	cfg->type = INPUT_TYPE_FILE;
+	cfg->source = (char *)path;
+	cfg->sfmt = sample_format_from_string(fmt);
+	cfg->sample_rate = 250000;
+	hfdl_file_input_set_loops(loops);
+	struct block *in = input_create(cfg);
+	if (in == NULL || input_init(in) < 0) return 1;
+	struct block *fft = fft_create(compute_fft_decimation_rate(250000, 5400), compute_filter_relative_transition_bw(250000, 250));
+	if (fft == NULL) return 2;
+	if (block_connect_one2one(in, fft) != 1) return 3;
+	struct circ_buffer *cb = &fft->consumer.in->circ_buffer;
+	const size_t blk = hfdl_frontend_block_samples(fft), elem = hfdl_ring_elem_size(cb->buf);
+	if (blk != 28672 || hfdl_ring_capacity(cb->buf) % blk != 0 || hfdl_ring_capacity(cb->buf) < 4 * blk) return 4;
+	if (hfdl_ring_format(cb->buf) != (int)cfg->sfmt || elem != get_sample_size(cfg->sfmt)) return 5;
+	float complex one = 1;
+	if (elem != 8 && hfdl_ring_write(cb->buf, &one, 1) != 0) return 6;      /* a raw ring refuses cf32 writes */
+	FILE *out = fopen(out_path, "wb");
+	if (block_start(in) != 1) return 7;
+	size_t total = 0, blocks = 0;
+	for (;;) {
+		pthread_mutex_lock(cb->mutex);
+		while (hfdl_ring_size(cb->buf) < blk && !block_connection_is_shutdown_signaled(fft->consumer.in)) pthread_cond_wait(cb->cond, cb->mutex);
+		size_t have = hfdl_ring_size(cb->buf);
+		size_t take = have >= blk ? blk : have;             /* the tail shorter than a block (the front end leaves it unread) */
+		const void *p = take ? hfdl_ring_peek(cb->buf, 0, take) : NULL;
+		int done = have < blk && block_connection_is_shutdown_signaled(fft->consumer.in);
+		pthread_mutex_unlock(cb->mutex);
+		if (take && p == NULL) return 8;                     /* whole blocks never wrap */
+		if (take) fwrite(p, elem, take, out);
+		pthread_mutex_lock(cb->mutex);
+		hfdl_ring_drop(cb->buf, take);
+		pthread_mutex_unlock(cb->mutex);
+		pthread_cond_signal(cb->cond);
+		total += take;
+		if (take == blk) blocks++;
+		if (done) break;
+	}
+	fclose(out);
+	while (block_is_running(in)) usleep(1000);
+	printf("samples %zu blocks %zu elem %zu capacity %zu pinned %d\n", total, blocks, elem, hfdl_ring_capacity(cb->buf), hfdl_ring_is_pinned(cb->buf));
+	block_disconnect_one2one(in, fft);
+	fft_destroy(fft);
 	return 0;
 }
 
@@ -185,6 +236,7 @@ int main(int argc, char **argv)
 	else if (argc >= 6 && !strcmp(argv[1], "file")) rc = check_file(argv[2], argv[3], atoi(argv[4]), argv[5]);
 	else if (argc >= 2 && !strcmp(argv[1], "graph")) rc = check_graph();
 	else if (argc >= 2 && !strcmp(argv[1], "plugin")) rc = check_plugin();
+	else if (argc >= 6 && !strcmp(argv[1], "direct")) rc = check_direct(argv[2], argv[3], argv[4], atoi(argv[5]));
 	if (rc) fprintf(stderr, "host_check %s failed at step %d\n", argc > 1 ? argv[1] : "?", rc);
 	return rc;
 }

@@ -1,11 +1,20 @@
-// hostsim.cpp -- TEST HARNESS ONLY: compiles the product's demod_core.h / demod_tables.h / planner.h with g++
-// (one "lane") so the demodulator's control logic and the host-side planner can be checked against the oracle
-// on a machine without a GPU.  Never linked into libhfdl_gpu.so; nothing in dumphfdl_amd/ calls it.
+// hostsim.cpp -- TEST HARNESS ONLY: compiles the product's demod_logic.h (device code: modem, framer FSM, header triage),
+// demod_tables.h and planner.h with g++ so the demodulator's control logic and the host-side planner can be checked
+// against the oracle on a machine without a GPU.  The device qualifiers and the four HIP names demod_logic.h uses are
+// defined HERE (the product headers carry no host branch); the block loop around the logic is tests/hostsim/serial_demod.h.
+// Never linked into libhfdl_gpu.so; nothing in dumphfdl_amd/ calls it.
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <complex>
-#include "../../dumphfdl_amd/csrc/demod_core.h"
+// ---- shims for compiling device code on the host (one "lane")
+#define __device__
+#define __host__
+static const struct { unsigned x; } threadIdx = { 0 };
+static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+#include "serial_demod.h"
 #include "../../dumphfdl_amd/csrc/demod_tables.h"
 #include "../../dumphfdl_amd/csrc/planner.h"
 
@@ -54,7 +63,7 @@ int sim_block(Sim *s, const float *in, int n_in, FrameRec *frames_out, float *sy
 	io.tap_resampled = s->tap_rs.data(); io.tap_mf = s->tap_mf.data(); io.tap_symbols = s->tap_sym.data();
 	io.tap_level = s->tap_lvl.data(); io.tap_counts = s->tap_counts; io.channel = 0;
 	s->frame_count = 0;
-	demod_block(s->st.s, s->st.a, s->K, io, (const cf *)in, n_in);
+	demod_block_serial(s->st.s, s->st.a, s->K, io, (const cf *)in, n_in);
 	for (int i = 0; i < s->frame_count; i++) {
 		frames_out[i] = s->frames[i];
 		std::memcpy(symbols_out + (size_t)i * 2 * MAX_DATA_SYMBOLS, s->data.data() + (size_t)s->frames[i].slot * MAX_DATA_SYMBOLS,

@@ -1,0 +1,137 @@
+"""BASELINE.json configurations at their full workload size, through the C ABI on one MI355X:
+configs[3] (burst-dense, 256 channels x 40 Msps) and the N > 1 launch path of configs[4] (two ranks sharing the one GPU of
+the test box, gloo for the barrier / reduction -- the data path has no collective)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from dumphfdl_amd import synth
+from dumphfdl_amd import frontend as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RMS_TOL = 1e-4
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.complex128)
+    b = np.asarray(b, np.complex128)
+    return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / max(np.mean(np.abs(b) ** 2), 1e-300)))
+
+
+def test_full_size_cfg4_burst_dense(gpu, oracle):
+    """BASELINE.json configs[3] as bench.py runs it: 256 channels x 40 Msps, every channel back-to-back bursts cycling all
+    eight modes, 32 blocks (235 M samples).  Every PDU carries a sent payload with its mode and a good on-device FCS,
+    nothing is dropped, each channel delivers all of its bursts that end inside the stretch, and an 8-channel oracle
+    subset yields the identical (freq, sample_index, mode, octets) set and channelizer output."""
+    sys.path.insert(0, ROOT)
+    import bench
+    w = dict(bench.WORKLOADS["cfg4"])
+    freqs = bench.channel_plan(w)
+    fe = gpu.Frontend(w["fs"], w["centerfreq"], freqs)
+    g = fe.geometry
+    assert (g.channels, g.fft_size, g.fft_inv_size, g.input_size) == (256, 1 << 23, 4096, 7340032)
+    x, bursts = bench.make_input(w, g.input_size, 0, 1)
+    nblk = len(x) // g.input_size
+    assert nblk >= 32 and {b["mode"] for b in bursts} == set(range(8))
+    sub = [0, 37, 90, 127, 128, 171, 222, 255]
+    ora = oracle.Frontend(w["fs"], w["centerfreq"], [freqs[c] for c in sub], nthreads=8)
+    fe.enable_taps(False)
+    pdus, worst = [], 0.0
+    for b in range(nblk):
+        blk = x[b * g.input_size:(b + 1) * g.input_size]
+        fe.push_block(blk)
+        ora.push_block(blk, nthreads=8)
+        if b in (0, 9, nblk - 1):
+            for i, c in enumerate(sub):
+                worst = max(worst, rel_rms(fe.read_tap(F.TAP_CHAN_OUT, c), ora.channel_view(i)["chan_out"]))
+        elif b % 4 == 3:
+            pdus += fe.poll_pdus(max_in_flight=1)          # the pipelined collection path, as the C host uses it
+    pdus += fe.poll_pdus()
+    cnt = fe.counters()
+    assert cnt["pdus_dropped"] == 0 and cnt["pdus_taken"] == len(pdus) and cnt["blocks"] == nblk
+    assert worst < RMS_TOL, worst
+    by_freq = {}
+    for b in bursts:
+        by_freq.setdefault(b["freq"], []).append(b)
+    seen_modes = set()
+    per_chan = {f: 0 for f in freqs}
+    for p in pdus:
+        match = [b for b in by_freq[p["freq"]] if p["octets"][:len(b["octets"])] == b["octets"]]
+        assert len(match) == 1 and match[0]["mode"] == p["mode"], (p["freq"], p["mode"])
+        assert len(p["octets"]) == synth.mode_sizes(p["mode"])["octets"]
+        assert p["fcs_status"] == F.FCS_GOOD
+        assert p["slot"] == ("D" if p["mode"] >= 4 else "S")
+        seen_modes.add(p["mode"])
+        per_chan[p["freq"]] += 1
+    assert seen_modes == set(range(8))
+    # every burst of every channel whose last symbol (+ the demodulator's pipeline delay) lies inside the stretch was decoded once
+    dur = len(x) / w["fs"]
+    for f in freqs:
+        due = [b for b in by_freq[f] if b["t0"] + synth.burst_symbols_len(b["mode"]) / 1800 < dur - 0.06]
+        assert len(due) <= per_chan[f] <= len(by_freq[f]), (f, len(due), per_chan[f])
+    assert len(pdus) >= 300
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    got8 = sorted(key(p) for p in pdus if p["channel"] in sub)
+    assert got8 == sorted(key(p) for p in ora.pdus) and len(got8) >= 8
+    # trellis work of the run (decoded bits per frame x 64 ACS)
+    steps = sum(synth.mode_sizes(p["mode"])["nbits"] for p in pdus)
+    assert steps > 500_000
+    fe.close()
+
+
+def test_two_rank_bench_on_one_gpu():
+    """The `bench.py --gpus N` launch path exactly as the driver starts it (torch.distributed.run, one process per rank),
+    with N = 2 on the single GPU of the test box: ranks take stream seeds 5 and 6 (BASELINE.json configs[4]), rank 0 prints
+    ONE JSON line whose sample count is the sum over ranks and whose time is the max; every PDU of both ranks matches a
+    payload its own stream carried."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 8 and r["warmup"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["stream_seeds"] == [5, 6]
+    block = r["config"]["block_samples"]
+    assert r["config"]["channels"] == 256 and block == 7340032
+    samples = 2 * 8 * block
+    assert abs(r["value"] * 1e6 * (r["ms_per_step"] * 8e-3) - samples) < 1e-6 * samples
+    assert r["pdus_in_timed_region"] > 0
+    assert r["pdus_matching_sent_payload"] == r["pdus_in_timed_region"]
+    assert r["roofline"]["launches"] == 8 and 0.05 < r["roofline"]["frac"] < 1.0
+    assert "cpu_baseline" not in r                       # rank 0 at N = 1 only
+
+
+def test_poll_sequence_drain_then_snapshot(gpu):
+    """hfdl_gpu_frontend_poll_pdus (drain) followed by hfdl_gpu_frontend_poll_pdus_ready(.., 1) with no push in between: the
+    snapshot is older than what was already taken -- nothing may be delivered twice and the ring must keep working."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_930_000, 10_037_000]
+    bursts = synth.plan_traffic(freqs, 9.0, seed=31, dense=True)
+    x = synth.synth_wideband(fs, cf, int(9.0 * fs), bursts, noise_sigma=0.01, seed=31)
+    fe = gpu.Frontend(fs, cf, freqs)
+    n = fe.input_size
+    got = []
+    for b in range(len(x) // n):
+        fe.push_block(x[b * n:(b + 1) * n])
+        got += fe.poll_pdus()                         # drain: taken == produced
+        again = fe.poll_pdus(max_in_flight=1)         # stale snapshot (the block before): must yield nothing
+        assert again == []
+    cnt = fe.counters()
+    assert cnt["pdus_dropped"] == 0 and cnt["pdus_taken"] == len(got) == len(bursts)
+    keys = [(p["freq"], p["sample_index"]) for p in got]
+    assert len(set(keys)) == len(keys)
+    # a NULL buffer with max > 0 is an argument error and discards nothing
+    import ctypes as C
+    L = F.load()
+    k = C.c_int32(0)
+    assert L.hfdl_gpu_frontend_poll_pdus(fe._h, None, 4, C.byref(k)) == -1
+    assert L.hfdl_gpu_frontend_poll_pdus_ready(fe._h, None, 4, C.byref(k), 1) == -1
+    fe.close()

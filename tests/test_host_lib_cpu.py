@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "dumphfdl_amd")
 def host_check(tmp_path_factory):
     subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "host")])
     exe = str(tmp_path_factory.mktemp("hc") / "host_check")
-    subprocess.check_call(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "include"),
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "host"),
                            os.path.join(ROOT, "tests", "hostsim", "host_check.c"), "-o", exe,
                            "-L", PKG, "-lhfdl_host", "-lhfdl_gpu", "-Wl,-rpath," + PKG, "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-lm"])
     return exe
@@ -57,6 +57,25 @@ def test_file_input_conversion(host_check, tmp_path, fmt, bufsize):
     got = np.fromfile(dst, np.complex64)
     assert len(got) == n and np.array_equal(got, want)
     assert ("max_tu %d " % (bufsize // {"CF32": 8, "CS16": 4, "CU8": 2}[fmt])) in out.stdout
+
+
+@pytest.mark.parametrize("fmt,loops", [("CS16", 1), ("CU8", 1), ("CF32", 1), ("CS16", 3)])
+def test_file_input_direct_into_frontend_ring(host_check, tmp_path, fmt, loops):
+    """In front of the GPU front-end block the ring carries the file's RAW samples (the device converts them), is a whole
+    number of front-end blocks long, and the file is read straight into it: what the consumer sees in place is the file,
+    byte for byte (x loops), with an odd trailing fragment of a sample dropped at end of file (whole_samples())."""
+    rng = np.random.default_rng(9)
+    bps = {"CF32": 8, "CS16": 4, "CU8": 2}[fmt]
+    n = 3 * 28672 + 12345
+    raw = rng.integers(0, 256, n * bps + (3 if bps > 2 else 1), dtype=np.uint8)       # trailing fragment of a sample
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+    raw.tofile(src)
+    out = subprocess.run([host_check, "direct", str(src), fmt, str(dst), str(loops)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    got = np.fromfile(dst, np.uint8)
+    want = np.tile(raw[:n * bps], loops)
+    assert len(got) == len(want) and np.array_equal(got, want)
+    assert ("samples %d blocks %d elem %d " % (n * loops, n * loops // 28672, bps)) in out.stdout
 
 
 def test_file_input_rejects_bad_config(host_check, tmp_path):

@@ -21,9 +21,11 @@ def _worker(rank, world, port, q):
     seed = shard.stream_seed(3, r, w)
     # every rank "processes" 10 blocks of its own stream; rank 1 is slower
     elapsed, samples, pdus = shard.reduce_job(0.5 + 0.25 * r, 10 * 917504, 7 + r, dist)
+    sums = shard.reduce_sums([3 + r, 100 * (r + 1)], dist)
+    seeds = shard.gather_ints(seed, dist)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((r, w, mine, seed, elapsed, samples, pdus))
+    q.put((r, w, mine, seed, elapsed, samples, pdus, sums, seeds))
 
 
 def test_two_rank_sharding_and_reduction():
@@ -49,6 +51,7 @@ def test_two_rank_sharding_and_reduction():
     assert (a[3], b[3]) == (5, 6)                                                     # independent stream seeds
     for r in res:
         assert r[4] == pytest.approx(0.75) and r[5] == 2 * 10 * 917504 and r[6] == 15  # max time, summed work
+        assert r[7] == [7, 300] and r[8] == [5, 6]                                     # summed checks, seeds in rank order on every rank
 
 
 def test_single_rank_is_passthrough():
@@ -57,3 +60,4 @@ def test_single_rank_is_passthrough():
     assert shard.reduce_job(1.5, 100, 3) == (1.5, 100, 3)
     assert shard.stream_seed(3, 0, 1) == 3
     assert shard.shard_channels([1, 2, 3], 0, 1) == [1, 2, 3]
+    assert shard.reduce_sums([4, 5]) == [4, 5] and shard.gather_ints(9) == [9]
