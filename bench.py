@@ -271,7 +271,8 @@ def host_path_leg(w, x, freqs, fmt="CF32", dev_index=0, seconds_cap=120):
             np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16).tofile(path)
         else:
             x.view(np.float32).tofile(path)
-        cmd = [exe, "--bench", "--iq-file", path, "--sample-rate", str(w["fs"]), "--sample-format", fmt, "--device", str(dev_index),
+        loops = max(1, int(np.ceil(1.5 * 2.5e9 / len(x))))        # >= ~1.5 s of work at 2.5 Gsamples/s
+        cmd = [exe, "--bench", "--loop", str(loops), "--iq-file", path, "--sample-rate", str(w["fs"]), "--sample-format", fmt, "--device", str(dev_index),
                "--centerfreq", "%.3f" % (w["centerfreq"] / 1e3)] + ["%.3f" % (f / 1e3) for f in freqs]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=seconds_cap)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -279,6 +280,7 @@ def host_path_leg(w, x, freqs, fmt="CF32", dev_index=0, seconds_cap=120):
             return dict(error="hfdl_replay --bench failed (rc %d): %s" % (out.returncode, out.stderr[-300:]))
         r = json.loads(line[-1])
         r["sample_format"] = fmt
+        r["file_loops"] = loops
         return r
     except Exception as e:
         return dict(error=str(e))

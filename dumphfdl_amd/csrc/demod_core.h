@@ -2,64 +2,357 @@
 //
 // Replaces the body of hfdl_decoder_thread after fastddc_inv_cc (reference src/hfdl.c:676-892):
 // msresamp -> AGC -> matched filter -> symsync -> Costas -> LMS equaliser -> M-PSK slicer -> preamble
-// correlator / framer.  Mapping: ONE WAVEFRONT PER CHANNEL.  The feed-forward stages (resampler, matched
-// filter) run with lanes over output samples; the feedback stages (AGC, timing/carrier loops, equaliser,
-// framer FSM) are one data-dependent recurrence per channel and run wave-uniformly, so every branch of the
-// framer is a scalar branch and no lane ever diverges.  The symsync / equaliser windows live in registers, one tap per lane.
-// State, modem and the framer FSM are in demod_logic.h.
+// correlator / framer.
+//
+// Mapping: ONE WORKGROUP OF THREE WAVEFRONTS PER CHANNEL, the waves forming a software pipeline over chunks of DM_CHUNK
+// 5400-sps samples.  The reference runs these stages as one serial loop; three of them are genuine recurrences (the AGC gain,
+// the symbol-timing loop, the carrier loop + equaliser + framer FSM) and each costs a lone wavefront a few hundred cycles per
+// sample in dependent-instruction latency.  They only feed FORWARD -- AGC -> timing recovery -> carrier/equaliser/framer --
+// with one rare exception, so they run concurrently on three SIMDs of the CU:
+//
+//   wave 0   AGC recurrence (agc_crcf_execute) + matched filter (lanes over outputs) of chunk s
+//   wave 1   symsync_crcf of chunk s-1: register-resident filter windows, four dot products per DPP row reduction
+//   wave 2   Costas loop, equaliser, slicer, framer FSM of chunk s-2 (demod_logic.h on_symbol)
+//
+// The exception: the framer resets the timing loop (symsync_crcf_reset at the end of a frame, on a failed preamble search,
+// on carrier run-away: src/hfdl.c:714,751,969).  Wave 1 therefore runs AHEAD speculatively; when wave 2 hits a reset at
+// sample k it publishes k, and wave 1 restarts at k+1 from the reset state, which is fully determined (zero matched-filter
+// window, the last 18 matched-filter samples in the derivative window, initial loop scalars).  Results are those of the
+// serial order, sample for sample; resets are rare (once per frame), so the re-run costs nothing measurable.
+// The waves meet at one workgroup barrier per chunk and exchange progress through a double-buffered LDS mailbox.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "demod_logic.h"
 
 namespace hfdl {
 
-// lane i <- src of lane i-1; lane 0 <- fill          (DPP wave_shr:1, GFX9)
-__device__ inline float wave_shr1(float fill, float src)
+constexpr int DM_WAVES = 3, DM_THREADS = 64 * DM_WAVES, DM_CHUNK = 32;
+
+// ---- DPP helpers (GFX9 encodings): all row-local, a row = 16 lanes ----
+__device__ __forceinline__ float dpp_row_shr1(float old, float src)      // lane i <- src[i-1]; lane 0 of every row <- old
 {
-	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(src), 0x138, 0xf, 0xf, false));
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x111, 0xf, 0xf, false));
 }
-// lane i <- src of lane i+1; lane 63 <- fill         (DPP wave_shl:1, GFX9)
-__device__ inline float wave_shl1(float fill, float src)
+__device__ __forceinline__ float dpp_row_shl1(float old, float src)      // lane i <- src[i+1]; lane 15 of every row <- old
 {
-	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(src), 0x130, 0xf, 0xf, false));
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x101, 0xf, 0xf, false));
 }
-// Sum of v over lanes 0..31 (two DPP rows), returned wave-uniform.
-__device__ inline float row32_sum(float v)
+__device__ __forceinline__ float dpp_row_ror1(float src)                 // lane i <- src[i-1], lane 0 <- src[15] (inside the row)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x121, 0xf, 0xf, false));
+}
+// inclusive scan-sum inside every 16-lane row (lanes shifted in from outside the row read 0): lane 15 of a row ends up
+// with the row's total.  One call reduces FOUR independent 16-term sums, one per row.
+__device__ __forceinline__ float row_scan_sum(float v)
 {
 	int x = __float_as_int(v);
 	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true)));
 	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true)));
 	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true)));
 	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));
-	return __int_as_float(__builtin_amdgcn_readlane(x, 15)) + __int_as_float(__builtin_amdgcn_readlane(x, 31));
+	return __int_as_float(x);
 }
-// Sum of v over lanes 0..15, returned wave-uniform.  Four DPP row_shr steps build an inclusive scan inside the
-// 16-lane row (lanes shifted in from outside the row read 0), lane 15 then holds the total.
-__device__ inline float row16_sum(float v)
+__device__ __forceinline__ float lane_value(float v, int lane)           // wave-uniform copy of one lane (lane is uniform)
 {
-	int x = __float_as_int(v);
-	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true)));
-	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true)));
-	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true)));
-	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));
-	return __int_as_float(__builtin_amdgcn_readlane(x, 15));
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// what the three waves share through LDS besides the sample buffers
+struct DemodShared {
+	cf *outq;                      // symsync outputs of the block, in order
+	int outq_cap;
+	uint16_t *cum;                 // cum[k] = outputs produced up to and including input sample k
+	const float2 *sstab;           // [16 banks][64 lanes] {tap t, tap t+16} of the lane's row: rows 0,1 matched filter, rows 2,3 derivative
+	ChanScalars *S;                // the channel's scalars; every wave owns a disjoint set of fields
+	int *mbox;                     // [2][4] progress mailbox: {mf_ready, ss_to, s3_done, s3_reset}
+};
+
+// progress of the three stages as every wave sees it after a step's barrier
+struct PipeProgress {
+	int mf_ready = 0, ss_ready = 0, s3_done = 0;
+	bool restart = false;
+	__device__ __forceinline__ void read(const int *mb)
+	{
+		mf_ready = mb[0];
+		s3_done = mb[2];
+		restart = mb[3] != 0;
+		ss_ready = restart ? s3_done : mb[1];          // a reset discards what wave 1 computed beyond the reset sample
+	}
+};
+
+// ---------------- wave 0: AGC + matched filter of samples [a0, a1) ----------------
+
+__device__ __forceinline__ void agc_mf_chunk(float &g, float &y2, const ChanArrays &a, const DemodConst &T, const BlockIo &io, int a0, int a1, int lane)
+{
+	// agc_crcf_execute (src/hfdl.c:686): a per-sample gain recurrence, wave-uniform
+	const float alpha = 0.01f;
+	const cf xin = (a0 + lane < a1 && lane < DM_CHUNK) ? io.rs[a0 + lane] : cf{0.f, 0.f};      // the chunk, one sample per lane
+	for (int k = a0; k < a1; k++) {
+		cf x; x.x = lane_value(xin.x, k - a0); x.y = lane_value(xin.y, k - a0);
+		cf y; y.x = x.x * g; y.y = x.y * g;
+		const float e = y.x * y.x + y.y * y.y;
+		y2 = (1.0f - alpha) * y2 + alpha * e;
+		// exp(a ln y2) == 2^(a log2 y2): one v_log_f32 + one v_exp_f32 on the gain recurrence's critical path
+		if (y2 > 1e-6f) g *= __builtin_amdgcn_exp2f(-0.5f * alpha * __builtin_amdgcn_logf(y2));
+		if (g > 1e6f) g = 1e6f;
+		io.agc[k] = y;
+		io.lvl[k] = __builtin_amdgcn_rcpf(g);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	// 19-tap matched filter, lanes over the chunk's outputs (firfilt_crcf, src/hfdl.c:694-695)
+	const int k = a0 + lane;
+	if (k < a1) {
+		float ar = 0, ai = 0;
+		for (int t = 0; t < D_MF; t++) {
+			const int idx = k - t;
+			const cf x = idx >= 0 ? io.agc[idx] : a.mf_hist[-idx - 1];
+			ar += T.mf[t] * x.x;
+			ai += T.mf[t] * x.y;
+		}
+		io.mf[k].x = ar; io.mf[k].y = ai;
+	}
+}
+
+// ---------------- wave 1: symbol timing recovery (symsync_crcf_execute, src/hfdl.c:696) ----------------
+
+struct SymsyncRegs {
+	float w_lo, w_hi;              // this lane's window samples: tap t and tap t+16 of its row's component (rows 0,1: matched; 2,3: derivative)
+	float rate, del, tau, bf, q, qhat, v1;
+	int b, decim, j;               // filter-bank index, decimation counter, running output index of the block
+};
+
+// window sample of age `age` (0 = newest) before input sample k0: from this block's matched-filter output, or the window the
+// previous block left (canonical array form: index 0 newest, index 18 - age older)
+__device__ __forceinline__ float ss_hist_sample(const ChanArrays &a, const cf *mf, int k0, int age, bool imag)
+{
+	const int i = k0 - 1 - age;
+	cf v;
+	if (i >= 0) v = mf[i];
+	else { const int t = -1 - i; v = a.ss_dmf[t == 0 ? 0 : D_SS_TAPS - t]; }
+	return imag ? v.y : v.x;
+}
+
+__device__ __forceinline__ void symsync_load(SymsyncRegs &r, const ChanScalars &s, const ChanArrays &a, int lane)
+{
+	const int row = lane >> 4, t = lane & 15;
+	const cf *src = row < 2 ? a.ss_mf : a.ss_dmf;
+	const cf lo = src[t == 0 ? 0 : D_SS_TAPS - t];
+	const cf hi = src[D_SS_TAPS - 16 - t >= 0 ? D_SS_TAPS - 16 - t : 0];      // taps 16, 17 (t = 0, 1)
+	r.w_lo = (row & 1) ? lo.y : lo.x;
+	r.w_hi = t < D_SS_TAPS - 16 ? ((row & 1) ? hi.y : hi.x) : 0.f;
+	r.rate = s.ss_rate; r.del = s.ss_del; r.tau = s.ss_tau; r.bf = s.ss_bf; r.q = s.ss_q; r.qhat = s.ss_qhat; r.v1 = s.ss_v1;
+	r.b = s.ss_b; r.decim = (int)s.ss_decim; r.j = 0;
+}
+
+// symsync_crcf_reset as the framer left it after input sample k0-1: loop scalars initial, matched-filter window cleared
+// (liquid clears that one only), derivative window = the last 18 matched-filter samples
+__device__ __forceinline__ void symsync_restart(SymsyncRegs &r, const ChanArrays &a, const BlockIo &io, const DemodShared &sh, int k0, int lane)
+{
+	const int row = lane >> 4, t = lane & 15;
+	r.rate = 1.5f; r.del = 1.5f; r.tau = 0.f; r.bf = 0.f; r.q = 0.f; r.qhat = 0.f; r.v1 = 0.f;
+	r.b = 0; r.decim = 0;
+	r.j = k0 > 0 ? (int)sh.cum[k0 - 1] : 0;
+	if (row < 2) { r.w_lo = 0.f; r.w_hi = 0.f; }
+	else {
+		r.w_lo = ss_hist_sample(a, io.mf, k0, t, row & 1);
+		r.w_hi = t < D_SS_TAPS - 16 ? ss_hist_sample(a, io.mf, k0, t + 16, row & 1) : 0.f;
+	}
+}
+
+__device__ __forceinline__ void symsync_store(const SymsyncRegs &r, ChanScalars &s, ChanArrays &a, int lane)
+{
+	const int row = lane >> 4, t = lane & 15;
+	cf *dst = row < 2 ? a.ss_mf : a.ss_dmf;
+	float *lo = (float *)&dst[t == 0 ? 0 : D_SS_TAPS - t];
+	lo[row & 1] = r.w_lo;
+	if (t < D_SS_TAPS - 16) ((float *)&dst[D_SS_TAPS - 16 - t])[row & 1] = r.w_hi;
+	if (lane == 0) {
+		s.ss_rate = r.rate; s.ss_del = r.del; s.ss_tau = r.tau; s.ss_bf = r.bf; s.ss_q = r.q; s.ss_qhat = r.qhat; s.ss_v1 = r.v1;
+		s.ss_b = r.b; s.ss_decim = (uint32_t)r.decim; s.ss_head = 0;
+	}
+}
+
+__device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &T, const BlockIo &io, const DemodShared &sh, int k0, int k1, int lane)
+{
+	const bool imag = (lane >> 4) & 1;
+	const cf min = (k0 + lane < k1) ? io.mf[k0 + lane] : cf{0.f, 0.f};          // the chunk's matched-filter outputs, one per lane
+	int bi = r.b < 0 ? 0 : (r.b >= D_SS_NPFB ? D_SS_NPFB - 1 : r.b);
+	float2 h = sh.sstab[bi * 64 + lane];
+	for (int k = k0; k < k1; k++) {
+		// push one sample into both windows: tap t <- tap t-1 inside every row, tap 16 <- tap 15 through the row rotate
+		const float nv = imag ? lane_value(min.y, k - k0) : lane_value(min.x, k - k0);
+		const float t15 = dpp_row_ror1(r.w_lo);
+		r.w_hi = dpp_row_shr1(t15, r.w_hi);
+		r.w_lo = dpp_row_shr1(nv, r.w_lo);
+		int produced = 0;
+		while (r.b < D_SS_NPFB && produced < 4) {
+			// four 18-tap dot products at once: row 0/1 = matched filter re/im, row 2/3 = derivative filter re/im
+			const float p = row_scan_sum(h.x * r.w_lo + h.y * r.w_hi);
+			const float mx = lane_value(p, 15), my = lane_value(p, 31);
+			if (lane == 0 && r.j < sh.outq_cap) { cf o; o.x = mx / 3.0f; o.y = my / 3.0f; sh.outq[r.j] = o; }
+			r.j++;
+			if (r.decim == 2) {
+				r.decim = 0;
+				const float dx = lane_value(p, 47), dy = lane_value(p, 63);
+				float q = mx * dx + my * dy;
+				q = q > 1.0f ? 1.0f : (q < -1.0f ? -1.0f : q);
+				r.q = q;
+				const float v0 = q - T.lf_a1 * r.v1;
+				r.qhat = T.lf_b0 * v0;
+				r.v1 = v0;
+				r.rate += T.ss_rate_adj * r.qhat;
+				r.del = r.rate + r.qhat;
+			}
+			r.decim++;
+			r.tau += r.del;
+			r.bf = r.tau * (float)D_SS_NPFB;
+			r.b = (int)roundf(r.bf);
+			produced++;
+			if (r.b < D_SS_NPFB) h = sh.sstab[(r.b < 0 ? 0 : r.b) * 64 + lane];      // another output from this input sample
+		}
+		r.tau -= 1.0f;
+		r.bf -= (float)D_SS_NPFB;
+		r.b -= D_SS_NPFB;
+		bi = r.b < 0 ? 0 : (r.b >= D_SS_NPFB ? D_SS_NPFB - 1 : r.b);
+		h = sh.sstab[bi * 64 + lane];                   // branch of the next input sample: fetched while the stores drain
+		if (lane == 0) sh.cum[k] = (uint16_t)(r.j < 65535 ? r.j : 65535);
+	}
+}
+
+// ---------------- wave 2: carrier loop, equaliser, slicer, framer (src/hfdl.c:709-891) ----------------
+
+struct CarrierRegs {
+	float eu, ev, ex2, ewx, ewy;   // equaliser: lane t < 15 of rows 0 and 1 = tap t (0 oldest); row 0 holds (x, y), row 1 (y, -x)
+};
+
+__device__ __forceinline__ void carrier_load(CarrierRegs &c, const ChanScalars &s, const ChanArrays &a, int lane)
+{
+	const int t = lane & 15;
+	const bool act = t < D_EQ && lane < 32, row1 = (lane >> 4) & 1;
+	int j = s.eq_head + t; if (j >= D_EQ) j -= D_EQ;
+	const cf e = act ? a.eq_buf[j] : cf{0.f, 0.f};
+	c.eu = row1 ? e.y : e.x;
+	c.ev = row1 ? -e.x : e.y;
+	c.ex2 = act ? a.eq_x2[j] : 0.f;
+	const cf w = act ? a.eq_w[t] : cf{0.f, 0.f};
+	c.ewx = w.x; c.ewy = w.y;
+}
+
+__device__ __forceinline__ void carrier_store(const CarrierRegs &c, ChanArrays &a, int lane)
+{
+	if (lane < D_EQ) {
+		cf e; e.x = c.eu; e.y = c.ev;
+		a.eq_buf[lane] = e; a.eq_x2[lane] = c.ex2;
+		cf w; w.x = c.ewx; w.y = c.ewy;
+		a.eq_w[lane] = w;
+	}
+}
+
+// processes samples [k0, k1); returns the index of the sample during which the framer reset the timing loop (the wave stops
+// after that sample), or -1
+__device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, const DemodShared &sh,
+		int k0, int k1, int &nsym, int lane)
+{
+	const int t = lane & 15;
+	const bool row1 = (lane >> 4) & 1, act = t < D_EQ && lane < 32, ins = t == D_EQ;
+	// the chunk's levels, output counts and (up to 64) timing-recovery outputs, one per lane: the loop below takes them with
+	// v_readlane instead of a dependent LDS round trip per sample
+	const float lv_l = (k0 + lane < k1) ? io.lvl[k0 + lane] : 0.f;
+	const int cum_l = (k0 + lane < k1) ? (int)sh.cum[k0 + lane] : 0;
+	const int jbase = k0 > 0 ? (int)sh.cum[k0 - 1] : 0;
+	const cf oq_l = (jbase + lane < sh.outq_cap) ? sh.outq[jbase + lane] : cf{0.f, 0.f};
+	int j = jbase;
+	for (int k = k0; k < k1; k++, s.sample_cnt++) {
+		const float level = lane_value(lv_l, k - k0);
+		if (s.fr_state == FR_A1 && (++s.nf_clk & 0xFFu) == 0xFFu)
+			s.noise_floor = 0.65f * s.noise_floor + 0.35f * fminf(s.noise_floor, level) + 1e-6f;
+		int j1 = __builtin_amdgcn_readlane(cum_l, k - k0);
+		if (j1 > sh.outq_cap) j1 = sh.outq_cap;
+		for (; j < j1; j++, s.symsync_out_idx++) {
+			cf oi;
+			if (j - jbase < 64) { oi.x = lane_value(oq_l.x, j - jbase); oi.y = lane_value(oq_l.y, j - jbase); }
+			else oi = sh.outq[j];
+			// costas_cccf_step + execute, :256-258, :284-292
+			s.phi += s.dphi;
+			if (s.phi > (float)M_PI) s.phi -= (float)(2.0 * M_PI);
+			else if (s.phi < -(float)M_PI) s.phi += (float)(2.0 * M_PI);
+			// |phi| <= pi: the hardware sin/cos (argument in revolutions) needs no range reduction
+			const float rev = s.phi * 0.15915494309189535f;
+			const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
+			cf r;
+			r.x = oi.x * cp + oi.y * sp;
+			r.y = oi.y * cp - oi.x * sp;
+			if (fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1) {
+				s.dphi = s.phi = 0.f;
+				symsync_reset(s, a);
+			}
+			// eqlms_cccf_push: park the new sample in lane 15 of the row, then shift the row down one lane
+			{
+				const float x2n = r.x * r.x + r.y * r.y;
+				const float x2o = lane_value(c.ex2, 0);
+				const float nu = row1 ? r.y : r.x, nv = row1 ? -r.x : r.y;
+				c.eu = dpp_row_shl1(0.f, ins ? nu : c.eu);
+				c.ev = dpp_row_shl1(0.f, ins ? nv : c.ev);
+				c.ex2 = dpp_row_shl1(0.f, ins ? x2n : c.ex2);
+				s.eq_x2sum = s.eq_x2sum + x2n - x2o;
+				s.eq_count++;
+			}
+			if (s.symsync_out_idx & 1u) {
+				// eqlms_cccf_execute, sum conj(w_i) x_i: real part reduced in row 0, imaginary part in row 1, one scan
+				const float p = row_scan_sum(act ? c.ewx * c.eu + c.ewy * c.ev : 0.f);
+				cf y; y.x = lane_value(p, 15); y.y = lane_value(p, 31);
+				if (s.fr_state == FR_EQ_TRAIN) {
+					// eqlms_cccf_step(d = known T symbol, d_hat = y)
+					bool run = true;
+					if (!s.eq_full) { if (s.eq_count < (uint32_t)D_EQ) run = false; else s.eq_full = 1; }
+					if (run) {
+						const float tv = t_symbol(s.T_idx) * ((s.bitmask & 1u) ? -1.0f : 1.0f);
+						const float er = tv - y.x, ei = -(0.0f - y.y);
+						const float bx = row1 ? -c.ev : c.eu, by = row1 ? c.eu : c.ev;       // the window sample (x, y) in either row
+						const float pr = er * bx - ei * by, pi = er * by + ei * bx;
+						c.ewx = c.ewx + 0.1f * pr / s.eq_x2sum;
+						c.ewy = c.ewy + 0.1f * pi / s.eq_x2sum;
+					}
+					s.T_idx++;
+				}
+				if (io.tap_symbols && lane == 0) io.tap_symbols[nsym] = y;
+				nsym++;
+				on_symbol(s, a, T, io, y, level);
+			}
+			if (s.ev_flags & EV_EQ_RESET) {      // eqlms_cccf_reset ran (framer reset): mirror it in the register window
+				c.eu = 0.f; c.ev = 0.f; c.ex2 = 0.f;
+				c.ewx = act ? T.eq_h0[t < D_EQ ? t : 0] : 0.f; c.ewy = 0.f;
+				s.ev_flags &= ~(uint32_t)EV_EQ_RESET;
+			}
+		}
+		if (s.ev_flags & EV_SS_RESET) {          // the timing loop was reset during this sample: wave 1 restarts after it
+			s.ev_flags = 0;
+			s.sample_cnt++;
+			return k;
+		}
+	}
+	return -1;
 }
 
 // ---------------- one block ----------------
 
-// returns the number of 5400-sps samples produced
-__device__ inline int demod_block(ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, const cf *in, int n_in)
+// All DM_THREADS threads of the channel's workgroup call this.  On return the channel's arrays (LDS, `a`) and scalars (*sh.S)
+// hold the state after the block.  Returns the number of 5400-sps samples produced.
+__device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const BlockIo &io, const DemodShared &sh, const cf *in, int n_in)
 {
-	const int lane = (int)threadIdx.x;
+	const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	ChanScalars &S = *sh.S;
 	unsigned long long tR0 = __builtin_amdgcn_s_memtime();
 
-	// ---- R: arbitrary resampler, 24-bit fixed-point phase, lanes over outputs (msresamp_crcf_execute, src/hfdl.c:676)
+	// ---- R: arbitrary resampler, 24-bit fixed-point phase, all threads over the outputs (msresamp_crcf_execute, src/hfdl.c:676)
+	const uint32_t rs_phase = S.rs_phase;
 	const uint64_t total = (uint64_t)n_in << 24;
 	int n_out = 0;
-	if ((uint64_t)s.rs_phase < total) n_out = (int)((total - s.rs_phase + T.rs_step - 1) / T.rs_step);
+	if ((uint64_t)rs_phase < total) n_out = (int)((total - rs_phase + T.rs_step - 1) / T.rs_step);
 	if (n_out > io.cap - 4) n_out = io.cap - 4;      // cannot happen: cap is sized from the geometry (+8); the last 4 level slots carry phase cycles
-	for (int k = lane; k < n_out; k += 64) {
-		const uint64_t t = (uint64_t)s.rs_phase + (uint64_t)k * T.rs_step;
+	for (int k = tid; k < n_out; k += DM_THREADS) {
+		const uint64_t t = (uint64_t)rs_phase + (uint64_t)k * T.rs_step;
 		const int i = (int)(t >> 24);
 		const float *h = T.rs_h + ((t & 0xFFFFFFu) >> 16) * D_RS_TAPS;
 		float ar = 0, ai = 0;
@@ -74,213 +367,109 @@ __device__ inline int demod_block(ChanScalars &s, ChanArrays &a, const DemodCons
 	__syncthreads();
 	{
 		cf nh;
-		const int j = lane;
-		if (j < D_RS_TAPS - 1) nh = (n_in - 1 - j >= 0) ? in[n_in - 1 - j] : a.rs_hist[j - n_in];
+		if (tid < D_RS_TAPS - 1) nh = (n_in - 1 - tid >= 0) ? in[n_in - 1 - tid] : a.rs_hist[tid - n_in];
 		__syncthreads();
-		if (j < D_RS_TAPS - 1) a.rs_hist[j] = nh;
+		if (tid < D_RS_TAPS - 1) a.rs_hist[tid] = nh;
+		if (tid == 0) {
+			S.rs_phase = (uint32_t)((uint64_t)rs_phase + (uint64_t)n_out * T.rs_step - total);
+			if (io.tap_counts) { io.tap_counts[0] = n_out; io.tap_counts[1] = 0; }
+		}
 	}
-	s.rs_phase = (uint32_t)((uint64_t)s.rs_phase + (uint64_t)n_out * T.rs_step - total);
-	if (io.tap_counts && lane == 0) io.tap_counts[0] = n_out;
+	__syncthreads();             // `in` (staged in the space of agc + mf) is dead from here on
 	if (n_out < 1) return 0;
 
-	unsigned long long tA0 = __builtin_amdgcn_s_memtime();
-	// ---- A: AGC, a per-sample gain recurrence (agc_crcf_execute, src/hfdl.c:686)
-	{
-		float g = s.agc_g, y2 = s.agc_y2;
-		const float alpha = 0.01f;
-		for (int k = 0; k < n_out; k++) {
-			const cf x = io.rs[k];
-			cf y; y.x = x.x * g; y.y = x.y * g;
-			const float e = y.x * y.x + y.y * y.y;
-			y2 = (1.0f - alpha) * y2 + alpha * e;
-			// exp(a ln y2) == 2^(a log2 y2): one v_log_f32 + one v_exp_f32 on the gain recurrence's critical path
-			if (y2 > 1e-6f) g *= __builtin_amdgcn_exp2f(-0.5f * alpha * __builtin_amdgcn_logf(y2));
-			if (g > 1e6f) g = 1e6f;
-			io.agc[k] = y;
-			io.lvl[k] = __builtin_amdgcn_rcpf(g);
+	unsigned long long tP0 = __builtin_amdgcn_s_memtime();
+	// ---- the three-wave pipeline over chunks of DM_CHUNK samples.  Every wave runs its OWN copy of the step loop (same number
+	// of barriers, same mailbox reads), so that only its own stage's state is live in its registers.
+	unsigned long long busy = 0;
+	int nsym = 0;
+	if (wave == 0) {
+		float agc_g = S.agc_g, agc_y2 = S.agc_y2;
+		PipeProgress pp;
+		for (int step = 0; pp.s3_done < n_out; step++) {
+			int *mb = sh.mbox + 4 * (step & 1);
+			int to = pp.mf_ready;
+			if (pp.mf_ready < n_out) {
+				to = pp.mf_ready + DM_CHUNK < n_out ? pp.mf_ready + DM_CHUNK : n_out;
+				agc_mf_chunk(agc_g, agc_y2, a, T, io, pp.mf_ready, to, lane);
+			}
+			if (lane == 0) mb[0] = to;
+			__syncthreads();
+			pp.read(mb);
 		}
-		s.agc_g = g; s.agc_y2 = y2;
-	}
-	__syncthreads();
-
-	unsigned long long tM0 = __builtin_amdgcn_s_memtime();
-	// ---- M: 19-tap matched filter, lanes over outputs (firfilt_crcf, src/hfdl.c:694-695)
-	for (int k = lane; k < n_out; k += 64) {
-		float ar = 0, ai = 0;
-		for (int t = 0; t < D_MF; t++) {
-			const int idx = k - t;
-			const cf x = idx >= 0 ? io.agc[idx] : a.mf_hist[-idx - 1];
-			ar += T.mf[t] * x.x;
-			ai += T.mf[t] * x.y;
-		}
-		io.mf[k].x = ar; io.mf[k].y = ai;
-	}
-	__syncthreads();
-	{
 		cf nh;
-		const int j = lane;
-		if (j < D_MF - 1) nh = (n_out - 1 - j >= 0) ? io.agc[n_out - 1 - j] : a.mf_hist[j - n_out];
-		__syncthreads();
-		if (j < D_MF - 1) a.mf_hist[j] = nh;
+		if (lane < D_MF - 1) nh = (n_out - 1 - lane >= 0) ? io.agc[n_out - 1 - lane] : a.mf_hist[lane - n_out];
+		__builtin_amdgcn_wave_barrier();
+		if (lane < D_MF - 1) a.mf_hist[lane] = nh;
+		if (lane == 0) { S.agc_g = agc_g; S.agc_y2 = agc_y2; }
+	} else if (wave == 1) {
+		SymsyncRegs ss;
+		symsync_load(ss, S, a, lane);
+		PipeProgress pp;
+		for (int step = 0; pp.s3_done < n_out; step++) {
+			int *mb = sh.mbox + 4 * (step & 1);
+			const unsigned long long tb = __builtin_amdgcn_s_memtime();
+			if (pp.restart) symsync_restart(ss, a, io, sh, pp.ss_ready, lane);
+			int to = pp.ss_ready + DM_CHUNK < pp.mf_ready ? pp.ss_ready + DM_CHUNK : pp.mf_ready;
+			if (to > pp.ss_ready) symsync_chunk(ss, T, io, sh, pp.ss_ready, to, lane); else to = pp.ss_ready;
+			if (lane == 0) mb[1] = to;
+			busy += __builtin_amdgcn_s_memtime() - tb;
+			__syncthreads();
+			pp.read(mb);
+		}
+		if (pp.restart) symsync_restart(ss, a, io, sh, n_out, lane);      // a reset during the block's last sample
+		__builtin_amdgcn_wave_barrier();
+		symsync_store(ss, S, a, lane);
+	} else {
+		CarrierRegs cr;
+		ChanScalars s3 = S;               // wave 2's working copy: it owns every field but the resampler / AGC / timing-loop ones
+		s3.ev_flags = 0;
+		carrier_load(cr, s3, a, lane);
+		PipeProgress pp;
+		for (int step = 0; pp.s3_done < n_out; step++) {
+			int *mb = sh.mbox + 4 * (step & 1);
+			const unsigned long long tb = __builtin_amdgcn_s_memtime();
+			int to = pp.s3_done + DM_CHUNK < pp.ss_ready ? pp.s3_done + DM_CHUNK : pp.ss_ready;
+			int reset_at = -1;
+			if (to > pp.s3_done) reset_at = carrier_chunk(cr, s3, a, T, io, sh, pp.s3_done, to, nsym, lane); else to = pp.s3_done;
+			if (lane == 0) { mb[2] = reset_at >= 0 ? reset_at + 1 : to; mb[3] = reset_at >= 0; }
+			busy += __builtin_amdgcn_s_memtime() - tb;
+			__syncthreads();
+			pp.read(mb);
+		}
+		carrier_store(cr, a, lane);
+		if (lane == 0) {
+			// every field wave 2 owns (the timing-loop scalars it touched through symsync_reset() are wave 1's)
+			S.phi = s3.phi; S.dphi = s3.dphi; S.err = s3.err;
+			S.eq_x2sum = s3.eq_x2sum; S.eq_count = s3.eq_count; S.eq_full = s3.eq_full; S.eq_head = 0;
+			S.bits_hi = s3.bits_hi; S.bits_lo = s3.bits_lo;
+			S.training_n = s3.training_n; S.data_n = s3.data_n; S.use_data = s3.use_data; S.data_slot = s3.data_slot;
+			S.symbol_cnt = s3.symbol_cnt; S.sample_cnt = s3.sample_cnt; S.pdu_sample_index = s3.pdu_sample_index;
+			S.s_state = s3.s_state; S.fr_state = s3.fr_state; S.data_arity = s3.data_arity; S.cur_arity = s3.cur_arity;
+			S.symbols_wanted = s3.symbols_wanted; S.search_retries = s3.search_retries;
+			S.eq_train_seq_cnt = s3.eq_train_seq_cnt; S.data_segment_cnt = s3.data_segment_cnt;
+			S.train_total = s3.train_total; S.train_bad = s3.train_bad; S.T_idx = s3.T_idx; S.M1 = s3.M1;
+			S.bitmask = s3.bitmask; S.symsync_out_idx = s3.symsync_out_idx; S.nf_clk = s3.nf_clk;
+			S.frame_symbol_cnt = s3.frame_symbol_cnt; S.freq_err_hz = s3.freq_err_hz; S.signal_level = s3.signal_level;
+			S.noise_floor = s3.noise_floor;
+			S.cnt_a2_found = s3.cnt_a2_found; S.cnt_m1_found = s3.cnt_m1_found; S.cnt_m1_not_found = s3.cnt_m1_not_found;
+			S.cnt_frames = s3.cnt_frames;
+			S.ev_flags = 0;
+			if (io.tap_counts) io.tap_counts[1] = nsym;
+		}
 	}
+	unsigned long long tP1 = __builtin_amdgcn_s_memtime();
 	if (io.tap_resampled) {
-		for (int k = lane; k < n_out; k += 64) {
+		__syncthreads();
+		for (int k = tid; k < n_out; k += DM_THREADS) {
 			io.tap_resampled[k] = io.rs[k];
 			io.tap_mf[k] = io.mf[k];
 			io.tap_level[k] = io.lvl[k];
 		}
-	}
-	__syncthreads();
-
-	unsigned long long tS0 = __builtin_amdgcn_s_memtime();
-	// ---- S: timing recovery, carrier loop, equaliser, slicer, framer -- wave-uniform (src/hfdl.c:696-891)
-	// Device form: the symsync / equaliser windows live in REGISTERS, one tap per lane (pushed with a DPP wave shift),
-	// every FIR is one multiply per lane plus a DPP row reduction, the matched and derivative-matched branch outputs are
-	// reduced together, and the branch taps of the next output are fetched as soon as its bank index is known.
-	int nsym = 0;
-	{
-		cf wmf, wdmf, ebuf, ew;
-		float ex2;
-		{
-			int i = s.ss_head - lane; if (i < 0) i += D_SS_TAPS;
-			const bool in = lane < D_SS_TAPS;
-			wmf = in ? a.ss_mf[i] : cf{0.f, 0.f};
-			wdmf = in ? a.ss_dmf[i] : cf{0.f, 0.f};
-			int j = s.eq_head + lane; if (j >= D_EQ) j -= D_EQ;
-			const bool ine = lane < D_EQ;
-			ebuf = ine ? a.eq_buf[j] : cf{0.f, 0.f};
-			ex2 = ine ? a.eq_x2[j] : 0.f;
-			ew = ine ? a.eq_w[lane] : cf{0.f, 0.f};
-		}
-		s.ev_flags = 0;
-		const int tapl = lane < D_SS_TAPS ? lane : 0;
-		const float tapm = lane < D_SS_TAPS ? 1.0f : 0.0f;
-		int bi = s.ss_b < 0 ? 0 : (s.ss_b >= D_SS_NPFB ? D_SS_NPFB - 1 : s.ss_b);
-		float hmf = T.ss_mf[bi * D_SS_TAPS + tapl] * tapm, hdm = T.ss_dmf[bi * D_SS_TAPS + tapl] * tapm;
-		for (int k = 0; k < n_out; k++, s.sample_cnt++) {
-			const cf mfo = io.mf[k];
-			const float level = io.lvl[k];
-			if (s.fr_state == FR_A1 && (++s.nf_clk & 0xFFu) == 0xFFu)
-				s.noise_floor = 0.65f * s.noise_floor + 0.35f * fminf(s.noise_floor, level) + 1e-6f;
-			// symsync_crcf_execute: push one sample into both windows (lane 0 = newest)
-			wmf.x = wave_shr1(mfo.x, wmf.x); wmf.y = wave_shr1(mfo.y, wmf.y);
-			wdmf.x = wave_shr1(mfo.x, wdmf.x); wdmf.y = wave_shr1(mfo.y, wdmf.y);
-			// at most 4 outputs per input sample, kept in named registers: an array indexed by `produced` would live in
-			// scratch memory, and beside the HBM-saturating fold kernel every scratch access is a multi-microsecond stall
-			cf out0 = cf{0.f, 0.f}, out1 = out0, out2 = out0, out3 = out0;
-			int produced = 0;
-			while (s.ss_b < D_SS_NPFB && produced < 4) {
-				cf m, d;
-				m.x = row32_sum(hmf * wmf.x); m.y = row32_sum(hmf * wmf.y);
-				d.x = row32_sum(hdm * wdmf.x); d.y = row32_sum(hdm * wdmf.y);
-				{
-					cf o; o.x = m.x / 3.0f; o.y = m.y / 3.0f;
-					if (produced == 0) out0 = o; else if (produced == 1) out1 = o; else if (produced == 2) out2 = o; else out3 = o;
-				}
-				if (s.ss_decim == 2) {
-					s.ss_decim = 0;
-					float q = m.x * d.x + m.y * d.y;
-					q = q > 1.0f ? 1.0f : (q < -1.0f ? -1.0f : q);
-					s.ss_q = q;
-					const float v0 = q - T.lf_a1 * s.ss_v1;
-					s.ss_qhat = T.lf_b0 * v0;
-					s.ss_v1 = v0;
-					s.ss_rate += T.ss_rate_adj * s.ss_qhat;
-					s.ss_del = s.ss_rate + s.ss_qhat;
-				}
-				s.ss_decim++;
-				s.ss_tau += s.ss_del;
-				s.ss_bf = s.ss_tau * (float)D_SS_NPFB;
-				s.ss_b = (int)roundf(s.ss_bf);
-				produced++;
-				if (s.ss_b < D_SS_NPFB) {       // another output from this input sample: its branch taps are needed now
-					bi = s.ss_b < 0 ? 0 : s.ss_b;
-					hmf = T.ss_mf[bi * D_SS_TAPS + tapl] * tapm; hdm = T.ss_dmf[bi * D_SS_TAPS + tapl] * tapm;
-				}
-			}
-			s.ss_tau -= 1.0f;
-			s.ss_bf -= (float)D_SS_NPFB;
-			s.ss_b -= D_SS_NPFB;
-			// branch of the next input sample is known now: fetch its taps while the carrier loop / equaliser run
-			bi = s.ss_b < 0 ? 0 : (s.ss_b >= D_SS_NPFB ? D_SS_NPFB - 1 : s.ss_b);
-			hmf = T.ss_mf[bi * D_SS_TAPS + tapl] * tapm; hdm = T.ss_dmf[bi * D_SS_TAPS + tapl] * tapm;
-
-			for (int i = 0; i < produced; i++, s.symsync_out_idx++) {
-				s.phi += s.dphi;
-				if (s.phi > (float)M_PI) s.phi -= (float)(2.0 * M_PI);
-				else if (s.phi < -(float)M_PI) s.phi += (float)(2.0 * M_PI);
-				// |phi| <= pi: the hardware sin/cos (argument in revolutions) needs no range reduction
-				const float rev = s.phi * 0.15915494309189535f;
-				const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
-				const cf oi = i == 0 ? out0 : (i == 1 ? out1 : (i == 2 ? out2 : out3));
-				cf r;
-				r.x = oi.x * cp + oi.y * sp;
-				r.y = oi.y * cp - oi.x * sp;
-				if (fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1) {
-					s.dphi = s.phi = 0.f;
-					symsync_reset(s, a);
-				}
-				// eqlms_cccf_push: lane 0 = oldest ... lane 14 = newest
-				{
-					const float x2n = r.x * r.x + r.y * r.y;
-					const float x2o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex2), 0));
-					const bool ins = lane == D_EQ;          // park the new sample in lane 15, then shift everything down one lane
-					ebuf.x = wave_shl1(0.f, ins ? r.x : ebuf.x); ebuf.y = wave_shl1(0.f, ins ? r.y : ebuf.y);
-					ex2 = wave_shl1(0.f, ins ? x2n : ex2);
-					s.eq_x2sum = s.eq_x2sum + x2n - x2o;
-					s.eq_count++;
-				}
-				if (s.symsync_out_idx & 1u) {
-					cf y;
-					{
-						const bool act = lane < D_EQ;
-						y.x = row16_sum(act ? ew.x * ebuf.x + ew.y * ebuf.y : 0.f);
-						y.y = row16_sum(act ? ew.x * ebuf.y - ew.y * ebuf.x : 0.f);
-					}
-					if (s.fr_state == FR_EQ_TRAIN) {
-						bool run = true;
-						if (!s.eq_full) { if (s.eq_count < (uint32_t)D_EQ) run = false; else s.eq_full = 1; }
-						if (run) {
-							const float tv = t_symbol(s.T_idx) * ((s.bitmask & 1u) ? -1.0f : 1.0f);
-							const float er = tv - y.x, ei = -(0.0f - y.y);
-							const float pr = er * ebuf.x - ei * ebuf.y, pi = er * ebuf.y + ei * ebuf.x;
-							ew.x = ew.x + 0.1f * pr / s.eq_x2sum;
-							ew.y = ew.y + 0.1f * pi / s.eq_x2sum;
-						}
-						s.T_idx++;
-					}
-					if (io.tap_symbols && lane == 0) io.tap_symbols[nsym] = y;
-					nsym++;
-					on_symbol(s, a, T, io, y, level);
-				}
-				if (s.ev_flags) {       // a reset ran (carrier runaway, framer reset, timeout): mirror it in the register windows
-					if (s.ev_flags & EV_SS_RESET) { wmf.x = 0.f; wmf.y = 0.f; }
-					if (s.ev_flags & EV_EQ_RESET) {
-						ebuf.x = 0.f; ebuf.y = 0.f; ex2 = 0.f;
-						ew.x = lane < D_EQ ? T.eq_h0[lane < D_EQ ? lane : 0] : 0.f; ew.y = 0.f;
-					}
-					s.ev_flags = 0;
-					bi = s.ss_b < 0 ? 0 : (s.ss_b >= D_SS_NPFB ? D_SS_NPFB - 1 : s.ss_b);
-					hmf = T.ss_mf[bi * D_SS_TAPS + tapl] * tapm; hdm = T.ss_dmf[bi * D_SS_TAPS + tapl] * tapm;
-				}
-			}
-		}
-		// back to the canonical array form (newest symsync sample at index 0, oldest equaliser sample at index 0)
-		__syncthreads();
-		if (lane < D_SS_TAPS) {
-			const int i = lane == 0 ? 0 : D_SS_TAPS - lane;
-			a.ss_mf[i] = wmf; a.ss_dmf[i] = wdmf;
-		}
-		if (lane < D_EQ) { a.eq_buf[lane] = ebuf; a.eq_x2[lane] = ex2; a.eq_w[lane] = ew; }
-		s.ss_head = 0;
-		s.eq_head = 0;
-		__syncthreads();
-	}
-	if (io.tap_counts && lane == 0) {
-		io.tap_counts[1] = nsym;
-		unsigned long long tE = __builtin_amdgcn_s_memtime();
-		io.tap_level[io.cap - 4] = (float)(tA0 - tR0); io.tap_level[io.cap - 3] = (float)(tM0 - tA0);
-		io.tap_level[io.cap - 2] = (float)(tS0 - tM0); io.tap_level[io.cap - 1] = (float)(tE - tS0);
+		// phase cycles: resampler, the whole pipelined phase (wall), wave 1 busy, wave 2 busy
+		if (tid == 0) { io.tap_level[io.cap - 4] = (float)(tP0 - tR0); io.tap_level[io.cap - 3] = (float)(tP1 - tP0); }
+		if (wave == 1 && lane == 0) io.tap_level[io.cap - 2] = (float)busy;
+		if (wave == 2 && lane == 0) io.tap_level[io.cap - 1] = (float)busy;
 	}
 	return n_out;
 }

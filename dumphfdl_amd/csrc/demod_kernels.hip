@@ -37,70 +37,93 @@ struct DemodBuffers {
 	int cap;
 };
 
-// global -> LDS copy by one wave, 8 independent loads per lane issued before the first is used
-template <typename T>
-__device__ __forceinline__ void stage_copy(T *__restrict__ dst, const T *__restrict__ src, int n, int lane)
+// global -> LDS copy by NT threads, 8 independent loads per thread issued before the first is used
+template <int NT, typename T>
+__device__ __forceinline__ void stage_copy(T *__restrict__ dst, const T *__restrict__ src, int n, int tid)
 {
-	int i = lane;
-	for (; i + 7 * 64 < n; i += 8 * 64) {
+	int i = tid;
+	for (; i + 7 * NT < n; i += 8 * NT) {
 		T v[8];
 #pragma unroll
-		for (int u = 0; u < 8; u++) v[u] = src[i + u * 64];
+		for (int u = 0; u < 8; u++) v[u] = src[i + u * NT];
 #pragma unroll
-		for (int u = 0; u < 8; u++) dst[i + u * 64] = v[u];
+		for (int u = 0; u < 8; u++) dst[i + u * NT] = v[u];
 	}
-	for (; i < n; i += 64) dst[i] = src[i];
+	for (; i < n; i += NT) dst[i] = src[i];
 }
 
-// __launch_bounds__(64, 5): at most 96 VGPRs.  The 256 demodulator wavefronts are co-resident with the fold kernel's
-// workgroups (stream A): four fold waves of 104 VGPRs leave exactly 96 of a SIMD's 512; one register more and every CU
-// hosting a channel runs 3 instead of 4 fold workgroups, and the HBM-bound fold loses ~15 % for as long as the
-// demodulator is resident (profiles/r01_experiments.md).  Staying inside 96 also keeps the symbol loop free of scratch
-// spills: scratch is memory, and beside a kernel that saturates HBM every spill reload is a multi-microsecond stall
-// (the 64-VGPR version of this kernel ran 2.2 x slower beside the fold than alone for exactly that reason).
-__global__ __launch_bounds__(64, 5) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
+// LDS carve-up of a channel's workgroup, shared by the kernel and the host-side size computation
+struct DemodLds {
+	size_t arrays, scalars, sstab, mf, eq, m1, corr, mbox, rs, agc, mfo, lvl, outq, cum, rs_h, total;
+	__host__ __device__ explicit DemodLds(int cap)
+	{
+		size_t o = 0;
+		auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 15) & ~(size_t)15; return at; };
+		arrays = take(sizeof(ChanArrays));
+		scalars = take(sizeof(ChanScalars));
+		sstab = take(sizeof(float2) * D_SS_NPFB * 64);
+		mf = take(sizeof(float) * 32);
+		eq = take(sizeof(float) * 16);
+		m1 = take(sizeof(uint64_t) * 16);
+		corr = take(sizeof(float) * 128);
+		mbox = take(sizeof(int) * 8);
+		rs = take(sizeof(cf) * (size_t)cap);
+		agc = take(sizeof(cf) * (size_t)cap);          // agc and mfo are adjacent: together they stage the block's input
+		mfo = take(sizeof(cf) * (size_t)cap);
+		lvl = take(sizeof(float) * (size_t)cap);
+		outq = take(sizeof(cf) * 2 * (size_t)cap);
+		cum = take(sizeof(uint16_t) * (size_t)cap);
+		rs_h = take(sizeof(float) * D_RS_NPFB * D_RS_TAPS);
+		total = o;
+	}
+};
+
+// __launch_bounds__(192, 5): at most 96 VGPRs per wave.  The demodulator workgroups (three waves each, on three SIMDs of a CU)
+// are co-resident with the fold kernel's workgroups (stream A): four fold waves of 104 VGPRs leave exactly 96 of a SIMD's 512;
+// one register more and every CU hosting a channel runs 3 instead of 4 fold workgroups, and the HBM-bound fold loses ~15 % for
+// as long as the demodulator is resident (profiles/r01_experiments.md).  Staying inside the budget also keeps the loops free
+// of scratch spills: scratch is memory, and beside a kernel that saturates HBM every spill reload is a multi-microsecond stall.
+__global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
 		const int *__restrict__ n_in, int outs_stride)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	const int c = blockIdx.x, lane = threadIdx.x;
-	// LDS carve-up
-	unsigned char *p = lds;
-	ChanArrays *A = (ChanArrays *)p;                 p += (sizeof(ChanArrays) + 15) & ~(size_t)15;
-	float *l_ss_mf = (float *)p;                     p += sizeof(float) * D_SS_NPFB * D_SS_TAPS;
-	float *l_ss_dmf = (float *)p;                    p += sizeof(float) * D_SS_NPFB * D_SS_TAPS;
-	float *l_mf = (float *)p;                        p += sizeof(float) * 32;
-	float *l_eq = (float *)p;                        p += sizeof(float) * 16;
-	uint64_t *l_m1 = (uint64_t *)p;                  p += sizeof(uint64_t) * 16;
-	float *l_corr = (float *)p;                      p += sizeof(float) * 128;
-	cf *rs = (cf *)p;                                p += sizeof(cf) * (size_t)B.cap;
-	cf *agc = (cf *)p;                               p += sizeof(cf) * (size_t)B.cap;
-	cf *mf = (cf *)p;                                p += sizeof(cf) * (size_t)B.cap;
-	float *lvl = (float *)p;                         p += sizeof(float) * (size_t)B.cap;
-	float *l_rs_h = (float *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+	const int c = blockIdx.x, tid = threadIdx.x;
+	const DemodLds L(B.cap);
+	ChanArrays *A = (ChanArrays *)(lds + L.arrays);
+	ChanScalars *S = (ChanScalars *)(lds + L.scalars);
+	float2 *l_sstab = (float2 *)(lds + L.sstab);
+	float *l_mf = (float *)(lds + L.mf), *l_eq = (float *)(lds + L.eq), *l_corr = (float *)(lds + L.corr);
+	uint64_t *l_m1 = (uint64_t *)(lds + L.m1);
+	float *l_rs_h = (float *)(lds + L.rs_h);
 	// The channelizer output of this block is staged in LDS (in the space of agc + mf, which are written only after the
 	// resampler has consumed it: 16 cap >= 8 n_in because the resampling rate is > 0.5), and so is the resampler's filter
 	// bank: all loads of a lane are in flight together, instead of one dependent memory round trip per filter tap.
-	cf *l_in = agc;
+	cf *l_in = (cf *)(lds + L.agc);
 
 	ChanState *gs = B.states + c;
-	ChanScalars S = gs->s;
 	const int n_block = n_in[c];
 	// prologue copies with 8 loads of a lane in flight at a time: beside the fold kernel a dependent load costs microseconds
-	stage_copy((uint32_t *)A, (const uint32_t *)&gs->a, (int)(sizeof(ChanArrays) / 4), lane);
-	stage_copy(l_in, chan_out + (size_t)c * outs_stride, n_block, lane);
-	stage_copy((float4 *)l_rs_h, (const float4 *)T.c.rs_h, D_RS_NPFB * D_RS_TAPS / 4, lane);
-	stage_copy(l_ss_mf, T.c.ss_mf, D_SS_NPFB * D_SS_TAPS, lane);
-	stage_copy(l_ss_dmf, T.c.ss_dmf, D_SS_NPFB * D_SS_TAPS, lane);
-	if (lane < D_MF) l_mf[lane] = T.c.mf[lane];
-	if (lane < D_EQ) l_eq[lane] = T.c.eq_h0[lane];
-	if (lane < 8) { l_m1[lane] = T.c.m1_hi[lane]; l_m1[8 + lane] = T.c.m1_lo[lane]; }
-	l_corr[lane] = T.c.corr_tab[lane]; l_corr[64 + lane] = T.c.corr_tab[64 + lane];
+	stage_copy<DM_THREADS>((uint32_t *)A, (const uint32_t *)&gs->a, (int)(sizeof(ChanArrays) / 4), tid);
+	stage_copy<DM_THREADS>((uint32_t *)S, (const uint32_t *)&gs->s, (int)(sizeof(ChanScalars) / 4), tid);
+	stage_copy<DM_THREADS>(l_in, chan_out + (size_t)c * outs_stride, n_block, tid);
+	stage_copy<DM_THREADS>((float4 *)l_rs_h, (const float4 *)T.c.rs_h, D_RS_NPFB * D_RS_TAPS / 4, tid);
+	// symsync taps in the lane order of the timing-recovery wave: entry [bank][lane] = {tap t, tap t + 16} of the lane's row
+	for (int e = tid; e < D_SS_NPFB * 64; e += DM_THREADS) {
+		const int bank = e >> 6, row = (e >> 4) & 3, t = e & 15;
+		const float *src = (row < 2 ? T.c.ss_mf : T.c.ss_dmf) + bank * D_SS_TAPS;
+		l_sstab[e] = make_float2(src[t], t + 16 < D_SS_TAPS ? src[t + 16] : 0.f);
+	}
+	if (tid < D_MF) l_mf[tid] = T.c.mf[tid];
+	if (tid < D_EQ) l_eq[tid] = T.c.eq_h0[tid];
+	if (tid < 8) { l_m1[tid] = T.c.m1_hi[tid]; l_m1[8 + tid] = T.c.m1_lo[tid]; }
+	if (tid < 128) l_corr[tid] = T.c.corr_tab[tid];
+	if (tid < 8) ((int *)(lds + L.mbox))[tid] = 0;
 	__syncthreads();
 
 	DemodConst K = T.c;
-	K.rs_h = l_rs_h; K.ss_mf = l_ss_mf; K.ss_dmf = l_ss_dmf; K.mf = l_mf; K.eq_h0 = l_eq; K.m1_hi = l_m1; K.m1_lo = l_m1 + 8; K.corr_tab = l_corr;
+	K.rs_h = l_rs_h; K.ss_mf = nullptr; K.ss_dmf = nullptr; K.mf = l_mf; K.eq_h0 = l_eq; K.m1_hi = l_m1; K.m1_lo = l_m1 + 8; K.corr_tab = l_corr;
 	BlockIo io;
-	io.rs = rs; io.agc = agc; io.mf = mf; io.lvl = lvl; io.cap = B.cap;
+	io.rs = (cf *)(lds + L.rs); io.agc = (cf *)(lds + L.agc); io.mf = (cf *)(lds + L.mfo); io.lvl = (float *)(lds + L.lvl); io.cap = B.cap;
 	io.data = B.data + (size_t)c * 2 * MAX_DATA_SYMBOLS;
 	io.frames = B.frames; io.frame_count = B.frame_count; io.frame_cap = B.frame_cap;
 	io.channel = c;
@@ -111,13 +134,21 @@ __global__ __launch_bounds__(64, 5) void demod_kernel(DevTables T, DemodBuffers 
 	} else {
 		io.tap_resampled = nullptr; io.tap_mf = nullptr; io.tap_symbols = nullptr; io.tap_level = nullptr; io.tap_counts = nullptr;
 	}
-	demod_block(S, *A, K, io, l_in, n_block);
+	DemodShared sh;
+	sh.outq = (cf *)(lds + L.outq); sh.outq_cap = 2 * B.cap;
+	sh.cum = (uint16_t *)(lds + L.cum);
+	sh.sstab = l_sstab;
+	sh.S = S;
+	sh.mbox = (int *)(lds + L.mbox);
+	demod_block(*A, K, io, sh, l_in, n_block);
 	__syncthreads();
-	if (lane == 0) gs->s = S;
 	{
 		uint32_t *dst = (uint32_t *)&gs->a;
 		const uint32_t *src = (const uint32_t *)A;
-		for (unsigned i = lane; i < sizeof(ChanArrays) / 4; i += 64) dst[i] = src[i];
+		for (unsigned i = tid; i < sizeof(ChanArrays) / 4; i += DM_THREADS) dst[i] = src[i];
+		dst = (uint32_t *)&gs->s;
+		src = (const uint32_t *)S;
+		for (unsigned i = tid; i < sizeof(ChanScalars) / 4; i += DM_THREADS) dst[i] = src[i];
 	}
 }
 
@@ -440,14 +471,7 @@ struct KernelTimer {
 	~KernelTimer() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
 };
 
-static size_t demod_lds_bytes(int cap)
-{
-	size_t b = (sizeof(ChanArrays) + 15) & ~(size_t)15;
-	b += sizeof(float) * D_SS_NPFB * D_SS_TAPS * 2 + sizeof(float) * 48 + sizeof(uint64_t) * 16 + sizeof(float) * 128;
-	b += (sizeof(cf) * 3 + sizeof(float)) * (size_t)cap;
-	b += 16 + sizeof(float) * D_RS_NPFB * D_RS_TAPS;
-	return b;
-}
+static size_t demod_lds_bytes(int cap) { return DemodLds(cap).total; }
 
 static size_t k5_lds_bytes() { return 2 * (size_t)K5_TABLE_BYTES + viterbi_lds_bytes(7560) + 128; }
 
@@ -541,7 +565,7 @@ int Demod::enqueue_block(const float2 *chan_out, const int *out_count, int buf, 
 	const bool tw = taps_on && taps_enabled;
 	B.tap_rs = tw ? (cf *)d_tap_rs : nullptr; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
 	B.cap = cap;
-	hipLaunchKernelGGL(demod_kernel, dim3((unsigned)nch), dim3(64), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
+	hipLaunchKernelGGL(demod_kernel, dim3((unsigned)nch), dim3(DM_THREADS), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
 	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)d_frames, d_counts, fc, fc_other, nch,
 			(const cf *)d_data, pv->t.scrambler, (const int32_t *)d_freqs, d_pdus, pdu_cap);
 	// what the ring holds once this block is done, for a host that collects without draining the pipeline

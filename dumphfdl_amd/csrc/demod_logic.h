@@ -327,7 +327,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 	} else if (s.s_state == SAMPLER_SYMBOLS) {
 		if (s.use_data) {
 			if (s.data_n < MAX_DATA_SYMBOLS) {
-				if (threadIdx.x == 0) io.data[s.data_slot * MAX_DATA_SYMBOLS + s.data_n] = sym;
+				if ((threadIdx.x & 63u) == 0) io.data[s.data_slot * MAX_DATA_SYMBOLS + s.data_n] = sym;
 				s.data_n++;
 			}
 		} else if (s.training_n < T_LEN) {
@@ -417,7 +417,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 			s.use_data = 1;
 		} else {
 			// end of frame: queue it for the burst decoder (decode_user_data + dispatch_pdu, :993-1080)
-			if (threadIdx.x == 0) {
+			if ((threadIdx.x & 63u) == 0) {
 				const int slot = atomicAdd(io.frame_count, 1);
 				if (slot < io.frame_cap) {
 					FrameRec fr;

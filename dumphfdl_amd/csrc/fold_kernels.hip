@@ -186,19 +186,25 @@ constexpr int IFFT_THREADS = 1024;
 // One thread runs it (it is a serial chain); ph[i] is the phasor that multiplies output i.
 __device__ __forceinline__ void nco_phasor_run(float2 *ph, int cnt, float starting_phase, float cd, float sd)
 {
+	// HIP's __fmul_rn / __fadd_rn are plain operators inside the headers and hipcc contracts a * b + c into an FMA by default,
+	// so they do NOT keep the products rounded separately.  The pragma on plain operators written HERE does, as the
+	// reference's x86-64 build rounds them (found by feeding tests/golden/nco_ref.npz straight to the device).
+#pragma clang fp contract(off)
 	float cphi = (float)cos((double)starting_phase), sphi = (float)sin((double)starting_phase);
 	for (int i = 0; i < cnt; i++) {
 		ph[i] = make_float2(cphi, sphi);
 		const float c0 = cphi, s0 = sphi;
-		cphi = __fsub_rn(__fmul_rn(c0, cd), __fmul_rn(s0, sd));
-		sphi = __fadd_rn(__fmul_rn(s0, cd), __fmul_rn(c0, sd));
+		cphi = c0 * cd - s0 * sd;
+		sphi = s0 * cd + c0 * sd;
 	}
 }
 
 // output[k] = input[i] * e^{j phi_k}, the reference's expression term for term (:54-57)
 __device__ __forceinline__ float2 nco_rotate(float2 p, float2 v)
 {
-	return make_float2(__fsub_rn(__fmul_rn(p.x, v.x), __fmul_rn(p.y, v.y)), __fadd_rn(__fmul_rn(p.y, v.x), __fmul_rn(p.x, v.y)));
+#pragma clang fp contract(off)
+	const float re = p.x * v.x - p.y * v.y, im = p.y * v.x + p.x * v.y;
+	return make_float2(re, im);
 }
 
 // carried state after a block of `cnt` outputs (:67-72): remainder of the decimation stride, phase advanced in double and

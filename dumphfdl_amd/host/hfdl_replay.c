@@ -13,6 +13,7 @@
  * --statsd-print stands in for dumphfdl's src/statsd.c: the strong statsd_* hooks below print one "STATSD" line per
  * counter total at exit and one per noise-floor gauge as it arrives (metric names as in doc/STATSD_METRICS.md).
  */
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -94,8 +95,14 @@ int main(int argc, char **argv)
 			}
 		}
 		else if (!strcmp(argv[i], "--noise-floor-stats-interval") && i + 1 < argc) hfdl_nf_stats_set_interval(atoi(argv[++i]));
-		else if (argv[i][0] != '-' && nfreq < 4096) freqs[nfreq++] = (int32_t)(1e3 * atof(argv[i]));     /* kHz -> Hz, src/main.c:197-212 */
-		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
+		else {
+			/* anything that reads as a number is a channel frequency in kHz (kHz -> Hz, src/main.c:197-212); synthetic plans
+			 * may carry negative ones */
+			char *end = NULL;
+			double khz = strtod(argv[i], &end);
+			if (end == argv[i] || *end != '\0' || nfreq >= 4096) { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
+			freqs[nfreq++] = (int32_t)lround(1e3 * khz);
+		}
 	}
 	if (!cfg->source || cfg->sample_rate < HFDL_SYMBOL_RATE * SPS || cfg->sfmt == SFMT_UNDEF || nfreq == 0) {
 		fprintf(stderr, "usage: %s --iq-file F --sample-rate HZ --sample-format FMT [--centerfreq KHZ] freq_khz...\n", argv[0]);

@@ -174,7 +174,8 @@ enum {
 	HFDL_GPU_TAP_MF_OUT = 5,         /* cf32[n], AGC + matched filter output of the last block */
 	HFDL_GPU_TAP_SYMBOLS = 6,        /* cf32[n], equalised on-time symbols of the last block */
 	HFDL_GPU_TAP_AGC_LEVEL = 7,      /* f32[n], agc signal level per 5400-sps sample */
-	HFDL_GPU_TAP_PHASE_CYCLES = 8    /* f32[4]: shader cycles the last demod launch spent in resampler / AGC / matched filter / symbol loop */
+	HFDL_GPU_TAP_PHASE_CYCLES = 8    /* f32[4]: shader cycles of the last demod launch: resampler phase, the whole three-wave pipelined phase (wall),
+	                                    busy cycles of the timing-recovery wave, busy cycles of the carrier / equaliser / framer wave */
 };
 /* Stage taps 4..8 make the demodulator write its intermediate samples to HBM every block; on by default (tests), a
  * production caller / the bench turns them off.  Taps 1..3 are always available (they are the kernels' own buffers). */
