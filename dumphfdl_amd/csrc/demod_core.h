@@ -52,6 +52,14 @@ __device__ __forceinline__ float row_scan_sum(float v)
 	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));
 	return __int_as_float(x);
 }
+// x / 3.0f, correctly rounded, without the IEEE division sequence (12 instructions on the timing loop's output path): reciprocal
+// multiply plus one FMA residual correction (Markstein); checked against true division over 6e4 random floats
+__device__ __forceinline__ float div3(float x)
+{
+	const float c = 0x1.555556p-2f;
+	const float q = x * c;
+	return __builtin_fmaf(__builtin_fmaf(-3.0f, q, x), c, q);
+}
 __device__ __forceinline__ float lane_value(float v, int lane)           // wave-uniform copy of one lane (lane is uniform)
 {
 	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -190,7 +198,7 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 			// four 18-tap dot products at once: row 0/1 = matched filter re/im, row 2/3 = derivative filter re/im
 			const float p = row_scan_sum(h.x * r.w_lo + h.y * r.w_hi);
 			const float mx = lane_value(p, 15), my = lane_value(p, 31);
-			if (lane == 0 && r.j < sh.outq_cap) { cf o; o.x = mx / 3.0f; o.y = my / 3.0f; sh.outq[r.j] = o; }
+			if (lane == 0 && r.j < sh.outq_cap) { cf o; o.x = div3(mx); o.y = div3(my); sh.outq[r.j] = o; }
 			r.j++;
 			if (r.decim == 2) {
 				r.decim = 0;
@@ -265,8 +273,11 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 	int j = jbase;
 	for (int k = k0; k < k1; k++, s.sample_cnt++) {
 		const float level = lane_value(lv_l, k - k0);
-		if (s.fr_state == FR_A1 && (++s.nf_clk & 0xFFu) == 0xFFu)
-			s.noise_floor = 0.65f * s.noise_floor + 0.35f * fminf(s.noise_floor, level) + 1e-6f;
+		if (s.fr_state == FR_A1) {
+			// every 256th sample only: a scalar branch, not a select evaluated on every sample
+			s.nf_clk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s.nf_clk + 1u));
+			if ((s.nf_clk & 0xFFu) == 0xFFu) s.noise_floor = 0.65f * s.noise_floor + 0.35f * fminf(s.noise_floor, level) + 1e-6f;
+		}
 		int j1 = __builtin_amdgcn_readlane(cum_l, k - k0);
 		if (j1 > sh.outq_cap) j1 = sh.outq_cap;
 		for (; j < j1; j++, s.symsync_out_idx++) {

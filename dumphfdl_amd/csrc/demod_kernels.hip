@@ -492,6 +492,7 @@ static DevTables resolve_tables(const float *d_img, const DemodTables &h)
 	t.c.m1_lo = (const uint64_t *)at(h.m1_lo);
 	t.scrambler = (const uint8_t *)at(h.scrambler);
 	t.c.corr_tab = (const float *)at(h.corr_tab);
+	t.c.a1_lo = h.a1_lo; t.c.a1_hi = h.a1_hi; t.c.a2_lo = h.a2_lo; t.c.a2_hi = h.a2_hi; t.c.pos_min = h.pos_min;
 	return t;
 }
 

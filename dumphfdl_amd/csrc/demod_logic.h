@@ -91,6 +91,7 @@ struct DemodConst {
 	uint64_t a_hi, a_lo;
 	const uint64_t *m1_hi, *m1_lo; // [8]
 	const float *corr_tab;         // [128]: 2.0f * m / 127.0f - 1.0f for m matching bits (the reference's expression, src/hfdl.c:781)
+	int32_t a1_lo, a1_hi, a2_lo, a2_hi, pos_min;      // the A1 / A2 thresholds on corr_tab as match counts (demod_tables.h)
 };
 
 // per-block scratch (LDS) and outputs (global)
@@ -343,9 +344,10 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 
 	switch (s.fr_state) {
 	case FR_A1: {
-		const float corr = T.corr_tab[bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo)];
-		if (fabsf(corr) > 0.36f) {
-			s.bitmask = corr > 0.f ? 0u : ~0u;
+		// |corr| > 0.36 on the fp32 table == a match count outside (a1_lo, a1_hi): no table look-up on the every-symbol path
+		const int m = bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo);
+		if (m <= T.a1_lo || m >= T.a1_hi) {
+			s.bitmask = m >= T.pos_min ? 0u : ~0u;
 			s.signal_level = level;
 			s.frame_symbol_cnt = 1.0f;
 			s.symbols_wanted = A_LEN;
@@ -354,8 +356,8 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 		}
 		break; }
 	case FR_A2: {
-		const float corr = T.corr_tab[bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo)];
-		if (fabsf(corr) > 0.3f) {
+		const int m = bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo);
+		if (m <= T.a2_lo || m >= T.a2_hi) {
 			s.cnt_a2_found++;                    // statsd "demod.preamble.A2_found"
 			s.pdu_sample_index = s.sample_cnt;
 			s.freq_err_hz = (float)((double)(s.dphi * 1800) / (2.0 * M_PI));

@@ -29,6 +29,10 @@ struct DemodTables {
 	uint64_t a_hi, a_lo, m1_hi[8], m1_lo[8];
 	uint8_t scrambler[120];
 	float corr_tab[128];
+	// the preamble thresholds of src/hfdl.c:42-44 as match counts: |corr_tab[m]| > 0.36 <=> m <= a1_lo or m >= a1_hi (the
+	// table is monotonic in m), same for 0.30 (A2); corr_tab[m] > 0 <=> m >= pos_min.  Derived FROM the fp32 table, so the
+	// integer tests decide exactly as the reference's float comparisons do.
+	int32_t a1_lo, a1_hi, a2_lo, a2_hi, pos_min, thr_pad;
 };
 
 namespace tables_detail {
@@ -143,6 +147,13 @@ inline void build_demod_tables(DemodTables &t, float resamp_rate)
 		v = v / (float)127;
 		v = v - 1.0f;
 		t.corr_tab[m] = v;
+	}
+	t.a1_lo = t.a2_lo = -1; t.a1_hi = t.a2_hi = t.pos_min = 128; t.thr_pad = 0;
+	for (int m = 0; m < 128; m++) {
+		const float c = t.corr_tab[m];
+		if (std::fabs(c) > 0.36f) { if (c < 0.f) t.a1_lo = m; else if (m < t.a1_hi) t.a1_hi = m; }
+		if (std::fabs(c) > 0.3f) { if (c < 0.f) t.a2_lo = m; else if (m < t.a2_hi) t.a2_hi = m; }
+		if (c > 0.f && m < t.pos_min) t.pos_min = m;
 	}
 	// --- descrambler: x^15 + x + 1 LFSR, fill 0x4d4b, 120-symbol period
 	{

@@ -43,6 +43,7 @@ Sim *sim_create(float resamp_rate, int cap)
 	s->K.lf_b0 = s->tab.lf_b0; s->K.lf_a1 = s->tab.lf_a1; s->K.ss_rate_adj = s->tab.ss_rate_adj;
 	s->K.eq_h0 = s->tab.eq_h0; s->K.a_hi = s->tab.a_hi; s->K.a_lo = s->tab.a_lo;
 	s->K.m1_hi = s->tab.m1_hi; s->K.m1_lo = s->tab.m1_lo; s->K.corr_tab = s->tab.corr_tab;
+	s->K.a1_lo = s->tab.a1_lo; s->K.a1_hi = s->tab.a1_hi; s->K.a2_lo = s->tab.a2_lo; s->K.a2_hi = s->tab.a2_hi; s->K.pos_min = s->tab.pos_min;
 	chan_state_init(s->st, s->tab.eq_h0);
 	s->cap = cap;
 	s->rs.resize(cap); s->agc.resize(cap); s->mf.resize(cap); s->lvl.resize(cap);

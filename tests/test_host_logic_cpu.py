@@ -112,7 +112,8 @@ def test_demod_tables_match_oracle(sim, oracle):
                     ("ss_mf", C.c_float * 288), ("ss_dmf", C.c_float * 288), ("lf_b0", C.c_float), ("lf_a1", C.c_float),
                     ("ss_rate_adj", C.c_float), ("eq_h0", C.c_float * 15), ("a_hi", C.c_uint64), ("a_lo", C.c_uint64),
                     ("m1_hi", C.c_uint64 * 8), ("m1_lo", C.c_uint64 * 8), ("scrambler", C.c_uint8 * 120),
-                    ("corr_tab", C.c_float * 128)]
+                    ("corr_tab", C.c_float * 128), ("a1_lo", C.c_int32), ("a1_hi", C.c_int32), ("a2_lo", C.c_int32),
+                    ("a2_hi", C.c_int32), ("pos_min", C.c_int32), ("thr_pad", C.c_int32)]
     sim.sim_sizeof_tables.restype = C.c_size_t
     assert sim.sim_sizeof_tables() == C.sizeof(T)
     for rate in (0.6912, 0.55296):
@@ -133,7 +134,13 @@ def test_demod_tables_match_oracle(sim, oracle):
     oracle.lib().orc_scrambler_bits(sb.ctypes.data, 120)
     assert bytes(t.scrambler) == bytes(sb)
     m = np.arange(128, dtype=np.float32)
-    assert np.array_equal(np.frombuffer(t.corr_tab, np.float32), np.float32(2.0) * m / np.float32(127) - np.float32(1.0))
+    corr = np.float32(2.0) * m / np.float32(127) - np.float32(1.0)
+    assert np.array_equal(np.frombuffer(t.corr_tab, np.float32), corr)
+    # the integer form of the preamble thresholds decides exactly like the fp32 comparisons of src/hfdl.c:781-800
+    for k in range(128):
+        assert (abs(corr[k]) > np.float32(0.36)) == (k <= t.a1_lo or k >= t.a1_hi)
+        assert (abs(corr[k]) > np.float32(0.3)) == (k <= t.a2_lo or k >= t.a2_hi)
+        assert (corr[k] > 0) == (k >= t.pos_min)
 
 
 def test_psk_soft_matches_oracle(sim, oracle):
