@@ -138,3 +138,39 @@ def test_poll_sequence_drain_then_snapshot(gpu):
     assert L.hfdl_gpu_frontend_poll_pdus(fe._h, None, 4, C.byref(k)) == -1
     assert L.hfdl_gpu_frontend_poll_pdus_ready(fe._h, None, 4, C.byref(k), 1) == -1
     fe.close()
+
+
+def _run_bench(args, nproc, port, tmp_path, tag):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dump = str(tmp_path / tag)
+    base = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--no-cpu-baseline", "--no-extra-legs", "--dump-pdus", dump] + args
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + base + ["--backend", "gloo"]
+    else:
+        cmd = [sys.executable] + base
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    keys = []
+    for r in range(nproc):
+        keys.append([tuple(k) for k in json.load(open("%s.rank%d.json" % (dump, r)))])
+    return json.loads(line[0]), keys
+
+
+def test_single_stream_channel_sharded_union_equals_unsharded(tmp_path):
+    """SURVEY.md 8(e), one stream over G GPUs: `bench.py --shard channels` gives every rank the SAME wideband stream and a
+    round-robin subset of the channels (here 2 ranks on the one GPU of the test box).  The union of the ranks' PDUs must be
+    the unsharded run's PDU set -- same (freq, sample_index, mode, octets) -- with no channel decoded twice."""
+    args = ["--workload", "cfg2", "--steps", "26", "--warmup", "0", "--shard", "channels"]
+    whole, k1 = _run_bench(args, 1, 0, tmp_path, "whole")
+    parts, k2 = _run_bench(args, 2, 29547, tmp_path, "parts")
+    assert whole["config"]["channels"] == parts["config"]["channels"] == 32 and parts["config"]["channels_rank0"] == 16
+    assert parts["scaling"] == "strong" and parts["config"]["stream_seeds"] == [2, 2]
+    assert parts["steps"] == 26 and abs(parts["value"] * 1e6 * parts["ms_per_step"] * 26e-3 - 26 * 917504) < 30     # ONE stream's samples
+    f0, f1 = {k[0] for k in k2[0]}, {k[0] for k in k2[1]}
+    assert not f0 & f1                                            # channel partition
+    assert sorted(k2[0] + k2[1]) == sorted(k1[0]) and len(k1[0]) >= 30
+    assert parts["pdus_in_timed_region"] == whole["pdus_in_timed_region"] == len(k1[0])
+    assert parts["pdus_matching_sent_payload"] == parts["pdus_in_timed_region"]
