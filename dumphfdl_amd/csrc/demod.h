@@ -16,11 +16,13 @@ struct Demod {
 	float *d_tables = nullptr;              // packed DemodTables image
 	ChanState *d_states = nullptr;
 	float2 *d_data = nullptr;               // [nch][2][5040] equalised data symbols
-	FrameRec *d_frames = nullptr;
-	int *d_counts = nullptr;                // [1] pdus produced, [2] pdus dropped, [3] pdus taken by the host, [4],[5] frames queued (even / odd block)
+	FrameRec *d_frames = nullptr;           // [2][nch]: frames finished by the demodulator of an even / odd block
+	int *d_counts = nullptr;                // [1] pdus produced, [2] pdus dropped, [3] pdus taken by the host, [4..7] frames queued, one counter per block mod 4
 	int *h_snap = nullptr;                  // pinned [2][4]: d_counts as of the end of the block that used buffer 0 / 1
 	uint32_t taken = 0, dropped = 0;
-	uint64_t launches = 0;
+	uint64_t launches = 0, decodes = 0;
+	bool separate_decode = false;           // the burst decoder runs on another stream than the demodulator
+	hipEvent_t ev_dec[2] = { nullptr, nullptr };   // decoder of an even / odd launch done: its frame queue and counter may be reused
 	hfdl_gpu_pdu *d_pdus = nullptr;
 	int32_t *d_freqs = nullptr;
 	int pdu_cap = 0;
@@ -34,7 +36,8 @@ struct Demod {
 	void *priv = nullptr;                   // DemodPriv (host image of the tables + resolved device pointers)
 
 	int init(int nch, int outs, float resamp_rate, const int32_t *freqs, hipStream_t st);
-	int enqueue_block(const float2 *chan_out, const int *out_count, int buf, hipStream_t st);
+	int enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st);    // K4 of a block
+	int enqueue_decode(int buf, hipStream_t st);                                              // K5 + PDU-ring snapshot of the same block
 	int collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);                    // stream idle: everything produced
 	int collect_snapshot(int buf, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);  // up to the end of that buffer's block
 	int take(unsigned produced, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const int f = blockIdx.x, lane = threadIdx.x;
 	int nframes = *nframes_ptr;
-	if (f == 0 && lane == 0 && stale_count) *stale_count = 0;      // the other block's counter: its decoder finished before this launch began
+	if (f == 0 && lane == 0 && stale_count) *stale_count = 0;      // the counter of the launch after next: its last users finished before this launch began
 	if (nframes > frame_cap) nframes = frame_cap;
 	if (f >= nframes) return;
 	uint8_t *table = lds;
@@ -523,7 +523,7 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	D_TRY(hipMemcpy(d_states, init.data(), sizeof(ChanState) * (size_t)nch, hipMemcpyHostToDevice));
 	D_TRY(hipMalloc(&d_data, sizeof(float2) * (size_t)nch * 2 * MAX_DATA_SYMBOLS));
 	D_TRY(hipMemsetAsync(d_data, 0, sizeof(float2) * (size_t)nch * 2 * MAX_DATA_SYMBOLS, st));
-	D_TRY(hipMalloc(&d_frames, sizeof(FrameRec) * (size_t)nch));
+	D_TRY(hipMalloc(&d_frames, sizeof(FrameRec) * 2 * (size_t)nch));
 	D_TRY(hipMalloc(&d_counts, sizeof(int) * 8));
 	D_TRY(hipMemsetAsync(d_counts, 0, sizeof(int) * 8, st));
 	D_TRY(hipHostMalloc((void **)&h_snap, sizeof(int) * 8, hipHostMallocDefault));
@@ -553,24 +553,43 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	return 0;
 }
 
-int Demod::enqueue_block(const float2 *chan_out, const int *out_count, int buf, hipStream_t st)
+// Frames finished by the demodulator of launch i are queued in d_frames[i & 1] and counted in d_counts[4 + (i & 3)].  The
+// burst decoder of launch i may run on another stream than the demodulator of launch i+1; it zeroes the counter of launch i+2,
+// whose previous users (launch i-2) are done and whose next user (the demodulator of launch i+2) is made to wait for this
+// decoder by the caller -- no memset launch per block, no counter shared by two kernels that can overlap.
+int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st)
 {
 	DemodPriv *pv = priv_of(this);
 	if (!pv) return HFDL_GPU_EINVAL;
+	(void)buf;
 	DemodBuffers B;
-	// frames queued by the demodulator of this block: counter 4 + parity; the burst decoder of this block zeroes the OTHER
-	// one (consumed by the previous block's decoder, next used by the next block's demodulator) -- no memset launch per block
-	const int par = (int)(launches++ & 1);      // alternates per demodulator launch (not per block: channelize-only blocks launch none)
-	int *fc = d_counts + 4 + par, *fc_other = d_counts + 4 + (par ^ 1);
-	B.states = d_states; B.data = (cf *)d_data; B.frames = d_frames; B.counts = d_counts; B.frame_count = fc; B.frame_cap = nch;
+	const uint64_t i = launches++;          // per demodulator launch (not per block: channelize-only blocks launch none)
+	if (separate_decode && ev_dec[i & 1]) D_TRY(hipStreamWaitEvent(st, ev_dec[i & 1], 0));      // the decoder of launch i-2 has read this frame queue
+	B.states = d_states; B.data = (cf *)d_data; B.frames = d_frames + (size_t)(i & 1) * nch; B.counts = d_counts;
+	B.frame_count = d_counts + 4 + (int)(i & 3); B.frame_cap = nch;
 	const bool tw = taps_on && taps_enabled;
 	B.tap_rs = tw ? (cf *)d_tap_rs : nullptr; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
 	B.cap = cap;
 	hipLaunchKernelGGL(demod_kernel, dim3((unsigned)nch), dim3(DM_THREADS), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
-	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)d_frames, d_counts, fc, fc_other, nch,
+	D_TRY(hipGetLastError());
+	return 0;
+}
+
+int Demod::enqueue_decode(int buf, hipStream_t st)
+{
+	DemodPriv *pv = priv_of(this);
+	if (!pv) return HFDL_GPU_EINVAL;
+	const uint64_t i = decodes++;
+	if (i + 1 != launches) return HFDL_GPU_EINVAL;      // one decoder launch per demodulator launch, in order
+	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)(d_frames + (size_t)(i & 1) * nch), d_counts,
+			d_counts + 4 + (int)(i & 3), d_counts + 4 + (int)((i + 2) & 3), nch,
 			(const cf *)d_data, pv->t.scrambler, (const int32_t *)d_freqs, d_pdus, pdu_cap);
 	// what the ring holds once this block is done, for a host that collects without draining the pipeline
 	D_TRY(hipMemcpyAsync(h_snap + 4 * (buf & 1), d_counts, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+	if (separate_decode) {
+		if (!ev_dec[i & 1]) D_TRY(hipEventCreateWithFlags(&ev_dec[i & 1], hipEventDisableTiming));
+		D_TRY(hipEventRecord(ev_dec[i & 1], st));
+	}
 	D_TRY(hipGetLastError());
 	return 0;
 }
@@ -660,6 +679,7 @@ void Demod::release()
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (h_snap) (void)hipHostFree(h_snap);
 	h_snap = nullptr;
+	for (auto &e : ev_dec) { if (e) (void)hipEventDestroy(e); e = nullptr; }
 	d_tables = nullptr; d_states = nullptr; d_data = nullptr; d_frames = nullptr; d_counts = nullptr; d_pdus = nullptr; d_freqs = nullptr;
 	d_tap_rs = d_tap_mf = d_tap_sym = nullptr; d_tap_lvl = nullptr; d_tap_counts = nullptr;
 	delete (DemodPriv *)priv;

@@ -112,7 +112,10 @@ int HostFftPlan::build(int n)
 struct hfdl_gpu_frontend {
 	int device = 0;
 	hipStream_t stream = nullptr;       // A: ingest + forward FFT + fold + inverse FFT/NCO of block k
-	hipStream_t stream_b = nullptr;     // B: demodulator + burst decoder of block k-1, concurrent with the fold of block k
+	hipStream_t stream_b = nullptr;     // B: demodulator (+ burst decoder, unless it has its own stream) of block k-1, concurrent with the fold of block k
+	hipStream_t stream_d = nullptr;     // D: burst decoder + PDU snapshot when the demodulator bounds the block (few channels); else == stream_b
+	bool own_decode_stream = false;
+	hipEvent_t ev_dm[2] = { nullptr, nullptr };      // demodulator kernel of the block in buffer 0 / 1 done (chan_out free; the decoder may start)
 	hipStream_t stream_c = nullptr;     // C: host -> device copies of block k+1 into the other staging buffer
 	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
 	hipEvent_t ev_stage_ready[2] = { nullptr, nullptr }, ev_stage_free[2] = { nullptr, nullptr };
@@ -154,9 +157,10 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	(void)hipSetDevice(fe->device);
 	if (fe->stream) (void)hipStreamSynchronize(fe->stream);
 	if (fe->stream_b) (void)hipStreamSynchronize(fe->stream_b);
+	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamSynchronize(fe->stream_d);
 	if (fe->stream_c) (void)hipStreamSynchronize(fe->stream_c);
 	for (int i = 0; i < 2; i++)
-		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_stage_ready[i], fe->ev_stage_free[i] }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_dm[i], fe->ev_stage_ready[i], fe->ev_stage_free[i] }) if (e) (void)hipEventDestroy(e);
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	if (fe->ev_fft) (void)hipEventDestroy(fe->ev_fft);
 	if (fe->ev_first_fold) (void)hipEventDestroy(fe->ev_first_fold);
@@ -166,6 +170,7 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_out_count[0], fe->d_out_count[1] };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (fe->stream) (void)hipStreamDestroy(fe->stream);
+	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamDestroy(fe->stream_d);
 	if (fe->stream_b) (void)hipStreamDestroy(fe->stream_b);
 	if (fe->stream_c) (void)hipStreamDestroy(fe->stream_c);
 	delete fe;
@@ -280,11 +285,24 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 		FE_TRY(hipStreamCreateWithFlags(&fe->stream_b, hipStreamNonBlocking));
 	}
 	FE_TRY(hipStreamCreateWithFlags(&fe->stream_c, hipStreamNonBlocking));
+	{
+		// The burst decoder of block k only hands PDUs to the host; the demodulator of block k+1 does not need it.  With few
+		// channels the demodulator (a serial recurrence per channel, ~0.3 ms per block whatever the channel count) bounds the
+		// block, and a frame ending in a block puts 0.3 ms of Viterbi on the same stream: the decoder then gets its own stream
+		// (cfg2: +25 %).  With many channels the fold bounds the block, stream B has slack, and one more busy hardware queue
+		// costs the fold more than it saves (profiles/r01_experiments.md): the decoder stays on stream B.
+		fe->own_decode_stream = nch < 128;
+		if (const char *e = getenv("HFDL_GPU_DECODE_STREAM")) fe->own_decode_stream = atoi(e) != 0;      // A/B measurements
+		if (fe->own_decode_stream) FE_TRY(hipStreamCreateWithFlags(&fe->stream_d, hipStreamNonBlocking));
+		else fe->stream_d = fe->stream_b;
+		fe->demod.separate_decode = fe->own_decode_stream;
+	}
 	for (int i = 0; i < 2; i++) {
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_ready[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_free[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_chan[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_demod[i], hipEventDisableTiming));
+		FE_TRY(hipEventCreateWithFlags(&fe->ev_dm[i], hipEventDisableTiming));
 	}
 	if ((rc = fe->fft.build(pl.n))) { frontend_free(fe); return rc; }
 	const size_t n = (size_t)pl.n;
@@ -431,9 +449,13 @@ static int launch_demod(hfdl_gpu_frontend *fe, int buf, bool after_fft)
 	// the forward FFT of the next block follows this block's inverse FFT on stream A, so its event covers ev_chan too
 	if (after_fft) HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_fft, 0));
 	else HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
-	int rc = fe->demod.enqueue_block(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b);
+	int rc = fe->demod.enqueue_demod(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b);
 	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
-	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_b));
+	HIP_TRY(hipEventRecord(fe->ev_dm[buf], fe->stream_b));
+	if (fe->own_decode_stream) HIP_TRY(hipStreamWaitEvent(fe->stream_d, fe->ev_dm[buf], 0));
+	rc = fe->demod.enqueue_decode(buf, fe->stream_d);
+	if (rc) return fail(rc, "burst decoder enqueue failed: %s", hipGetErrorString(hipGetLastError()));
+	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_d));
 	return 0;
 }
 
@@ -472,7 +494,7 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 	} else {
 		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
 	}
-	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_demod[buf], 0));       // chan_out[buf] is free once demod(k-2) has read it
+	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm[buf], 0));          // chan_out[buf] is free once demod(k-2) has read it
 	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_tw_m, fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream, fe->ev_chan[buf]);
 	HIP_TRY(hipGetLastError());
 	fe->blocks++;
@@ -542,6 +564,7 @@ extern "C" int hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe)
 	HIP_TRY(hipStreamSynchronize(fe->stream_c));
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipStreamSynchronize(fe->stream_b));
+	if (fe->own_decode_stream) HIP_TRY(hipStreamSynchronize(fe->stream_d));
 	HIP_TRY(hipGetLastError());
 	return drain_events(fe);
 }
@@ -622,7 +645,7 @@ extern "C" int hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *
 	if (!out && max > 0) return fail(HFDL_GPU_EINVAL, "null PDU buffer with max = %d", max);
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
-	rc = fe->demod.collect(out, max, n, fe->stream_b);
+	rc = fe->demod.collect(out, max, n, fe->stream_d);
 	if (rc) return fail(rc, "pdu collection failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;
 }
@@ -638,7 +661,7 @@ extern "C" int hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu
 	if (buf < 0) return 0;                              // fewer than two blocks pushed: nothing is known to be done
 	HIP_TRY(hipSetDevice(fe->device));
 	HIP_TRY(hipEventSynchronize(fe->ev_demod[buf]));
-	int rc = fe->demod.collect_snapshot(buf, out, max, n, fe->stream_b);
+	int rc = fe->demod.collect_snapshot(buf, out, max, n, fe->stream_d);
 	if (rc) return fail(rc, "pdu collection failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;
 }
