@@ -26,7 +26,10 @@
 
 namespace hfdl {
 
-constexpr int DM_WAVES = 3, DM_THREADS = 64 * DM_WAVES, DM_CHUNK = 32;
+#ifndef HFDL_DM_CHUNK
+#define HFDL_DM_CHUNK 32
+#endif
+constexpr int DM_WAVES = 3, DM_THREADS = 64 * DM_WAVES, DM_CHUNK = HFDL_DM_CHUNK;      // chunk: measured, profiles/r02_experiments.md
 
 // ---- DPP helpers (GFX9 encodings): all row-local, a row = 16 lanes ----
 __device__ __forceinline__ float dpp_row_shr1(float old, float src)      // lane i <- src[i-1]; lane 0 of every row <- old
@@ -271,6 +274,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 	const int jbase = k0 > 0 ? (int)sh.cum[k0 - 1] : 0;
 	const cf oq_l = (jbase + lane < sh.outq_cap) ? sh.outq[jbase + lane] : cf{0.f, 0.f};
 	int j = jbase;
+	bool runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
 	for (int k = k0; k < k1; k++, s.sample_cnt++) {
 		const float level = lane_value(lv_l, k - k0);
 		if (s.fr_state == FR_A1) {
@@ -294,18 +298,20 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 			cf r;
 			r.x = oi.x * cp + oi.y * sp;
 			r.y = oi.y * cp - oi.x * sp;
-			if (fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1) {
+			if (runaway) {                       // costas run-away while searching (src/hfdl.c:709-716); dphi only moves in on_symbol()
 				s.dphi = s.phi = 0.f;
 				symsync_reset(s, a);
+				runaway = false;
 			}
 			// eqlms_cccf_push: park the new sample in lane 15 of the row, then shift the row down one lane
 			{
 				const float x2n = r.x * r.x + r.y * r.y;
 				const float x2o = lane_value(c.ex2, 0);
 				const float nu = row1 ? r.y : r.x, nv = row1 ? -r.x : r.y;
-				c.eu = dpp_row_shl1(0.f, ins ? nu : c.eu);
-				c.ev = dpp_row_shl1(0.f, ins ? nv : c.ev);
-				c.ex2 = dpp_row_shl1(0.f, ins ? x2n : c.ex2);
+				const float su = ins ? nu : c.eu, sv = ins ? nv : c.ev, sx = ins ? x2n : c.ex2;
+				c.eu = dpp_row_shl1(su, su);         // lane 15 of a row (outside the 15-tap window) keeps the parked sample: don't care
+				c.ev = dpp_row_shl1(sv, sv);
+				c.ex2 = dpp_row_shl1(sx, sx);
 				s.eq_x2sum = s.eq_x2sum + x2n - x2o;
 				s.eq_count++;
 			}
@@ -330,6 +336,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				if (io.tap_symbols && lane == 0) io.tap_symbols[nsym] = y;
 				nsym++;
 				on_symbol(s, a, T, io, y, level);
+				runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
 			}
 			if (s.ev_flags & EV_EQ_RESET) {      // eqlms_cccf_reset ran (framer reset): mirror it in the register window
 				c.eu = 0.f; c.ev = 0.f; c.ex2 = 0.f;

@@ -1,9 +1,24 @@
 #!/bin/bash
-# HBM traffic of the fold kernel: separate counter passes (FETCH_SIZE, WRITE_SIZE, L2 hit/miss), kernel trace only.
+# HBM traffic and issue statistics per kernel: SEPARATE rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE, L2 hit/miss, SQ),
+# each with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
+#   profiles/pmc_passes.sh <workload> <outdir> [commit]
+WL=${1:-cfg3}
+OUT=${2:-/root/repo/gpurun_out/pmc_$WL}
+COMMIT=${3:-unknown}
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/pmc_*
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
-	d=/tmp/pmc_$(echo $c | tr ' ' '_')
-	rocprofv3 --pmc $c --kernel-trace -d $d -- python /root/repo/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $d.log 2>&1
+rm -rf /tmp/pmc_${WL}_*
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+	d=/tmp/pmc_${WL}_$(echo $c | tr ' ' '_' | cut -c1-40)
+	rocprofv3 --pmc $c --kernel-trace -d $d -- python /root/repo/bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-extra-legs > $d.log 2>&1
 done
-python /root/repo/profiles/pmc_summary.py $(find /tmp/pmc_* -name "*.db" | sort)
+DBS=$(find /tmp/pmc_${WL}_* -name "*.db" | sort)
+{
+	echo "# r02 $WL PMC passes (profiles/pmc_passes.sh $WL: rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-extra-legs, one pass per counter set; commit $COMMIT)"
+	echo
+	echo "Per-dispatch averages. FETCH_SIZE / WRITE_SIZE in KB; on gfx950 reads = 2 x FETCH_SIZE for wide coalesced streaming reads (calibrated in the same run on stream_read_kernel, which reads a known byte count). SQ_* count quad-cycles summed over the dispatch's waves."
+	echo
+	python /root/repo/profiles/pmc_summary.py $DBS
+} > $OUT/${WL}_pmc_counters.md
+python /root/repo/profiles/fold_traffic.py $WL $COMMIT $DBS > $OUT/fold_traffic_${WL}.json
+cat $OUT/fold_traffic_${WL}.json
