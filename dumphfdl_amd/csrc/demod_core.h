@@ -11,12 +11,12 @@
 // with one rare exception, so they run concurrently on three SIMDs of the CU:
 //
 //   wave 0   AGC recurrence (agc_crcf_execute) + matched filter (lanes over outputs) of chunk s
-//   wave 1   symsync_crcf of chunk s-1: register-resident filter windows, four dot products per DPP row reduction
+//   wave 1   symsync_crcf of chunk s-1: every output gathers its 18-tap windows from LDS, four dot products per DPP row reduction
 //   wave 2   Costas loop, equaliser, slicer, framer FSM of chunk s-2 (demod_logic.h on_symbol)
 //
 // The exception: the framer resets the timing loop (symsync_crcf_reset at the end of a frame, on a failed preamble search,
 // on carrier run-away: src/hfdl.c:714,751,969).  Wave 1 therefore runs AHEAD speculatively; when wave 2 hits a reset at
-// sample k it publishes k, and wave 1 restarts at k+1 from the reset state, which is fully determined (zero matched-filter
+// sample k it publishes k, and wave 1 restarts at k+1 from the reset state, which is fully determined (empty matched-filter
 // window, the last 18 matched-filter samples in the derivative window, initial loop scalars).  Results are those of the
 // serial order, sample for sample; resets are rare (once per frame), so the re-run costs nothing measurable.
 // The waves meet at one workgroup barrier per chunk and exchange progress through a double-buffered LDS mailbox.
@@ -127,100 +127,96 @@ __device__ __forceinline__ void agc_mf_chunk(float &g, float &y2, const ChanArra
 
 // ---------------- wave 1: symbol timing recovery (symsync_crcf_execute, src/hfdl.c:696) ----------------
 
+// The filter windows are not kept anywhere: window sample `age` of input sample k is matched-filter output k - age, and the
+// block's matched-filter outputs sit in LDS behind a prefix holding the previous block's last 18 (SS_HIST entries before
+// mf[0], padded so that the unused "tap t + 16" reads of lanes t >= 2 stay in bounds).  Every output GATHERS its taps with
+// one LDS read per lane, issued one input sample ahead; nothing is shifted per input sample.  liquid's symsync_crcf_reset
+// clears the matched-filter window only: `valid_from` is the first input sample whose matched-filter window entries count
+// (older ones read as zero in rows 0, 1); ChanScalars.ss_head carries it from block to block (<= 0 at block start).
+constexpr int SS_HIST = 34;
 struct SymsyncRegs {
-	float w_lo, w_hi;              // this lane's window samples: tap t and tap t+16 of its row's component (rows 0,1: matched; 2,3: derivative)
 	float rate, del, tau, bf, q, qhat, v1;
 	int b, decim, j;               // filter-bank index, decimation counter, running output index of the block
+	int valid_from;
 };
 
-// window sample of age `age` (0 = newest) before input sample k0: from this block's matched-filter output, or the window the
-// previous block left (canonical array form: index 0 newest, index 18 - age older)
-__device__ __forceinline__ float ss_hist_sample(const ChanArrays &a, const cf *mf, int k0, int age, bool imag)
+__device__ __forceinline__ void symsync_load(SymsyncRegs &r, const ChanScalars &s, const ChanArrays &a, const BlockIo &io, int lane)
 {
-	const int i = k0 - 1 - age;
-	cf v;
-	if (i >= 0) v = mf[i];
-	else { const int t = -1 - i; v = a.ss_dmf[t == 0 ? 0 : D_SS_TAPS - t]; }
-	return imag ? v.y : v.x;
-}
-
-__device__ __forceinline__ void symsync_load(SymsyncRegs &r, const ChanScalars &s, const ChanArrays &a, int lane)
-{
-	const int row = lane >> 4, t = lane & 15;
-	const cf *src = row < 2 ? a.ss_mf : a.ss_dmf;
-	const cf lo = src[t == 0 ? 0 : D_SS_TAPS - t];
-	const cf hi = src[D_SS_TAPS - 16 - t >= 0 ? D_SS_TAPS - 16 - t : 0];      // taps 16, 17 (t = 0, 1)
-	r.w_lo = (row & 1) ? lo.y : lo.x;
-	r.w_hi = t < D_SS_TAPS - 16 ? ((row & 1) ? hi.y : hi.x) : 0.f;
+	// history prefix: mf[-1 - age] = the window the previous block left (canonical array form: index 0 newest, 18 - age older)
+	if (lane < SS_HIST) {
+		cf v; v.x = 0.f; v.y = 0.f;
+		if (lane < D_SS_TAPS) v = a.ss_dmf[lane == 0 ? 0 : D_SS_TAPS - lane];
+		io.mf[-1 - lane] = v;
+	}
 	r.rate = s.ss_rate; r.del = s.ss_del; r.tau = s.ss_tau; r.bf = s.ss_bf; r.q = s.ss_q; r.qhat = s.ss_qhat; r.v1 = s.ss_v1;
 	r.b = s.ss_b; r.decim = (int)s.ss_decim; r.j = 0;
+	r.valid_from = s.ss_head;
 }
 
-// symsync_crcf_reset as the framer left it after input sample k0-1: loop scalars initial, matched-filter window cleared
-// (liquid clears that one only), derivative window = the last 18 matched-filter samples
-__device__ __forceinline__ void symsync_restart(SymsyncRegs &r, const ChanArrays &a, const BlockIo &io, const DemodShared &sh, int k0, int lane)
+// symsync_crcf_reset as the framer left it after input sample k0-1: loop scalars initial, matched-filter window empty
+__device__ __forceinline__ void symsync_restart(SymsyncRegs &r, const DemodShared &sh, int k0)
 {
-	const int row = lane >> 4, t = lane & 15;
 	r.rate = 1.5f; r.del = 1.5f; r.tau = 0.f; r.bf = 0.f; r.q = 0.f; r.qhat = 0.f; r.v1 = 0.f;
 	r.b = 0; r.decim = 0;
 	r.j = k0 > 0 ? (int)sh.cum[k0 - 1] : 0;
-	if (row < 2) { r.w_lo = 0.f; r.w_hi = 0.f; }
-	else {
-		r.w_lo = ss_hist_sample(a, io.mf, k0, t, row & 1);
-		r.w_hi = t < D_SS_TAPS - 16 ? ss_hist_sample(a, io.mf, k0, t + 16, row & 1) : 0.f;
-	}
+	r.valid_from = k0;
 }
 
-__device__ __forceinline__ void symsync_store(const SymsyncRegs &r, ChanScalars &s, ChanArrays &a, int lane)
+__device__ __forceinline__ void symsync_store(const SymsyncRegs &r, ChanScalars &s, ChanArrays &a, const BlockIo &io, int n_out, int lane)
 {
-	const int row = lane >> 4, t = lane & 15;
-	cf *dst = row < 2 ? a.ss_mf : a.ss_dmf;
-	float *lo = (float *)&dst[t == 0 ? 0 : D_SS_TAPS - t];
-	lo[row & 1] = r.w_lo;
-	if (t < D_SS_TAPS - 16) ((float *)&dst[D_SS_TAPS - 16 - t])[row & 1] = r.w_hi;
+	if (lane < D_SS_TAPS) a.ss_dmf[lane == 0 ? 0 : D_SS_TAPS - lane] = io.mf[n_out - 1 - lane];      // reaches into the prefix when n_out < 18
 	if (lane == 0) {
 		s.ss_rate = r.rate; s.ss_del = r.del; s.ss_tau = r.tau; s.ss_bf = r.bf; s.ss_q = r.q; s.ss_qhat = r.qhat; s.ss_v1 = r.v1;
-		s.ss_b = r.b; s.ss_decim = (uint32_t)r.decim; s.ss_head = 0;
+		s.ss_b = r.b; s.ss_decim = (uint32_t)r.decim;
+		const int vf = r.valid_from - n_out;
+		s.ss_head = vf < -64 ? -64 : vf;
 	}
 }
 
 __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &T, const BlockIo &io, const DemodShared &sh, int k0, int k1, int lane)
 {
-	const bool imag = (lane >> 4) & 1;
-	const cf min = (k0 + lane < k1) ? io.mf[k0 + lane] : cf{0.f, 0.f};          // the chunk's matched-filter outputs, one per lane
+	const int row = lane >> 4, t = lane & 15;
+	// &mf[k - t].component of this lane's row for k = 0; tap t + 16 is 16 samples further back
+	const float *base = (const float *)(io.mf - t) + (row & 1);
 	int bi = r.b < 0 ? 0 : (r.b >= D_SS_NPFB ? D_SS_NPFB - 1 : r.b);
 	float2 h = sh.sstab[bi * 64 + lane];
+	float w_lo = base[2 * k0], w_hi = base[2 * (k0 - 16)];
 	for (int k = k0; k < k1; k++) {
-		// push one sample into both windows: tap t <- tap t-1 inside every row, tap 16 <- tap 15 through the row rotate
-		const float nv = imag ? lane_value(min.y, k - k0) : lane_value(min.x, k - k0);
-		const float t15 = dpp_row_ror1(r.w_lo);
-		r.w_hi = dpp_row_shr1(t15, r.w_hi);
-		r.w_lo = dpp_row_shr1(nv, r.w_lo);
-		int produced = 0;
-		while (r.b < D_SS_NPFB && produced < 4) {
-			// four 18-tap dot products at once: row 0/1 = matched filter re/im, row 2/3 = derivative filter re/im
-			const float p = row_scan_sum(h.x * r.w_lo + h.y * r.w_hi);
-			const float mx = lane_value(p, 15), my = lane_value(p, 31);
-			if (lane == 0 && r.j < sh.outq_cap) { cf o; o.x = div3(mx); o.y = div3(my); sh.outq[r.j] = o; }
-			r.j++;
-			if (r.decim == 2) {
-				r.decim = 0;
-				const float dx = lane_value(p, 47), dy = lane_value(p, 63);
-				float q = mx * dx + my * dy;
-				q = q > 1.0f ? 1.0f : (q < -1.0f ? -1.0f : q);
-				r.q = q;
-				const float v0 = q - T.lf_a1 * r.v1;
-				r.qhat = T.lf_b0 * v0;
-				r.v1 = v0;
-				r.rate += T.ss_rate_adj * r.qhat;
-				r.del = r.rate + r.qhat;
+		// the next input sample's window entries are fetched now, a whole iteration before they can be needed (sample k1 belongs to
+		// the next chunk and may still be in the making: that value is never used)
+		const float n_lo = base[2 * (k + 1)], n_hi = base[2 * (k + 1 - 16)];
+		if (r.b < D_SS_NPFB) {
+			float wl = w_lo, wh = w_hi;
+			if (k - (D_SS_TAPS - 1) < r.valid_from && row < 2) {          // matched-filter window entries from before the last reset are empty
+				if (k - t < r.valid_from) wl = 0.f;
+				if (k - t - 16 < r.valid_from) wh = 0.f;
 			}
-			r.decim++;
-			r.tau += r.del;
-			r.bf = r.tau * (float)D_SS_NPFB;
-			r.b = (int)roundf(r.bf);
-			produced++;
-			if (r.b < D_SS_NPFB) h = sh.sstab[(r.b < 0 ? 0 : r.b) * 64 + lane];      // another output from this input sample
+			int produced = 0;
+			do {
+				// four 18-tap dot products at once: row 0/1 = matched filter re/im, row 2/3 = derivative filter re/im
+				const float p = row_scan_sum(h.x * wl + h.y * wh);
+				const float mx = lane_value(p, 15), my = lane_value(p, 31);
+				if (lane == 0 && r.j < sh.outq_cap) { cf o; o.x = div3(mx); o.y = div3(my); sh.outq[r.j] = o; }
+				r.j++;
+				if (r.decim == 2) {
+					r.decim = 0;
+					const float dx = lane_value(p, 47), dy = lane_value(p, 63);
+					float q = mx * dx + my * dy;
+					q = q > 1.0f ? 1.0f : (q < -1.0f ? -1.0f : q);
+					r.q = q;
+					const float v0 = q - T.lf_a1 * r.v1;
+					r.qhat = T.lf_b0 * v0;
+					r.v1 = v0;
+					r.rate += T.ss_rate_adj * r.qhat;
+					r.del = r.rate + r.qhat;
+				}
+				r.decim++;
+				r.tau += r.del;
+				r.bf = r.tau * (float)D_SS_NPFB;
+				r.b = (int)roundf(r.bf);
+				produced++;
+				if (r.b < D_SS_NPFB) h = sh.sstab[(r.b < 0 ? 0 : r.b) * 64 + lane];      // another output from this input sample
+			} while (r.b < D_SS_NPFB && produced < 4);
 		}
 		r.tau -= 1.0f;
 		r.bf -= (float)D_SS_NPFB;
@@ -228,6 +224,7 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 		bi = r.b < 0 ? 0 : (r.b >= D_SS_NPFB ? D_SS_NPFB - 1 : r.b);
 		h = sh.sstab[bi * 64 + lane];                   // branch of the next input sample: fetched while the stores drain
 		if (lane == 0) sh.cum[k] = (uint16_t)(r.j < 65535 ? r.j : 65535);
+		w_lo = n_lo; w_hi = n_hi;
 	}
 }
 
@@ -422,12 +419,14 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 		if (lane == 0) { S.agc_g = agc_g; S.agc_y2 = agc_y2; }
 	} else if (wave == 1) {
 		SymsyncRegs ss;
-		symsync_load(ss, S, a, lane);
+		symsync_load(ss, S, a, io, lane);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
 		PipeProgress pp;
 		for (int step = 0; pp.s3_done < n_out; step++) {
 			int *mb = sh.mbox + 4 * (step & 1);
 			const unsigned long long tb = __builtin_amdgcn_s_memtime();
-			if (pp.restart) symsync_restart(ss, a, io, sh, pp.ss_ready, lane);
+			if (pp.restart) symsync_restart(ss, sh, pp.ss_ready);
 			int to = pp.ss_ready + DM_CHUNK < pp.mf_ready ? pp.ss_ready + DM_CHUNK : pp.mf_ready;
 			if (to > pp.ss_ready) symsync_chunk(ss, T, io, sh, pp.ss_ready, to, lane); else to = pp.ss_ready;
 			if (lane == 0) mb[1] = to;
@@ -435,9 +434,8 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 			__syncthreads();
 			pp.read(mb);
 		}
-		if (pp.restart) symsync_restart(ss, a, io, sh, n_out, lane);      // a reset during the block's last sample
-		__builtin_amdgcn_wave_barrier();
-		symsync_store(ss, S, a, lane);
+		if (pp.restart) symsync_restart(ss, sh, n_out);      // a reset during the block's last sample
+		symsync_store(ss, S, a, io, n_out, lane);
 	} else {
 		CarrierRegs cr;
 		ChanScalars s3 = S;               // wave 2's working copy: it owns every field but the resampler / AGC / timing-loop ones

@@ -69,7 +69,7 @@ struct DemodLds {
 		mbox = take(sizeof(int) * 8);
 		rs = take(sizeof(cf) * (size_t)cap);
 		agc = take(sizeof(cf) * (size_t)cap);          // agc and mfo are adjacent: together they stage the block's input
-		mfo = take(sizeof(cf) * (size_t)cap);
+		mfo = take(sizeof(cf) * ((size_t)cap + SS_HIST)) + sizeof(cf) * SS_HIST;     // SS_HIST history entries sit right before mf[0]
 		lvl = take(sizeof(float) * (size_t)cap);
 		outq = take(sizeof(cf) * 2 * (size_t)cap);
 		cum = take(sizeof(uint16_t) * (size_t)cap);

@@ -42,7 +42,7 @@ struct ChanScalars {
 	uint32_t rs_phase;
 	float agc_g, agc_y2;
 	float ss_rate, ss_del, ss_tau, ss_bf, ss_q, ss_qhat, ss_v1;
-	int32_t ss_b, ss_head;
+	int32_t ss_b, ss_head;         // ss_head on the device: first input sample (relative to the next block, <= 0) whose matched-filter window entries count
 	uint32_t ss_decim;
 	float phi, dphi, err;
 	float eq_x2sum;
