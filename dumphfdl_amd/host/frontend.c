@@ -255,7 +255,7 @@ static void *frontend_thread(void *ctx)
 	const size_t elem = hfdl_ring_elem_size(ring->buf);
 	const int gfmt = gpu_format_of(hfdl_ring_format(ring->buf));
 	uint64_t k = 0, npdus = 0;
-	double t_first = 0, t_last = 0;
+	double t_first = 0, t_last = 0, t_published = 0;
 	for (;;) {
 		pthread_mutex_lock(ring->mutex);
 		/* shutdown is honoured only when there is not a whole block left, so buffered samples are flushed (src/fft.c:39-48) */
@@ -298,7 +298,10 @@ static void *frontend_thread(void *ctx)
 			pthread_mutex_unlock(ring->mutex);
 			pthread_cond_signal(ring->cond);
 		}
-		publish_counters(fe, stats, (int32_t)nch);
+		/* the StatsD counters / gauges are read from the device every 50 ms of wall time at most: one strided device read per
+		 * block would cost more than a block of a small geometry takes (a block is decoded in ~0.3 ms) */
+		const double now = now_s();
+		if (now - t_published >= 0.05) { publish_counters(fe, stats, (int32_t)nch); t_published = now; }
 	}
 shutdown:
 	if (fe) {

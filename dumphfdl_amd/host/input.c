@@ -128,7 +128,7 @@ static size_t read_fully(int fd, void *buf, size_t want)        /* what fread() 
 /* ---- parallel positional reads: a regular file is copied out of the page cache by several threads at once ----
  * One thread moves ~5-8 GB/s from the page cache; the front end takes cf32 at > 20 GB/s (2.7 Gsamples/s). */
 #define FILE_READERS_MAX 8
-#define FILE_PIECE (4u << 20)
+#define FILE_PIECE (1u << 20)
 struct read_pool {
 	pthread_t th[FILE_READERS_MAX];
 	int nthreads;
