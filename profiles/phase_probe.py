@@ -27,7 +27,7 @@ for b in range(4, 7):
     fe.push_block(ptr(b)); fe.sync()
     t = np.array([fe.read_tap(F.TAP_PHASE_CYCLES, c) for c in chans])
     n5400 = len(fe.read_tap(F.TAP_AGC_LEVEL, 0))
-    print(name, "alone       block", b, "cycles R/P/W1/W2 (mean over %d ch):" % len(chans), t.mean(axis=0).astype(int),
+    print(name, "alone       block", b, "cycles R/P/W1/W2 (mean over %d ch):" % len(chans), t.mean(axis=0).astype(int), "max", t.max(axis=0).astype(int),
           "samples/block", n5400, "per sample: P %.0f W1 %.0f W2 %.0f" % tuple(t.mean(axis=0)[1:] / max(n5400, 1)))
 for rep in range(3):
     for b in range(7, 12):
