@@ -67,4 +67,45 @@ __device__ __forceinline__ float2 unit_twiddle(unsigned e, int logn)
 	return make_float2(cs, sn);
 }
 
+// ---- decimating_shift_addition_cc's phasor recurrence (src/libcsdr_gpl.c:48-66), shared by every kernel that runs it ----
+// fp32, products rounded separately: HIP's __fmul_rn / __fadd_rn are plain operators inside the headers and hipcc contracts
+// a * b + c into an FMA by default, so they do NOT keep the products apart.  The pragma on plain operators written HERE does, as the
+// reference's x86-64 build rounds them (found by feeding tests/golden/nco_ref.npz straight to the device).
+__device__ __forceinline__ void nco_phasor_step(float &cphi, float &sphi, float cd, float sd)
+{
+#pragma clang fp contract(off)
+	const float c0 = cphi, s0 = sphi;
+	cphi = c0 * cd - s0 * sd;
+	sphi = s0 * cd + c0 * sd;
+}
+
+// the reference seeds the recurrence with `float cosphi = cos(s.starting_phase)`: double-precision cos / sin, rounded to float
+__device__ __forceinline__ float2 nco_phasor_seed(float starting_phase)
+{
+	return make_float2((float)cos((double)starting_phase), (float)sin((double)starting_phase));
+}
+
+__device__ __forceinline__ int nco_output_count(const NcoState &st, int input_size, int q)
+{
+	return st.decimation_remain < input_size ? (input_size - st.decimation_remain + q - 1) / q : 0;
+}
+
+// segment `job.seg` of the phasor table, lanes over channels: thread = channel
+__device__ __forceinline__ void nco_table_segment(const NcoJob &job, int c)
+{
+	if (c >= job.nch) return;
+	const ChanConst k = job.cc[c];
+	const NcoState st = job.nco[c];
+	const int cnt = nco_output_count(st, job.post_input_size, job.post);
+	const int per = (job.outs + job.nseg - 1) / job.nseg;
+	const int i0 = job.seg * per, i1 = (job.seg + 1) * per < cnt ? (job.seg + 1) * per : cnt;
+	float2 p = job.seg == 0 ? nco_phasor_seed(st.starting_phase) : job.cont[c];
+	float2 *dst = job.ph + (size_t)i0 * job.nch + c;
+	for (int i = i0; i < i1; i++, dst += job.nch) {
+		*dst = p;
+		nco_phasor_step(p.x, p.y, k.nco_cosdelta, k.nco_sindelta);
+	}
+	job.cont[c] = p;
+}
+
 }  // namespace hfdl

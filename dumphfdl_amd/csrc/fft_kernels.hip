@@ -34,11 +34,14 @@ __device__ __forceinline__ float2 load_sample(const void *__restrict__ raw, int 
 // never the one being read) as they pass through, so no separate copy runs.
 template <int FMT>
 __global__ __launch_bounds__(FFT_THREADS) void fft_pass1(const float2 *__restrict__ hist, const void *__restrict__ fresh,
-		int split, float2 *__restrict__ hist_next, float2 *__restrict__ out, FftPlan p)
+		int split, float2 *__restrict__ hist_next, float2 *__restrict__ out, FftPlan p, NcoJob job, int riders)
 {
+	// rider workgroups come FIRST in the grid: dispatched at once, they run beside the whole pass (at the end of the grid they would start when the pass is nearly over)
+	if ((int)blockIdx.x < riders) { nco_table_segment(job, (int)blockIdx.x * FFT_THREADS + (int)threadIdx.x); return; }
+	const int bid = (int)blockIdx.x - riders;
 	extern __shared__ float2 sm[];
 	const int cs = p.n >> p.l1;            // R2*R3 columns
-	const int c0 = blockIdx.x * FFT_TILE;
+	const int c0 = bid * FFT_TILE;
 	const int total = p.r1 * FFT_TILE;
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
 		const int r = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
@@ -66,11 +69,14 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass1(const float2 *__restric
 }
 
 // pass 2: for each (k1, n3): R2-point FFT over n2 (stride R3), twiddle W_{R2 R3}^{k2 n3}.  In place.
-__global__ __launch_bounds__(FFT_THREADS) void fft_pass2(float2 *__restrict__ buf, FftPlan p)
+__global__ __launch_bounds__(FFT_THREADS) void fft_pass2(float2 *__restrict__ buf, FftPlan p, NcoJob job, int riders)
 {
+	// rider workgroups come FIRST in the grid: dispatched at once, they run beside the whole pass (at the end of the grid they would start when the pass is nearly over)
+	if ((int)blockIdx.x < riders) { nco_table_segment(job, (int)blockIdx.x * FFT_THREADS + (int)threadIdx.x); return; }
+	const int bid = (int)blockIdx.x - riders;
 	extern __shared__ float2 sm[];
 	const int r23 = p.n >> p.l1, ncol = p.r1 * p.r3;
-	const int cc0 = blockIdx.x * FFT_TILE;
+	const int cc0 = bid * FFT_TILE;
 	const int total = p.r2 * FFT_TILE;
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
 		const int r = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
@@ -100,11 +106,14 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass2(float2 *__restrict__ bu
 // pass 3: for each (k1,k2): contiguous R3-point FFT; X[k1 + R1 k2 + R1 R2 k3] stored at (k + n/2) mod n
 // when `shifted` (fft_swap_sides as an index remap).  A tile is 16 adjacent k1 so stores stay 128-byte runs.
 __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restrict__ in, float2 *__restrict__ out, FftPlan p, int shifted,
-		FftOutLayout lay)
+		FftOutLayout lay, NcoJob job, int riders)
 {
+	// rider workgroups come FIRST in the grid: dispatched at once, they run beside the whole pass (at the end of the grid they would start when the pass is nearly over)
+	if ((int)blockIdx.x < riders) { nco_table_segment(job, (int)blockIdx.x * FFT_THREADS + (int)threadIdx.x); return; }
+	const int bid = (int)blockIdx.x - riders;
 	extern __shared__ float2 sm[];
 	const int r23 = p.n >> p.l1, ncol = p.r1 * p.r2;
-	const int cc0 = blockIdx.x * FFT_TILE;
+	const int cc0 = bid * FFT_TILE;
 	const int total = p.r3 * FFT_TILE;
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
 		const int col = e >> p.l3, n3 = e & (p.r3 - 1);     // fast index walks a contiguous row
@@ -134,19 +143,24 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restric
 }
 
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
-		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay, hipEvent_t done)
+		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay, hipEvent_t done, NcoJob nco)
 {
 	const int c1 = (p.n >> p.l1), c2 = p.r1 * p.r3, c3 = p.r1 * p.r2;
-	const dim3 g1((c1 + FFT_TILE - 1) / FFT_TILE), blk(FFT_THREADS);
+	const int g1 = (c1 + FFT_TILE - 1) / FFT_TILE, g2 = (c2 + FFT_TILE - 1) / FFT_TILE, g3 = (c3 + FFT_TILE - 1) / FFT_TILE;
+	const int riders = nco.cc ? (nco.nch + FFT_THREADS - 1) / FFT_THREADS : 0;       // workgroups that run a third of the NCO phasor table each pass
+	const dim3 blk(FFT_THREADS);
 	// tile + the radix's twiddle table
 	const size_t l1 = (size_t)p.r1 * (FFT_TILE + 1) * sizeof(float2), l2 = (size_t)p.r2 * (FFT_TILE + 1) * sizeof(float2);
-	if (fmt == SFMT_CS16) hipLaunchKernelGGL(fft_pass1<SFMT_CS16>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
-	else if (fmt == SFMT_CU8) hipLaunchKernelGGL(fft_pass1<SFMT_CU8>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
-	else hipLaunchKernelGGL(fft_pass1<SFMT_CF32>, g1, blk, l1, st, hist, fresh, split, hist_next, work, p);
-	hipLaunchKernelGGL(fft_pass2, dim3((c2 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), l2, st,
-			work, p);
-	hipExtLaunchKernelGGL(fft_pass3, dim3((c3 + FFT_TILE - 1) / FFT_TILE), dim3(FFT_THREADS), (size_t)p.r3 * (FFT_TILE + 1) * sizeof(float2), st, nullptr, done, 0,
-			(const float2 *)work, out, p, shifted ? 1 : 0, lay);
+	nco.nseg = 3;
+	nco.seg = 0;
+	if (fmt == SFMT_CS16) hipLaunchKernelGGL(fft_pass1<SFMT_CS16>, dim3(g1 + riders), blk, l1, st, hist, fresh, split, hist_next, work, p, nco, riders);
+	else if (fmt == SFMT_CU8) hipLaunchKernelGGL(fft_pass1<SFMT_CU8>, dim3(g1 + riders), blk, l1, st, hist, fresh, split, hist_next, work, p, nco, riders);
+	else hipLaunchKernelGGL(fft_pass1<SFMT_CF32>, dim3(g1 + riders), blk, l1, st, hist, fresh, split, hist_next, work, p, nco, riders);
+	nco.seg = 1;
+	hipLaunchKernelGGL(fft_pass2, dim3(g2 + riders), blk, l2, st, work, p, nco, riders);
+	nco.seg = 2;
+	hipExtLaunchKernelGGL(fft_pass3, dim3(g3 + riders), blk, (size_t)p.r3 * (FFT_TILE + 1) * sizeof(float2), st, nullptr, done, 0,
+			(const float2 *)work, out, p, shifted ? 1 : 0, lay, nco, riders);
 }
 
 }  // namespace hfdl

@@ -181,21 +181,13 @@ void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, 
 // wave 0 runs it while the other 15 waves sum the fold slices out of HBM; all 16 then share the inverse FFT.
 constexpr int IFFT_THREADS = 1024;
 
-// decimating_shift_addition_cc's phasor recurrence (src/libcsdr_gpl.c:48-66): fp32, no contraction, seeded from the carried
-// starting phase with double-precision cos / sin rounded to float exactly as the reference's `float cosphi = cos(...)`.
-// One thread runs it (it is a serial chain); ph[i] is the phasor that multiplies output i.
+// ph[i] = the phasor that multiplies output i (recurrence: fft_core.h); one thread runs it -- it is a serial chain
 __device__ __forceinline__ void nco_phasor_run(float2 *ph, int cnt, float starting_phase, float cd, float sd)
 {
-	// HIP's __fmul_rn / __fadd_rn are plain operators inside the headers and hipcc contracts a * b + c into an FMA by default,
-	// so they do NOT keep the products rounded separately.  The pragma on plain operators written HERE does, as the
-	// reference's x86-64 build rounds them (found by feeding tests/golden/nco_ref.npz straight to the device).
-#pragma clang fp contract(off)
-	float cphi = (float)cos((double)starting_phase), sphi = (float)sin((double)starting_phase);
+	float2 p = nco_phasor_seed(starting_phase);
 	for (int i = 0; i < cnt; i++) {
-		ph[i] = make_float2(cphi, sphi);
-		const float c0 = cphi, s0 = sphi;
-		cphi = c0 * cd - s0 * sd;
-		sphi = s0 * cd + c0 * sd;
+		ph[i] = p;
+		nco_phasor_step(p.x, p.y, cd, sd);
 	}
 }
 
@@ -221,29 +213,22 @@ __device__ __forceinline__ void nco_advance(NcoState &st, int cnt, int q, int in
 	st.output_size = cnt;
 }
 
-__device__ __forceinline__ int nco_output_count(const NcoState &st, int input_size, int q)
-{
-	return st.decimation_remain < input_size ? (input_size - st.decimation_remain + q - 1) / q : 0;
-}
 
 __global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__restrict__ partial, const ChanConst *__restrict__ cc,
-		NcoState *__restrict__ nco, const float2 *__restrict__ tw, float2 *__restrict__ chan_out, int *__restrict__ out_count,
+		NcoState *__restrict__ nco, const float2 *__restrict__ ph, const float2 *__restrict__ tw, float2 *__restrict__ chan_out, int *__restrict__ out_count,
 		Geometry g, int logm)
 {
-	extern __shared__ float2 sm[];          // m bins, then `outs` phasors
-	float2 *ph = sm + g.m;
+	extern __shared__ float2 sm[];          // m bins
 	const int c = blockIdx.x;
 	const ChanConst k = cc[c];
 	const int m = g.m, mask = m - 1;
 	NcoState st = nco[c];
 	const int q = g.post;
 	const int cnt = nco_output_count(st, g.post_input_size, q);
-	if (threadIdx.x < 64) {
-		if (threadIdx.x == 0) nco_phasor_run(ph, cnt, st.starting_phase, k.nco_cosdelta, k.nco_sindelta);
-	} else {
+	{
 		const int h0 = (int)(((long long)g.n - k.offsetbin + m / 2) % m);
 		const float2 *pc = partial + (size_t)c * g.slices * (size_t)m;
-		for (int u = threadIdx.x - 64; u < m; u += IFFT_THREADS - 64) {
+		for (int u = threadIdx.x; u < m; u += IFFT_THREADS) {
 			const int j = (u - h0 - m / 2) & mask;
 			float2 acc = make_float2(0.f, 0.f);
 			for (int s = 0; s < g.slices; s++) {
@@ -262,7 +247,7 @@ __global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__
 		const int idx = g.scrap + st.decimation_remain + q * i;
 		float2 v = sm[(int)(__brev((unsigned)idx) >> (32 - logm))];
 		v.x = __fdiv_rn(v.x, norm); v.y = __fdiv_rn(v.y, norm);
-		o[i] = nco_rotate(ph[i], v);
+		o[i] = nco_rotate(ph[(size_t)i * g.nch + c], v);       // the block's phasor table, made beside its forward FFT (kernels.h NcoJob)
 	}
 	if (threadIdx.x == 0) {
 		nco_advance(st, cnt, q, g.post_input_size, k.nco_rate);
@@ -293,14 +278,14 @@ void launch_nco_decimate(const float2 *in, int input_size, float cd, float sd, f
 	hipLaunchKernelGGL(nco_decimate_kernel, dim3(1), dim3(IFFT_THREADS), 0, st, in, input_size, cd, sd, rate, q, state, ph, out);
 }
 
-void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
+void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco, const float2 *ph,
 		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st, hipEvent_t done)
 {
 	int logm = 0;
 	while ((1 << logm) < g.m) logm++;
-	size_t lds = sizeof(float2) * ((size_t)g.m + (size_t)g.outs + 1);
+	size_t lds = sizeof(float2) * ((size_t)g.m + 1);
 	if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)ifft_nco_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipExtLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(IFFT_THREADS), (unsigned)lds, st, nullptr, done, 0, partial, cc, nco, tw_m, chan_out, out_count, g, logm);
+	hipExtLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(IFFT_THREADS), (unsigned)lds, st, nullptr, done, 0, partial, cc, nco, ph, tw_m, chan_out, out_count, g, logm);
 }
 
 }  // namespace hfdl

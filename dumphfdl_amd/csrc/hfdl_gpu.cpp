@@ -133,6 +133,7 @@ struct hfdl_gpu_frontend {
 	int *d_out_count[2] = { nullptr, nullptr };
 	ChanConst *d_cc = nullptr;
 	NcoState *d_nco = nullptr;
+	float2 *d_ph = nullptr, *d_ph_cont = nullptr;      // the block's NCO phasor table [outs][nch] and the riders' segment hand-over [nch]
 	size_t stage_cap[2] = { 0, 0 };
 	Demod demod;
 	// fold timing
@@ -167,7 +168,7 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	fe->demod.release();
 	fe->fft.release();
 	void *ptrs[] = { fe->d_hist[0], fe->d_hist[1], fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_out[0], fe->d_chan_out[1], fe->d_tw_m,
-		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_out_count[0], fe->d_out_count[1] };
+		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_ph, fe->d_ph_cont, fe->d_out_count[0], fe->d_out_count[1] };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (fe->stream) (void)hipStreamDestroy(fe->stream);
 	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamDestroy(fe->stream_d);
@@ -321,6 +322,8 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	}
 	FE_TRY(hipMalloc(&fe->d_nco, sizeof(NcoState) * (size_t)nch));
 	FE_TRY(hipMemsetAsync(fe->d_nco, 0, sizeof(NcoState) * (size_t)nch, fe->stream));
+	FE_TRY(hipMalloc(&fe->d_ph, sizeof(float2) * (size_t)nch * g.outs));
+	FE_TRY(hipMalloc(&fe->d_ph_cont, sizeof(float2) * (size_t)nch));
 	FE_TRY(hipMalloc(&fe->d_cc, sizeof(ChanConst) * (size_t)nch));
 	{
 		float2 *tw = nullptr;
@@ -478,8 +481,13 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 	// of idle machine each (profiles/r01_experiments.md).
 	const bool pend = fe->pending_demod_buf >= 0;
 	if (pend && !fe->ev_fft) HIP_TRY(hipEventCreateWithFlags(&fe->ev_fft, hipEventDisableTiming));
+	// the block's NCO phasor table rides on the three FFT pass launches (the carried NcoState is final: the previous block's
+	// inverse-FFT kernel precedes them on this stream)
+	NcoJob job;
+	job.cc = fe->d_cc; job.nco = fe->d_nco; job.ph = fe->d_ph; job.cont = fe->d_ph_cont;
+	job.nch = g.nch; job.outs = g.outs; job.post_input_size = g.post_input_size; job.post = g.post;
 	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->d_spec, true, fe->stream,
-			FftOutLayout(), pend ? fe->ev_fft : nullptr);
+			FftOutLayout(), pend ? fe->ev_fft : nullptr, job);
 	if (pend) {
 		int rc = flush_pending_demod(fe, true);
 		if (rc) return rc;
@@ -495,7 +503,7 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
 	}
 	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm[buf], 0));          // chan_out[buf] is free once demod(k-2) has read it
-	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_tw_m, fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream, fe->ev_chan[buf]);
+	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_ph, fe->d_tw_m, fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream, fe->ev_chan[buf]);
 	HIP_TRY(hipGetLastError());
 	fe->blocks++;
 	fe->last_buf = buf;
@@ -734,6 +742,14 @@ extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32
 		int cnt = 0;
 		HIP_TRY(hipMemcpy(&cnt, fe->d_out_count[fe->last_buf] + channel, sizeof(cnt), hipMemcpyDeviceToHost));
 		src = fe->d_chan_out[fe->last_buf] + (size_t)channel * g.outs; nf = 2 * (size_t)cnt; break; }
+	case HFDL_GPU_TAP_NCO_PHASORS: {
+		int cnt = 0;
+		HIP_TRY(hipMemcpy(&cnt, fe->d_out_count[fe->last_buf] + channel, sizeof(cnt), hipMemcpyDeviceToHost));
+		if (2 * (size_t)cnt > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", 2 * (size_t)cnt, cap);
+		// column `channel` of the [outs][nch] table
+		if (cnt) HIP_TRY(hipMemcpy2D(dst, sizeof(float2), fe->d_ph + channel, sizeof(float2) * (size_t)g.nch, sizeof(float2), (size_t)cnt, hipMemcpyDeviceToHost));
+		*n_floats = 2 * (size_t)cnt;
+		return 0; }
 	case HFDL_GPU_TAP_PHASE_CYCLES: src = fe->demod.d_tap_lvl + (size_t)channel * fe->demod.cap + fe->demod.cap - 4; nf = 4; break;
 	default:
 		rc = fe->demod.tap(what, channel, &src, &nf);

@@ -39,6 +39,20 @@ struct Geometry {
 	int64_t tap_chan_stride, tap_row_stride;
 };
 
+// The NCO phasor table of a block, made while that block's forward FFT runs.  decimating_shift_addition_cc's phasor recurrence
+// (src/libcsdr_gpl.c:48-66) is 1792 strictly serial fp32 steps per channel at cfg3 -- 47 us for a lone lane, which used to be the
+// whole duration of the inverse-FFT kernel.  It depends on the carried NcoState only, which is final when the previous block's
+// kernel has run: one extra workgroup per FFT pass launch runs a third of it, LANES OVER CHANNELS (256 channels = 4 wavefronts),
+// hidden inside the pass.  Table layout [output index][channel] so the lanes' stores coalesce.
+struct NcoJob {
+	const ChanConst *cc = nullptr;     // null: no rider workgroup on this launch
+	const NcoState *nco = nullptr;     // state before the block (decimating_shift_addition_status_t)
+	float2 *ph = nullptr;              // [outs][nch] phasor table of the block
+	float2 *cont = nullptr;            // [nch] phasor at the start of the next segment
+	int32_t nch = 0, outs = 0, post_input_size = 0, post = 0;
+	int32_t seg = 0, nseg = 3;
+};
+
 // owning device allocation for the one-shot stage entry points (freed on every exit path)
 struct DevBuf {
 	void *p = nullptr;
@@ -56,11 +70,13 @@ enum { SFMT_CF32 = 0, SFMT_CS16 = 1, SFMT_CU8 = 2 };
 // output index i of the transform is stored at (i >> row_log) * row_stride + (i & (2^row_log - 1)); row_log = 0: contiguous
 struct FftOutLayout { int row_log = 0; int64_t row_stride = 0; };
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
-		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay = FftOutLayout(), hipEvent_t done = nullptr);
+		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay = FftOutLayout(), hipEvent_t done = nullptr,
+		NcoJob nco = NcoJob());
 // optional events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL): no separate barrier packets in the queue
 void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st,
 		hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
-void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco,
+// `ph`: the block's phasor table [outs][nch] (NcoJob riders of the forward FFT)
+void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco, const float2 *ph,
 		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st, hipEvent_t done = nullptr);
 void launch_nco_decimate(const float2 *in, int input_size, float cosdelta, float sindelta, float rate, int decimation,
 		NcoState *state, float2 *phasor_scratch, float2 *out, hipStream_t st);

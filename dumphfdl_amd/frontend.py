@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PDU_MAX_OCTETS = 960
 
-TAP_SPECTRUM, TAP_FILTER, TAP_CHAN_OUT, TAP_RESAMPLED, TAP_MF_OUT, TAP_SYMBOLS, TAP_AGC_LEVEL, TAP_PHASE_CYCLES = range(1, 9)
+TAP_SPECTRUM, TAP_FILTER, TAP_CHAN_OUT, TAP_RESAMPLED, TAP_MF_OUT, TAP_SYMBOLS, TAP_AGC_LEVEL, TAP_PHASE_CYCLES, TAP_NCO_PHASORS = range(1, 10)
 
 
 SFMT_CF32, SFMT_CS16, SFMT_CU8 = 0, 1, 2

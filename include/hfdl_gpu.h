@@ -174,6 +174,8 @@ enum {
 	HFDL_GPU_TAP_MF_OUT = 5,         /* cf32[n], AGC + matched filter output of the last block */
 	HFDL_GPU_TAP_SYMBOLS = 6,        /* cf32[n], equalised on-time symbols of the last block */
 	HFDL_GPU_TAP_AGC_LEVEL = 7,      /* f32[n], agc signal level per 5400-sps sample */
+	HFDL_GPU_TAP_NCO_PHASORS = 9,    /* cf32[n]: the NCO phasors (cos phi_k, sin phi_k) that multiplied the last block's outputs of `channel`
+	                                    (decimating_shift_addition_cc's recurrence, src/libcsdr_gpl.c:48-66; bit-exact vs the reference) */
 	HFDL_GPU_TAP_PHASE_CYCLES = 8    /* f32[4]: shader cycles of the last demod launch: resampler phase, the whole three-wave pipelined phase (wall),
 	                                    busy cycles of the timing-recovery wave, busy cycles of the carrier / equaliser / framer wave */
 };
