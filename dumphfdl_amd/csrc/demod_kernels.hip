@@ -1,6 +1,7 @@
 // demod_kernels.hip -- K4 (per-channel streaming demodulator) and K5 (batched burst decoder) for gfx950.
 //
-// K4  demod_kernel        one wavefront per channel; body in demod_core.h (reference src/hfdl.c:676-892)
+// K4  demod_kernel        one workgroup of three wavefronts per channel, a software pipeline over chunks of samples;
+//                         body in demod_core.h / demod_logic.h (reference src/hfdl.c:676-892)
 // K5  burst_decode_kernel one wavefront per finished frame: descramble + soft de-map + 40-row de-interleave
 //                         + rate-1/4 combine + K=7 Viterbi + octet bit reversal + PDU metadata
 //                         (reference decode_user_data / dispatch_pdu, src/hfdl.c:993-1080;
@@ -29,7 +30,7 @@ struct DemodBuffers {
 	cf *data;
 	FrameRec *frames;
 	int *counts;
-	int *frame_count;           // this block's frames-queued counter (two, used alternately: see Demod::enqueue_block)
+	int *frame_count;           // this launch's frames-queued counter (four, rotating: see Demod::enqueue_demod)
 	int frame_cap;
 	cf *tap_rs, *tap_mf, *tap_sym;
 	float *tap_lvl;
