@@ -265,12 +265,22 @@ def host_path_leg(w, x, freqs, fmt="CF32", dev_index=0, seconds_cap=120):
     exe = os.path.join(ROOT, "dumphfdl_amd", "hfdl_replay")
     if not os.path.exists(exe):
         return dict(error="dumphfdl_amd/hfdl_replay not built")
-    path = "/dev/shm/hfdl_bench_%d.%s" % (os.getpid(), fmt.lower())
+    path = None
     try:
-        if fmt == "CS16":
-            np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16).tofile(path)
-        else:
-            x.view(np.float32).tofile(path)
+        raw = np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16) if fmt == "CS16" else x.view(np.float32)
+        for d in ("/dev/shm", "/tmp"):              # page cache either way; /dev/shm can be tiny inside containers
+            try:
+                path = "%s/hfdl_bench_%d.%s" % (d, os.getpid(), fmt.lower())
+                raw.tofile(path)
+                break
+            except OSError:
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+                path = None
+        if path is None:
+            return dict(error="no room for the I/Q file in /dev/shm or /tmp")
         loops = max(1, int(np.ceil(1.5 * 2.5e9 / len(x))))        # >= ~1.5 s of work at 2.5 Gsamples/s
         cmd = [exe, "--bench", "--loop", str(loops), "--iq-file", path, "--sample-rate", str(w["fs"]), "--sample-format", fmt, "--device", str(dev_index),
                "--centerfreq", "%.3f" % (w["centerfreq"] / 1e3)] + ["%.3f" % (f / 1e3) for f in freqs]
@@ -286,7 +296,8 @@ def host_path_leg(w, x, freqs, fmt="CF32", dev_index=0, seconds_cap=120):
         return dict(error=str(e))
     finally:
         try:
-            os.remove(path)
+            if path:
+                os.remove(path)
         except OSError:
             pass
 

@@ -2,8 +2,8 @@
  * hfdl_oracle.h -- CPU restatement of dumphfdl's channelizer + HFDL demod/FEC hot path.
  *
  * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.
- * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load or call
- * anything under oracle/.  The shipped path (dumphfdl_amd/) never links or dlopens it.
+ * Only tests/, __graft_entry__.smoke() and bench.py's parity / cpu_baseline legs (the checker and the
+ * reported CPU baseline, never the thing measured) may load or call anything under oracle/.  The shipped path (dumphfdl_amd/) never links or dlopens it.
  *
  * Parity status (see DESIGN.md "Oracle"):
  *   - Viterbi K=7 r=1/2, CRC-16, NCO/decimator: PINNED against the reference's own C files
