@@ -259,6 +259,7 @@ __device__ __forceinline__ void carrier_store(const CarrierRegs &c, ChanArrays &
 
 // processes samples [k0, k1); returns the index of the sample during which the framer reset the timing loop (the wave stops
 // after that sample), or -1
+template <bool TAPS>
 __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, const DemodShared &sh,
 		int k0, int k1, int &nsym, int lane)
 {
@@ -330,7 +331,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 					}
 					s.T_idx++;
 				}
-				if (io.tap_symbols && lane == 0) io.tap_symbols[nsym] = y;
+				if (TAPS && lane == 0) io.tap_symbols[nsym] = y;
 				nsym++;
 				on_symbol(s, a, T, io, y, level);
 				runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
@@ -354,6 +355,9 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 
 // All DM_THREADS threads of the channel's workgroup call this.  On return the channel's arrays (LDS, `a`) and scalars (*sh.S)
 // hold the state after the block.  Returns the number of 5400-sps samples produced.
+// TAPS: the per-stage debug taps (DATADUMPS analogue) and the phase cycle counters are compiled in; the production launch uses the
+// variant without them (fewer live pointers in the carrier wave, which is short of SGPRs as it is).
+template <bool TAPS>
 __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const BlockIo &io, const DemodShared &sh, const cf *in, int n_in)
 {
 	const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -387,7 +391,7 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 		if (tid < D_RS_TAPS - 1) a.rs_hist[tid] = nh;
 		if (tid == 0) {
 			S.rs_phase = (uint32_t)((uint64_t)rs_phase + (uint64_t)n_out * T.rs_step - total);
-			if (io.tap_counts) { io.tap_counts[0] = n_out; io.tap_counts[1] = 0; }
+			if (TAPS) { io.tap_counts[0] = n_out; io.tap_counts[1] = 0; }
 		}
 	}
 	__syncthreads();             // `in` (staged in the space of agc + mf) is dead from here on
@@ -425,12 +429,12 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 		PipeProgress pp;
 		for (int step = 0; pp.s3_done < n_out; step++) {
 			int *mb = sh.mbox + 4 * (step & 1);
-			const unsigned long long tb = __builtin_amdgcn_s_memtime();
+			const unsigned long long tb = TAPS ? __builtin_amdgcn_s_memtime() : 0ull;
 			if (pp.restart) symsync_restart(ss, sh, pp.ss_ready);
 			int to = pp.ss_ready + DM_CHUNK < pp.mf_ready ? pp.ss_ready + DM_CHUNK : pp.mf_ready;
 			if (to > pp.ss_ready) symsync_chunk(ss, T, io, sh, pp.ss_ready, to, lane); else to = pp.ss_ready;
 			if (lane == 0) mb[1] = to;
-			busy += __builtin_amdgcn_s_memtime() - tb;
+			if (TAPS) busy += __builtin_amdgcn_s_memtime() - tb;
 			__syncthreads();
 			pp.read(mb);
 		}
@@ -444,12 +448,12 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 		PipeProgress pp;
 		for (int step = 0; pp.s3_done < n_out; step++) {
 			int *mb = sh.mbox + 4 * (step & 1);
-			const unsigned long long tb = __builtin_amdgcn_s_memtime();
+			const unsigned long long tb = TAPS ? __builtin_amdgcn_s_memtime() : 0ull;
 			int to = pp.s3_done + DM_CHUNK < pp.ss_ready ? pp.s3_done + DM_CHUNK : pp.ss_ready;
 			int reset_at = -1;
-			if (to > pp.s3_done) reset_at = carrier_chunk(cr, s3, a, T, io, sh, pp.s3_done, to, nsym, lane); else to = pp.s3_done;
+			if (to > pp.s3_done) reset_at = carrier_chunk<TAPS>(cr, s3, a, T, io, sh, pp.s3_done, to, nsym, lane); else to = pp.s3_done;
 			if (lane == 0) { mb[2] = reset_at >= 0 ? reset_at + 1 : to; mb[3] = reset_at >= 0; }
-			busy += __builtin_amdgcn_s_memtime() - tb;
+			if (TAPS) busy += __builtin_amdgcn_s_memtime() - tb;
 			__syncthreads();
 			pp.read(mb);
 		}
@@ -471,11 +475,11 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 			S.cnt_a2_found = s3.cnt_a2_found; S.cnt_m1_found = s3.cnt_m1_found; S.cnt_m1_not_found = s3.cnt_m1_not_found;
 			S.cnt_frames = s3.cnt_frames;
 			S.ev_flags = 0;
-			if (io.tap_counts) io.tap_counts[1] = nsym;
+			if (TAPS) io.tap_counts[1] = nsym;
 		}
 	}
 	unsigned long long tP1 = __builtin_amdgcn_s_memtime();
-	if (io.tap_resampled) {
+	if (TAPS) {
 		__syncthreads();
 		for (int k = tid; k < n_out; k += DM_THREADS) {
 			io.tap_resampled[k] = io.rs[k];

@@ -84,6 +84,7 @@ struct DemodLds {
 // one register more and every CU hosting a channel runs 3 instead of 4 fold workgroups, and the HBM-bound fold loses ~15 % for
 // as long as the demodulator is resident (profiles/r01_experiments.md).  Staying inside the budget also keeps the loops free
 // of scratch spills: scratch is memory, and beside a kernel that saturates HBM every spill reload is a multi-microsecond stall.
+template <bool TAPS>
 __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
 		const int *__restrict__ n_in, int outs_stride)
 {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, Demod
 	io.data = B.data + (size_t)c * 2 * MAX_DATA_SYMBOLS;
 	io.frames = B.frames; io.frame_count = B.frame_count; io.frame_cap = B.frame_cap;
 	io.channel = c;
-	if (B.tap_rs) {
+	if (TAPS) {
 		io.tap_resampled = B.tap_rs + (size_t)c * B.cap; io.tap_mf = B.tap_mf + (size_t)c * B.cap;
 		io.tap_symbols = B.tap_sym + (size_t)c * B.cap; io.tap_level = B.tap_lvl + (size_t)c * B.cap;
 		io.tap_counts = B.tap_counts + 2 * c;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, Demod
 	sh.sstab = l_sstab;
 	sh.S = S;
 	sh.mbox = (int *)(lds + L.mbox);
-	demod_block(*A, K, io, sh, l_in, n_block);
+	demod_block<TAPS>(*A, K, io, sh, l_in, n_block);
 	__syncthreads();
 	{
 		uint32_t *dst = (uint32_t *)&gs->a;
@@ -549,7 +550,8 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	lds_bytes = demod_lds_bytes(cap);
 	if (lds_bytes > 160 * 1024) return HFDL_GPU_ERANGE;
 	int rc;
-	if ((rc = set_big_lds((const void *)demod_kernel, lds_bytes))) return rc;
+	if ((rc = set_big_lds((const void *)demod_kernel<true>, lds_bytes))) return rc;
+	if ((rc = set_big_lds((const void *)demod_kernel<false>, lds_bytes))) return rc;
 	if ((rc = set_big_lds((const void *)burst_decode_kernel, k5_lds_bytes()))) return rc;
 	return 0;
 }
@@ -571,7 +573,8 @@ int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int buf, 
 	const bool tw = taps_on && taps_enabled;
 	B.tap_rs = tw ? (cf *)d_tap_rs : nullptr; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
 	B.cap = cap;
-	hipLaunchKernelGGL(demod_kernel, dim3((unsigned)nch), dim3(DM_THREADS), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
+	if (tw) hipLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)nch), dim3(DM_THREADS), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
+	else hipLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)nch), dim3(DM_THREADS), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
 	D_TRY(hipGetLastError());
 	return 0;
 }
