@@ -55,7 +55,7 @@ _lib = None
 EXPORTS = [
     "hfdl_gpu_plan_geometry", "hfdl_gpu_host_alloc", "hfdl_gpu_host_free",
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
-    "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
+    "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_input_done_upto", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage",
@@ -90,6 +90,7 @@ def load():
     L.hfdl_gpu_frontend_push_block_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     L.hfdl_gpu_frontend_sync.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_input_done.argtypes = [C.c_void_p]
+    L.hfdl_gpu_frontend_input_done_upto.argtypes = [C.c_void_p, C.c_uint64]
     L.hfdl_gpu_frontend_poll_pdus.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.hfdl_gpu_frontend_poll_pdus_ready.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
     L.hfdl_gpu_frontend_counters.argtypes = [C.c_void_p, C.POINTER(FrontendCounters)]

@@ -256,23 +256,27 @@ static void *frontend_thread(void *ctx)
 	const int gfmt = gpu_format_of(hfdl_ring_format(ring->buf));
 	uint64_t k = 0, npdus = 0;
 	double t_first = 0, t_last = 0, t_published = 0;
+	double s_wait = 0, s_push = 0, s_poll = 0, s_release = 0;      /* where this thread's time went (seconds) */
+	size_t leased = 0;                       /* blocks handed to the GPU whose ring slots are not released yet (0..2), oldest first */
 	for (;;) {
+		const double tw0 = now_s();
 		pthread_mutex_lock(ring->mutex);
 		/* shutdown is honoured only when there is not a whole block left, so buffered samples are flushed (src/fft.c:39-48) */
-		while (hfdl_ring_size(ring->buf) < need) {
+		while (hfdl_ring_size(ring->buf) < (leased + 1) * need) {
 			if (block_connection_is_shutdown_signaled(block->consumer.in)) { pthread_mutex_unlock(ring->mutex); goto shutdown; }
 			pthread_cond_wait(ring->cond, ring->mutex);
 		}
-		const void *blk = ok ? hfdl_ring_peek(ring->buf, 0, need) : NULL;
+		const void *blk = ok ? hfdl_ring_peek(ring->buf, leased * need, need) : NULL;
 		if (ok && blk == NULL) {                    /* a block that wraps around the end of a foreign ring: one copy */
 			if (bounce == NULL) bounce = hfdl_xcalloc(need, sizeof(float complex));
 			hfdl_ring_read(ring->buf, bounce, need);
 		}
 		if (!ok) hfdl_ring_drop(ring->buf, hfdl_ring_size(ring->buf));
-		const bool backlog = hfdl_ring_size(ring->buf) >= 2 * need || (blk == NULL && hfdl_ring_size(ring->buf) >= need);   /* another whole block is already waiting */
+		const bool backlog = hfdl_ring_size(ring->buf) >= (leased + 2) * need || (blk == NULL && hfdl_ring_size(ring->buf) >= need);   /* another whole block is already waiting */
 		pthread_mutex_unlock(ring->mutex);
 		if (!ok) continue;
-		if (k == 0) t_first = now_s();
+		const double tw1 = now_s();
+		if (k == 0) t_first = tw1; else s_wait += tw1 - tw0;
 		if (hfdl_gpu_frontend_push_block_raw(fe, blk ? blk : bounce, need, blk ? gfmt : HFDL_GPU_SFMT_CF32, 0) != 0) {
 			fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
 			do_exit = 1;
@@ -280,6 +284,9 @@ static void *frontend_thread(void *ctx)
 			continue;
 		}
 		k++;
+		if (blk != NULL) leased++;
+		const double tw2 = now_s();
+		s_push += tw2 - tw1;
 		/* Keeping up with the source (live radio): wait for this block and deliver its PDUs at once.  Behind (file
 		 * replay, catching up): leave it running and collect the previous block, so the producer's reads and the copy of
 		 * this block overlap it. */
@@ -289,15 +296,20 @@ static void *frontend_thread(void *ctx)
 			for (int32_t i = 0; i < n; i++) push_pdu(&pdus[i], &t0);
 			npdus += (uint64_t)n;
 		} while (n == max_pdus);
-		/* the DMA engine has read the block (it started as soon as the staging buffer of two blocks ago was free, and ran
-		 * beside the kernels of the previous block): give the slot back to the producer */
-		if (blk != NULL) {
-			hfdl_gpu_frontend_input_done(fe);
+		const double tw3 = now_s();
+		s_poll += tw3 - tw2;
+		/* Ring slots go back to the producer when the DMA engine has read them.  Two blocks are leased at most: with a
+		 * backlog the copy of the block just pushed is NOT waited for -- only the one before it (done long ago), so the copy
+		 * engine never idles on this thread; without a backlog the pipeline was drained above and both are free. */
+		while (leased > (backlog ? 1u : 0u)) {
+			hfdl_gpu_frontend_input_done_upto(fe, k - leased);          /* the oldest leased block, as the GPU library numbers host blocks */
 			pthread_mutex_lock(ring->mutex);
 			hfdl_ring_drop(ring->buf, need);
 			pthread_mutex_unlock(ring->mutex);
 			pthread_cond_signal(ring->cond);
+			leased--;
 		}
+		s_release += now_s() - tw3;
 		/* the StatsD counters / gauges are read from the device every 50 ms of wall time at most: one strided device read per
 		 * block would cost more than a block of a small geometry takes (a block is decoded in ~0.3 ms) */
 		const double now = now_s();
@@ -318,6 +330,7 @@ shutdown:
 		g_run.seconds = k ? t_last - t_first : 0.0;
 		g_run.bytes_per_sample = (int32_t)elem; g_run.channels = (int32_t)nch; g_run.block_samples = (int32_t)need;
 		g_run.zero_copy = hfdl_ring_is_pinned(ring->buf);
+		g_run.wait_input_s = s_wait; g_run.push_s = s_push; g_run.collect_s = s_poll; g_run.release_s = s_release;
 		pthread_mutex_unlock(&g_run_lock);
 	}
 	block_connection_one2many_shutdown(down);

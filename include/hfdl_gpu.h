@@ -117,6 +117,10 @@ int  hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_geometry *
 int  hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
 /* wait until every host -> device input copy enqueued so far has finished (the kernels keep running) */
 int  hfdl_gpu_frontend_input_done(hfdl_gpu_frontend *fe);
+/* wait until the copy of host block number `host_block` (0 = the first block pushed with on_device == 0) has finished, WITHOUT
+ * waiting for the blocks pushed after it: a caller that leases two page-locked buffers pushes block k+1, then waits for block k and
+ * reuses its buffer -- the copy engine never idles on the host thread */
+int  hfdl_gpu_frontend_input_done_upto(hfdl_gpu_frontend *fe, uint64_t host_block);
 /* Same, for raw recorder / SDR samples converted on the device inside the overlap-assembly load of the forward FFT
  * (convert_cs16 / convert_cu8 / convert_cf32, src/input-helpers.c:10-78): interleaved I,Q int16 (full scale 32767.5),
  * uint8 (offset 63.5, full scale 127) or float32.  Halves / quarters the host->device bytes per sample. */

@@ -190,6 +190,8 @@ struct hfdl_run_stats {
 	int32_t bytes_per_sample;        /* of the samples as they crossed PCIe: 8 cf32, 4 cs16, 2 cu8 (converted on the device) */
 	int32_t channels, block_samples;
 	int32_t zero_copy;               /* 1: blocks were DMA'd straight out of the page-locked input ring */
+	double wait_input_s, push_s, collect_s, release_s;   /* the front-end thread's time: waiting for the producer, enqueueing,
+	                                                        collecting PDUs (waits for the previous block), releasing ring slots (waits for DMA) */
 };
 void          hfdl_frontend_run_stats(struct hfdl_run_stats *out);
 /* replay a regular input file this many times back to back (default 1); not in the reference */

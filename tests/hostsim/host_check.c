@@ -89,7 +89,7 @@ static int check_direct(const char *path, const char *fmt, const char *out_path,
 	if (block_connect_one2one(in, fft) != 1) return 3;
 	struct circ_buffer *cb = &fft->consumer.in->circ_buffer;
 	const size_t blk = hfdl_frontend_block_samples(fft), elem = hfdl_ring_elem_size(cb->buf);
-	if (blk != 28672 || hfdl_ring_capacity(cb->buf) % blk != 0 || hfdl_ring_capacity(cb->buf) < 4 * blk) return 4;
+	if (blk != 28672 || hfdl_ring_capacity(cb->buf) % blk != 0 || hfdl_ring_capacity(cb->buf) < 6 * blk) return 4;
 	if (hfdl_ring_format(cb->buf) != (int)cfg->sfmt || elem != get_sample_size(cfg->sfmt)) return 5;
 	float complex one = 1;
 	if (elem != 8 && hfdl_ring_write(cb->buf, &one, 1) != 0) return 6;      /* a raw ring refuses cf32 writes */
