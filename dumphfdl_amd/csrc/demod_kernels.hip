@@ -433,6 +433,12 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 		out->fcs_status = (uint8_t)pdu_triage(l_oct, (uint32_t)noct, &kind, &hdr_len);
 		out->pdu_kind = (uint8_t)kind;
 		out->hdr_len = (uint16_t)hdr_len;
+		LpduCounts lc;
+		lc.processed = lc.good = lc.bad_fcs = lc.too_short = lc.truncated = 0;
+		if (out->fcs_status == 0 && kind != 0) lc = lpdu_walk(l_oct, (uint32_t)noct, kind, hdr_len);
+		out->lpdus_processed = lc.processed; out->lpdus_good = lc.good; out->lpdus_bad_fcs = lc.bad_fcs;
+		out->lpdus_too_short = lc.too_short; out->lpdus_truncated = lc.truncated;
+		out->lpdu_pad[0] = out->lpdu_pad[1] = out->lpdu_pad[2] = 0;
 	}
 }
 
@@ -459,6 +465,20 @@ __global__ void pdu_triage_kernel(const uint8_t *__restrict__ octets, const int3
 	fcs_status[i] = (uint8_t)pdu_triage(octets + (size_t)i * stride, (uint32_t)lens[i], &k, &hl);
 	kind[i] = (uint8_t)k;
 	hdr_len[i] = (uint16_t)hl;
+}
+
+__global__ void lpdu_walk_kernel(const uint8_t *__restrict__ octets, const int32_t *__restrict__ lens, int npdus, int stride, uint8_t *__restrict__ counts)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= npdus) return;
+	const uint8_t *buf = octets + (size_t)i * stride;
+	int k = 0;
+	uint32_t hl = 0;
+	LpduCounts c;
+	c.processed = c.good = c.bad_fcs = c.too_short = c.truncated = 0;
+	if (pdu_triage(buf, (uint32_t)lens[i], &k, &hl) == 0 && k != 0) c = lpdu_walk(buf, (uint32_t)lens[i], k, hl);
+	uint8_t *o = counts + (size_t)i * 5;
+	o[0] = c.processed; o[1] = c.good; o[2] = c.bad_fcs; o[3] = c.too_short; o[4] = c.truncated;
 }
 
 // ---------------------------------------------------------------- host side
@@ -742,6 +762,22 @@ int demod_pdu_triage_batch(const uint8_t *octets, const int32_t *lens, int32_t n
 	D_TRY(hipMemcpy(fcs_status, d_fcs.p, n, hipMemcpyDeviceToHost));
 	D_TRY(hipMemcpy(kind, d_kind.p, n, hipMemcpyDeviceToHost));
 	D_TRY(hipMemcpy(hdr_len, d_hl.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int demod_lpdu_walk_batch(const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride, uint8_t *counts)
+{
+	DevBuf d_oct, d_lens, d_cnt;
+	const size_t n = (size_t)npdus;
+	D_TRY(d_oct.alloc(n * (size_t)stride));
+	D_TRY(d_lens.alloc(n * sizeof(int32_t)));
+	D_TRY(d_cnt.alloc(n * 5));
+	D_TRY(hipMemcpy(d_oct.p, octets, n * (size_t)stride, hipMemcpyHostToDevice));
+	D_TRY(hipMemcpy(d_lens.p, lens, n * sizeof(int32_t), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(lpdu_walk_kernel, dim3((unsigned)((npdus + 63) / 64)), dim3(64), 0, nullptr, d_oct.as<const uint8_t>(), d_lens.as<const int32_t>(), npdus, stride, d_cnt.as<uint8_t>());
+	D_TRY(hipDeviceSynchronize());
+	D_TRY(hipGetLastError());
+	D_TRY(hipMemcpy(counts, d_cnt.p, n * 5, hipMemcpyDeviceToHost));
 	return 0;
 }
 

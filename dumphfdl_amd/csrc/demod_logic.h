@@ -208,14 +208,17 @@ HFDL_FN void psk_soft(int arity, cf x, uint8_t *soft)
 // ---------------- PDU header triage: FCS = CRC-16/X-25 over the header, stored low octet first ----------------
 // hfdl_pdu_fcs_check (src/pdu.c:68-79), header length rules of mpdu_parse (src/mpdu.c:56-79) and spdu_parse (src/spdu.c:12,55-62)
 
-// crc16_ccitt(data, len, crc_init) of src/crc.c:4-47 (reflected polynomial 0x8408; the reference walks a 256-entry table,
-// this is the same recurrence bit by bit -- no table to stage, and it runs once per PDU on one lane)
+// crc16_ccitt(data, len, crc_init) of src/crc.c:4-47 (reflected polynomial 0x8408).  The reference walks a 256-entry table; one
+// table entry is the eight shift-and-conditional-xor steps of the low octet, which for this polynomial (x^16 + x^12 + x^5 + 1)
+// collapse to three shifted copies of d = low ^ (low << 4): ~8 integer operations per octet on the one lane that runs it, no
+// table to stage.  Pinned against the reference's compiled crc.c by tests/golden/crc_ref.json.
 HFDL_FN uint16_t crc16_ccitt_step(const uint8_t *p, uint32_t len, uint16_t crc_init)
 {
 	uint32_t crc = crc_init;
 	for (uint32_t i = 0; i < len; i++) {
-		crc ^= p[i];
-		for (int b = 0; b < 8; b++) crc = (crc & 1u) ? (crc >> 1) ^ 0x8408u : crc >> 1;
+		uint32_t d = (p[i] ^ crc) & 0xFFu;
+		d = (d ^ (d << 4)) & 0xFFu;
+		crc = ((d << 8) | (crc >> 8)) ^ (d >> 4) ^ (d << 3);
 	}
 	return (uint16_t)crc;
 }
@@ -251,6 +254,56 @@ HFDL_FN int pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hd
 	if (len < hdr_len + 2) return 2;
 	const uint16_t rx = (uint16_t)(buf[hdr_len] | (buf[hdr_len + 1] << 8));
 	return rx == crc16_x25(buf, hdr_len) ? 0 : 1;
+}
+
+// ---------------- LPDU list walk: what mpdu_parse does next (src/mpdu.c:92-158) with lpdu_parse's FCS check (src/lpdu.c:136-149) ----------------
+// For an MPDU whose header FCS is good: every LPDU the header announces is located (one size octet per LPDU, size - 1) and its own
+// FCS -- the same CRC, over all but its last two octets -- is checked.  The counts are the reference's StatsD events of this stage:
+// lpdus.processed, lpdus.good, lpdu.errors.bad_fcs, lpdu.errors.too_short; `truncated` = an announced LPDU runs past the PDU
+// (parse_lpdu_list returns -1 and the MPDU's remaining LPDUs are not looked at).
+struct LpduCounts { uint8_t processed, good, bad_fcs, too_short, truncated; };
+
+// one aircraft's / the downlink's list: size octets at `lens`, LPDUs from `data`; returns octets consumed or -1 (src/mpdu.c:136-158)
+HFDL_FN int lpdu_list_walk(const uint8_t *lens, const uint8_t *data, const uint8_t *end, uint32_t lpdu_cnt, LpduCounts &c)
+{
+	int consumed = 0;
+	for (uint32_t j = 0; j < lpdu_cnt; j++) {
+		const uint32_t lpdu_len = (uint32_t)lens[j] + 1;
+		if (data + lpdu_len > end) { c.truncated = 1; return -1; }
+		c.processed++;
+		if (lpdu_len < 3) c.too_short++;                                        // lpdu_parse: "need at least LPDU type + FCS"
+		else {
+			const uint16_t rx = (uint16_t)(data[lpdu_len - 2] | (data[lpdu_len - 1] << 8));
+			if (rx == crc16_x25(data, lpdu_len - 2)) c.good++; else c.bad_fcs++;
+		}
+		data += lpdu_len;
+		consumed += (int)lpdu_len;
+	}
+	return consumed;
+}
+
+// buf / len: the PDU; kind / hdr_len: from pdu_triage(), which must have returned 0 (header FCS good)
+HFDL_FN LpduCounts lpdu_walk(const uint8_t *buf, uint32_t len, int kind, uint32_t hdr_len)
+{
+	LpduCounts c;
+	c.processed = c.good = c.bad_fcs = c.too_short = c.truncated = 0;
+	const uint8_t *end = buf + len;
+	const uint8_t *data = buf + hdr_len + 2;                                    // first data octet of the first LPDU, src/mpdu.c:91
+	if (kind == 1) {                                                            // downlink: size octets from octet 6
+		lpdu_list_walk(buf + 6, data, end, (buf[0] >> 2) & 0xFu, c);
+	} else if (kind == 2) {                                                     // uplink: per aircraft {id, NLP/DDR/P, size octets}, src/mpdu.c:104-123
+		const uint32_t aircraft_cnt = ((buf[0] & 0x70u) >> 4) + 1;
+		const uint8_t *hdr = buf + 2;
+		for (uint32_t i = 0; i < aircraft_cnt; i++) {
+			hdr++;                                                              // destination aircraft id
+			const uint32_t lpdu_cnt = (*hdr++ >> 4) & 0xFu;
+			const int used = lpdu_list_walk(hdr, data, end, lpdu_cnt, c);
+			if (used < 0) break;
+			hdr += lpdu_cnt;
+			data += used;
+		}
+	}
+	return c;
 }
 
 HFDL_FN void symsync_reset(ChanScalars &s, ChanArrays &a)

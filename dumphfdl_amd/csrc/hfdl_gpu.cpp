@@ -879,3 +879,14 @@ extern "C" int hfdl_gpu_pdu_triage(int device, const uint8_t *octets, const int3
 	if (rc) return fail(rc, "pdu triage failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;
 }
+
+extern "C" int hfdl_gpu_lpdu_walk(int device, const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride, uint8_t *counts)
+{
+	if (!octets || !lens || !counts || npdus <= 0 || stride <= 0) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	for (int i = 0; i < npdus; i++) if (lens[i] < 1 || lens[i] > stride) return fail(HFDL_GPU_EINVAL, "PDU %d: length %d outside 1..%d", i, lens[i], stride);
+	int rc = select_device(device);
+	if (rc) return rc;
+	rc = demod_lpdu_walk_batch(octets, lens, npdus, stride, counts);
+	if (rc) return fail(rc, "lpdu walk failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}

@@ -32,6 +32,8 @@ class Pdu(C.Structure):
                 ("slot", C.c_char), ("fcs_status", C.c_uint8), ("pdu_kind", C.c_uint8), ("hdr_len", C.c_uint16),
                 ("sample_index", C.c_uint64),
                 ("train_bits_bad", C.c_int32), ("train_bits_total", C.c_int32),
+                ("lpdus_processed", C.c_uint8), ("lpdus_good", C.c_uint8), ("lpdus_bad_fcs", C.c_uint8), ("lpdus_too_short", C.c_uint8),
+                ("lpdus_truncated", C.c_uint8), ("lpdu_pad", C.c_uint8 * 3),
                 ("octets", C.c_uint8 * PDU_MAX_OCTETS)]
 
 
@@ -58,7 +60,7 @@ EXPORTS = [
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_input_done_upto", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
-    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage",
+    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
 
@@ -112,6 +114,7 @@ def load():
                                         C.c_void_p, C.POINTER(C.c_int32)]
     L.hfdl_gpu_crc16_ccitt.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint16, C.POINTER(C.c_uint16)]
     L.hfdl_gpu_pdu_triage.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hfdl_gpu_lpdu_walk.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     _lib = L
     return L
 
@@ -217,7 +220,8 @@ class Frontend:
                             octets=bytes(p.octets[:p.len]), freq_err_hz=p.freq_err_hz, rssi_db=p.rssi_db,
                             noise_floor_db=p.noise_floor_db, slot=p.slot.decode(), sample_index=p.sample_index,
                             fcs_status=p.fcs_status, pdu_kind=p.pdu_kind, hdr_len=p.hdr_len,
-                            train_bits_bad=p.train_bits_bad, train_bits_total=p.train_bits_total))
+                            train_bits_bad=p.train_bits_bad, train_bits_total=p.train_bits_total,
+                            lpdus=(p.lpdus_processed, p.lpdus_good, p.lpdus_bad_fcs, p.lpdus_too_short, p.lpdus_truncated)))
         return out
 
     def poll_pdus(self, max_pdus=4096, max_in_flight=0):
@@ -345,3 +349,16 @@ def pdu_triage(pdus, device=0):
     fcs, kind, hl = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint16)
     _check(load().hfdl_gpu_pdu_triage(device, _p(octets), _p(lens), n, stride, _p(fcs), _p(kind), _p(hl)))
     return [(int(fcs[i]), int(kind[i]), int(hl[i])) for i in range(n)]
+
+
+def lpdu_walk(pdus, device=0):
+    """pdus: list of bytes -> list of (processed, good, bad_fcs, too_short, truncated) computed on the device."""
+    n = len(pdus)
+    stride = max(len(p) for p in pdus)
+    octets = np.zeros((n, stride), np.uint8)
+    for i, p in enumerate(pdus):
+        octets[i, :len(p)] = np.frombuffer(bytes(p), np.uint8)
+    lens = np.array([len(p) for p in pdus], np.int32)
+    counts = np.zeros((n, 5), np.uint8)
+    _check(load().hfdl_gpu_lpdu_walk(device, _p(octets), _p(lens), n, stride, _p(counts)))
+    return [tuple(int(v) for v in counts[i]) for i in range(n)]

@@ -79,6 +79,44 @@ def make_mpdu(rng, total_len):
     return bytes(buf)
 
 
+def make_mpdu_with_lpdus(rng, total_len, uplink=False, spoil=()):
+    """An MPDU whose LPDU list is real (src/mpdu.c:56-158): `total_len` octets, size octets = LPDU length - 1, every LPDU ends in
+    its own FCS (src/lpdu.c:143-144).  `spoil`: indices of LPDUs whose FCS is broken.  Returns (octets, lpdu_count)."""
+    def lpdu(n, bad):
+        body = bytearray(rng.integers(0, 256, n - 2, dtype=np.uint8).tobytes())
+        fcs = crc16_x25(body) ^ (0x0100 if bad else 0)
+        return bytes(body) + bytes([fcs & 0xFF, fcs >> 8])
+
+    if not uplink:
+        cnt = int(rng.integers(1, 8))
+        hdr_len = 6 + cnt
+        room = total_len - hdr_len - 2
+        lens = [int(v) for v in rng.integers(3, min(257, max(4, room // cnt)), cnt)]
+        hdr = bytearray(rng.integers(0, 256, hdr_len, dtype=np.uint8).tobytes())
+        hdr[0] = (hdr[0] & 0xC0) | (cnt << 2) | 0x3
+        for j, n in enumerate(lens):
+            hdr[6 + j] = n - 1
+        groups = [lens]
+    else:
+        ac = int(rng.integers(1, 4))
+        per_ac = [int(rng.integers(1, 4)) for _ in range(ac)]
+        cnt = sum(per_ac)
+        room = total_len - (2 + 2 * ac + cnt) - 2
+        groups = [[int(v) for v in rng.integers(3, min(257, max(4, room // cnt)), k)] for k in per_ac]
+        hdr = bytearray([0x01 | ((ac - 1) << 4), int(rng.integers(0, 128))])
+        for g in groups:
+            hdr += bytes([int(rng.integers(0, 256)), (len(g) << 4) | int(rng.integers(0, 16))]) + bytes(n - 1 for n in g)
+    fcs = crc16_x25(hdr)
+    out = bytes(hdr) + bytes([fcs & 0xFF, fcs >> 8])
+    k = 0
+    for g in groups:
+        for n in g:
+            out += lpdu(n, k in spoil)
+            k += 1
+    assert len(out) <= total_len
+    return out + bytes(total_len - len(out)), cnt
+
+
 def make_pdu(rng, mode):
     sz = mode_sizes(mode)
     if sz["max_payload"] == 66 and rng.random() < 0.5:

@@ -19,6 +19,7 @@
  *   decimating_shift_addition_init / _cc           src/libcsdr_gpl.h:43-44, src/libcsdr_gpl.c:26-74 -> hfdl_gpu_nco_decimate
  *   crc16_ccitt                                    src/crc.h, src/crc.c:4-47            -> hfdl_gpu_crc16_ccitt
  *   hfdl_pdu_fcs_check + header length rules       src/pdu.c:68-79, src/mpdu.c:56-79, src/spdu.c:55-62 -> hfdl_gpu_pdu_triage
+ *   parse_lpdu_list + lpdu_parse's FCS check       src/mpdu.c:92-158, src/lpdu.c:136-149 -> hfdl_gpu_lpdu_walk (and hfdl_gpu_pdu.lpdus_*)
  *
  * All functions return 0 on success or a negative HFDL_GPU_E* code (the reference's constructors
  * return NULL / -1 and xcalloc failure _exit()s: src/util.c:25-33); hfdl_gpu_last_error() gives text.
@@ -86,6 +87,10 @@ typedef struct {
 	uint16_t hdr_len;                /* octets covered by the FCS */
 	uint64_t sample_index;
 	int32_t  train_bits_bad, train_bits_total;
+	/* MPDUs with a good header FCS: the LPDU list walked on the device (parse_lpdu_list, src/mpdu.c:136-158) with every LPDU's own
+	 * FCS checked (lpdu_parse, src/lpdu.c:136-149) -- the reference's lpdus.processed / lpdus.good / lpdu.errors.bad_fcs /
+	 * lpdu.errors.too_short events of this PDU; lpdus_truncated = an announced LPDU runs past the PDU.  All 0 otherwise. */
+	uint8_t  lpdus_processed, lpdus_good, lpdus_bad_fcs, lpdus_too_short, lpdus_truncated, lpdu_pad[3];
 	uint8_t  octets[HFDL_GPU_PDU_MAX_OCTETS];
 } hfdl_gpu_pdu;
 
@@ -221,6 +226,10 @@ int  hfdl_gpu_crc16_ccitt(int device, const uint8_t *data, uint32_t len, uint16_
  * pdu_kind[i] = HFDL_GPU_KIND_*, hdr_len[i] = octets covered by the FCS (what burst decoding fills into hfdl_gpu_pdu) */
 int  hfdl_gpu_pdu_triage(int device, const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride,
 		uint8_t *fcs_status, uint8_t *pdu_kind, uint16_t *hdr_len);
+
+/* the LPDU list walk of `npdus` PDUs (must be MPDUs or SPDUs as they come out of the decoder): counts[i * 5 + 0..4] = lpdus processed,
+ * good, bad FCS, too short, truncated flag -- zeros when the header triage of PDU i is not "FCS good" */
+int  hfdl_gpu_lpdu_walk(int device, const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride, uint8_t *counts);
 
 /* kernel time in ms of the last hfdl_gpu_fft_forward / _viterbi27 / _burst_decode call made by this thread (HIP events
  * around the launch; allocation and host <-> device copies excluded) */

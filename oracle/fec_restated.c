@@ -121,6 +121,51 @@ int orc_pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hdr_le
 	return orc_fcs_check(buf, hl) ? 0 : 1;
 }
 
+/* ---- LPDU list walk: parse_lpdu_list (src/mpdu.c:136-158) + lpdu_parse's length / FCS checks (src/lpdu.c:136-149) ----
+ * counts[0..4] = lpdus.processed, lpdus.good, lpdu.errors.bad_fcs, lpdu.errors.too_short, truncated flag. */
+static int lpdu_list_counts(const uint8_t *lpdu_len_ptr, const uint8_t *data_ptr, const uint8_t *endptr, uint32_t lpdu_cnt, uint8_t *counts)
+{
+	int consumed_octets = 0;
+	for (uint32_t j = 0; j < lpdu_cnt; j++) {
+		uint32_t lpdu_len = (uint32_t)*lpdu_len_ptr + 1;                       /* src/mpdu.c:142 */
+		if (data_ptr + lpdu_len <= endptr) {                                   /* :143 */
+			counts[0]++;                                                       /* lpdu_parse: "lpdus.processed", src/lpdu.c:127 */
+			if (lpdu_len < 3) counts[3]++;                                     /* :136-140 */
+			else if (orc_fcs_check(data_ptr, lpdu_len - 2)) counts[1]++;       /* :143-150 */
+			else counts[2]++;
+			data_ptr += lpdu_len;
+			consumed_octets += (int)lpdu_len;
+			lpdu_len_ptr++;
+		} else {
+			counts[4] = 1;                                                     /* :152-155: return -1 */
+			return -1;
+		}
+	}
+	return consumed_octets;
+}
+
+void orc_lpdu_walk(const uint8_t *buf, uint32_t len, uint8_t *counts)
+{
+	int kind = 0;
+	uint32_t hdr_len = 0;
+	for (int i = 0; i < 5; i++) counts[i] = 0;
+	if (orc_pdu_triage(buf, len, &kind, &hdr_len) != 0 || kind == 0) return;  /* bad header FCS: "goto end" before any LPDU, src/mpdu.c:83-89 */
+	const uint8_t *dataptr = buf + hdr_len + 2;                                /* src/mpdu.c:91 */
+	if (kind == 1) {
+		lpdu_list_counts(buf + 6, dataptr, buf + len, (buf[0] >> 2) & 0xF, counts);        /* :96-100 */
+	} else {
+		uint32_t aircraft_cnt = ((buf[0] & 0x70) >> 4) + 1;
+		const uint8_t *hdrptr = buf + 2;                                       /* :106 */
+		uint32_t lpdu_cnt = 0;
+		int consumed = 0;
+		for (uint32_t i = 0; i < aircraft_cnt; i++, hdrptr += lpdu_cnt, dataptr += consumed) {   /* :108 */
+			hdrptr++;                                                          /* dst_id */
+			lpdu_cnt = (*hdrptr++ >> 4) & 0xF;
+			if ((consumed = lpdu_list_counts(hdrptr, dataptr, buf + len, lpdu_cnt, counts)) < 0) return;
+		}
+	}
+}
+
 uint8_t orc_reverse_byte(uint8_t x)
 {
 	x = (uint8_t)((x >> 4) | (x << 4));

@@ -79,6 +79,8 @@ int      orc_fcs_check(const uint8_t *buf, uint32_t hdr_len);                  /
 /* header triage as mpdu_parse / spdu_parse begin: src/mpdu.c:56-89, src/spdu.c:12,55-62, src/pdu.c:124-128.
  * returns 0 good FCS, 1 bad FCS, 2 too short; kind 0 SPDU, 1 MPDU downlink, 2 MPDU uplink */
 int      orc_pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hdr_len);
+/* parse_lpdu_list + lpdu_parse's checks (src/mpdu.c:92-158, src/lpdu.c:127-150): counts[5] = processed, good, bad FCS, too short, truncated */
+void     orc_lpdu_walk(const uint8_t *buf, uint32_t len, uint8_t *counts);
 uint8_t  orc_reverse_byte(uint8_t x);                                          /* src/util.h:109 */
 
 /* ---------------- HFDL frame constants (src/hfdl.c:29-46,81-138) ---------------- */

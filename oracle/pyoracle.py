@@ -89,6 +89,7 @@ def lib():
         L.orc_crc16_ccitt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint16]
         L.orc_fcs_check.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_pdu_triage.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
+        L.orc_lpdu_walk.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_viterbi27_decode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.orc_conv27_encode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.orc_fft_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
@@ -231,6 +232,14 @@ def pdu_triage(octets):
     kind, hl = C.c_int(0), C.c_uint32(0)
     st = lib().orc_pdu_triage(_p(a), len(a), C.byref(kind), C.byref(hl))
     return st, kind.value, hl.value
+
+
+def lpdu_walk(octets):
+    """(processed, good, bad_fcs, too_short, truncated) of the PDU's LPDU list."""
+    a = np.frombuffer(bytes(octets), np.uint8).copy()
+    counts = np.zeros(5, np.uint8)
+    lib().orc_lpdu_walk(_p(a), len(a), _p(counts))
+    return tuple(int(v) for v in counts)
 
 
 def decode_user_data(mode, symbols, bitmask_lsb=0):

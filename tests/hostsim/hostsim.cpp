@@ -87,6 +87,15 @@ void sim_psk_soft(int arity, float re, float im, uint8_t *soft) { cf x; x.x = re
 
 int sim_pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hdr_len) { return pdu_triage(buf, len, kind, hdr_len); }
 
+void sim_lpdu_walk(const uint8_t *buf, uint32_t len, uint8_t *counts)
+{
+	int kind = 0; uint32_t hl = 0;
+	for (int i = 0; i < 5; i++) counts[i] = 0;
+	if (pdu_triage(buf, len, &kind, &hl) != 0 || kind == 0) return;
+	const LpduCounts c = lpdu_walk(buf, len, kind, hl);
+	counts[0] = c.processed; counts[1] = c.good; counts[2] = c.bad_fcs; counts[3] = c.too_short; counts[4] = c.truncated;
+}
+
 void sim_tables(float resamp_rate, DemodTables *out) { build_demod_tables(*out, resamp_rate); }
 
 // planner: geometry + channel constants + time-domain taps as the GPU shim computes them

@@ -154,6 +154,8 @@ def _run_both(gpu, oracle, fs, cf, freqs, x, check_stages=False):
         assert abs(st["noise_floor_db"] - 20 * np.log10(oc["noise_floor"])) < 0.2
         assert st["freq"] == freqs[c]
     fe.close()
+    for p in pdus:                                          # the on-device LPDU walk of every PDU = the oracle's over the same octets
+        assert p["lpdus"] == oracle.lpdu_walk(p["octets"]), (p["freq"], p["sample_index"])
     return pdus, ora.pdus, worst
 
 
@@ -178,6 +180,38 @@ def test_end_to_end_small_matches_oracle(gpu, oracle):
         assert abs(a["freq_err_hz"] - b["freq_err_hz"]) < 0.05
         assert abs(a["rssi_db"] - b["rssi_db"]) < 0.05 and abs(a["noise_floor_db"] - b["noise_floor_db"]) < 0.2
         assert a["slot"] == b["slot"] and a["bit_rate"] == b["bit_rate"]
+
+
+def test_end_to_end_lpdu_lists(gpu, oracle):
+    """MPDUs carrying real LPDU lists (down- and uplink; some LPDUs with a spoiled FCS) through the whole path: every PDU
+    record's lpdus_* counts -- parse_lpdu_list + lpdu_parse's checks done by the burst decoder on the device -- equal both
+    the oracle's walk of the decoded octets and what was put on the air."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_930_000, 10_037_000, 10_081_500]
+    dur = 9.0
+    bursts = synth.plan_traffic(freqs, dur, seed=31, dense=True)
+    rng = np.random.default_rng(31)
+    sent = {}
+    for i, b in enumerate(bursts):
+        n = synth.mode_sizes(b["mode"])["max_payload"]
+        if n < 120:
+            continue
+        spoil = (0,) if i % 3 == 0 else ()
+        b["octets"], cnt = synth.make_mpdu_with_lpdus(rng, n, uplink=bool(i & 1), spoil=spoil)
+        sent[b["octets"]] = (cnt, cnt - len(spoil), len(spoil), 0, 0)
+    assert len(sent) >= 4
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.01, seed=31)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    seen = 0
+    for p in got:
+        for octets, counts in sent.items():                 # the decoder hands over whole interleaver blocks: payload + padding
+            if p["octets"][:len(octets)] == octets:
+                assert p["lpdus"] == counts and p["fcs_status"] == 0
+                seen += 1
+    assert seen == len(sent)
+    assert any(p["lpdus"][2] for p in got) and any(p["pdu_kind"] == 2 and p["lpdus"][1] for p in got)
 
 
 def test_end_to_end_cfg2_shape(gpu, oracle):

@@ -211,6 +211,47 @@ def test_pdu_triage_matches_oracle(sim, oracle):
     assert oracle.pdu_triage(good)[:2] == (0, 0) and oracle.pdu_triage(good[:40])[0] == 2
 
 
+def lpdu_cases(rng):
+    """MPDUs with real LPDU lists (down- and uplink, clean and with spoiled LPDU FCS), truncated ones, too-short LPDUs,
+    SPDUs, header-FCS failures and random octets."""
+    cases = []
+    for i in range(40):
+        total = int(rng.integers(120, 404))
+        up = bool(i & 1)
+        spoil = () if i % 4 < 2 else (int(rng.integers(0, 3)),)
+        cases.append(synth.make_mpdu_with_lpdus(rng, total, uplink=up, spoil=spoil)[0])
+    cases += [c[:int(len(c) * 0.6)] for c in cases[:8]]                         # announced LPDUs run past the end
+    short = bytearray([0x03 | (2 << 2), 1, 2, 3, 4, 5, 1, 0])                   # downlink, two LPDUs of 2 and 1 octets
+    fcs = synth.crc16_x25(short)
+    cases.append(bytes(short) + bytes([fcs & 0xFF, fcs >> 8]) + bytes(3))
+    cases.append(synth.make_spdu(rng) + bytes(2))
+    cases.append(cases[0][:3] + bytes([cases[0][3] ^ 1]) + cases[0][4:])        # header FCS broken: nothing is walked
+    cases += [rng.integers(0, 256, int(rng.integers(1, 300)), dtype=np.uint8).tobytes() for _ in range(300)]
+    return cases
+
+
+def test_lpdu_walk_matches_oracle(sim, oracle):
+    """The device-side LPDU list walk (parse_lpdu_list + lpdu_parse's length / FCS checks; same source compiled for the
+    host) against the oracle's restatement, and against what the generator wrote."""
+    rng = np.random.default_rng(33)
+    sim.sim_lpdu_walk.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    for up in (False, True):
+        pdu, cnt = synth.make_mpdu_with_lpdus(rng, 300, uplink=up)
+        assert oracle.lpdu_walk(pdu) == (cnt, cnt, 0, 0, 0)
+        pdu, cnt = synth.make_mpdu_with_lpdus(rng, 300, uplink=up, spoil=(0,))
+        assert oracle.lpdu_walk(pdu) == (cnt, cnt - 1, 1, 0, 0)
+    seen = set()
+    for c in lpdu_cases(rng):
+        a = np.frombuffer(c, np.uint8).copy()
+        counts = np.zeros(5, np.uint8)
+        sim.sim_lpdu_walk(a.ctypes.data, len(a), counts.ctypes.data)
+        got = tuple(int(v) for v in counts)
+        assert got == oracle.lpdu_walk(c)
+        seen.add(tuple(bool(v) for v in got))
+    assert {(True, True, False, False, False), (True, True, True, False, False), (False,) * 5} <= seen
+    assert any(s[4] for s in seen) and any(s[3] for s in seen)
+
+
 def test_bench_traffic_plans():
     """bench.py's synthetic traffic: bursts of a channel never overlap, all end inside the resident stretch, the burst-dense
     workload cycles all eight modes (BASELINE.json configs[3]) and the plan is a pure function of the seed."""
