@@ -232,10 +232,18 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 
 struct CarrierRegs {
 	float eu, ev, ex2, ewx, ewy;   // equaliser: lane t < 15 of rows 0 and 1 = tap t (0 oldest); row 0 holds (x, y), row 1 (y, -x)
+	float px, py;                  // lane i < 16: PSK constellation entry i (demod_tables.h psk_pts)
 };
 
-__device__ __forceinline__ void carrier_load(CarrierRegs &c, const ChanScalars &s, const ChanArrays &a, int lane)
+struct PskLanes {                  // the constellation table held across the lanes of the carrier wave
+	float px, py;
+	__device__ __forceinline__ cf operator()(int i) const { cf y; y.x = lane_value(px, i); y.y = lane_value(py, i); return y; }
+};
+
+__device__ __forceinline__ void carrier_load(CarrierRegs &c, const ChanScalars &s, const ChanArrays &a, const DemodConst &T, int lane)
 {
+	c.px = lane < 16 ? T.psk_pts[2 * lane] : 0.f;
+	c.py = lane < 16 ? T.psk_pts[2 * lane + 1] : 0.f;
 	const int t = lane & 15;
 	const bool act = t < D_EQ && lane < 32, row1 = (lane >> 4) & 1;
 	int j = s.eq_head + t; if (j >= D_EQ) j -= D_EQ;
@@ -284,19 +292,21 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 		if (j1 > sh.outq_cap) j1 = sh.outq_cap;
 		for (; j < j1; j++, s.symsync_out_idx++) {
 			cf oi;
-			if (j - jbase < 64) { oi.x = lane_value(oq_l.x, j - jbase); oi.y = lane_value(oq_l.y, j - jbase); }
+			if (__builtin_expect(j - jbase < 64, 1)) { oi.x = lane_value(oq_l.x, j - jbase); oi.y = lane_value(oq_l.y, j - jbase); }
 			else oi = sh.outq[j];
 			// costas_cccf_step + execute, :256-258, :284-292
-			s.phi += s.dphi;
-			if (s.phi > (float)M_PI) s.phi -= (float)(2.0 * M_PI);
-			else if (s.phi < -(float)M_PI) s.phi += (float)(2.0 * M_PI);
+			{   // selects, not branches: a taken branch costs a lone wave ~4 instruction slots (profiles/micro)
+				const float ph = s.phi + s.dphi;
+				const float dn = ph - (float)(2.0 * M_PI), up = ph + (float)(2.0 * M_PI);
+				s.phi = ph > (float)M_PI ? dn : (ph < -(float)M_PI ? up : ph);
+			}
 			// |phi| <= pi: the hardware sin/cos (argument in revolutions) needs no range reduction
 			const float rev = s.phi * 0.15915494309189535f;
 			const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
 			cf r;
 			r.x = oi.x * cp + oi.y * sp;
 			r.y = oi.y * cp - oi.x * sp;
-			if (runaway) {                       // costas run-away while searching (src/hfdl.c:709-716); dphi only moves in on_symbol()
+			if (__builtin_expect(runaway, 0)) {  // costas run-away while searching (src/hfdl.c:709-716); dphi only moves in on_symbol()
 				s.dphi = s.phi = 0.f;
 				symsync_reset(s, a);
 				runaway = false;
@@ -333,16 +343,16 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				}
 				if (TAPS && lane == 0) io.tap_symbols[nsym] = y;
 				nsym++;
-				on_symbol(s, a, T, io, y, level);
+				on_symbol(s, a, T, io, y, level, PskLanes{c.px, c.py});
 				runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
 			}
-			if (s.ev_flags & EV_EQ_RESET) {      // eqlms_cccf_reset ran (framer reset): mirror it in the register window
+			if (__builtin_expect((s.ev_flags & EV_EQ_RESET) != 0, 0)) {      // eqlms_cccf_reset ran (framer reset): mirror it in the register window
 				c.eu = 0.f; c.ev = 0.f; c.ex2 = 0.f;
 				c.ewx = act ? T.eq_h0[t < D_EQ ? t : 0] : 0.f; c.ewy = 0.f;
 				s.ev_flags &= ~(uint32_t)EV_EQ_RESET;
 			}
 		}
-		if (s.ev_flags & EV_SS_RESET) {          // the timing loop was reset during this sample: wave 1 restarts after it
+		if (__builtin_expect((s.ev_flags & EV_SS_RESET) != 0, 0)) {          // the timing loop was reset during this sample: wave 1 restarts after it
 			s.ev_flags = 0;
 			s.sample_cnt++;
 			return k;
@@ -444,7 +454,7 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 		CarrierRegs cr;
 		ChanScalars s3 = S;               // wave 2's working copy: it owns every field but the resampler / AGC / timing-loop ones
 		s3.ev_flags = 0;
-		carrier_load(cr, s3, a, lane);
+		carrier_load(cr, s3, a, T, lane);
 		PipeProgress pp;
 		for (int step = 0; pp.s3_done < n_out; step++) {
 			int *mb = sh.mbox + 4 * (step & 1);

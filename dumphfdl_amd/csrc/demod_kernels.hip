@@ -8,6 +8,7 @@
 //                          libfec update_viterbi27_blk / chainback_viterbi27, src/libfec/viterbi27_port.c:105-221).
 //     Viterbi mapping: lane = trellis state (64 = one wavefront); the two predecessor metrics arrive by
 //     cross-lane shuffle, the 64 decisions of a trellis step are one __ballot word kept in LDS.
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <utility>
 #include <vector>
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 	uint8_t *table = lds;
 	uint8_t *vin = lds + K5_TABLE_BYTES;
 	uint64_t *decw = (uint64_t *)(lds + 2 * K5_TABLE_BYTES);
-	uint8_t *l_scr = lds + 2 * K5_TABLE_BYTES + viterbi_lds_bytes(7560);             // 128 bytes
+	uint8_t *l_scr = lds + 2 * K5_TABLE_BYTES + viterbi_lds_bytes(7560);             // 128 bytes, then the constellation table
+	float *l_psk = (float *)(l_scr + DEC_PSK_OFFSET);
 
 	const FrameRec fr = frames[f];
 	const ModeParams mp = mode_params(fr.mode);
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 	const float mask_flip = fr.bitmask_lsb ? -1.0f : 1.0f;
 	l_scr[lane] = lane < 120 ? scrambler[lane] : 0;
 	if (lane + 64 < 120) l_scr[lane + 64] = scrambler[lane + 64];
+	if (lane < 32) l_psk[lane] = ((const float *)(scrambler + DEC_PSK_OFFSET))[lane];
 	__syncthreads();
 	// descramble + soft de-map + de-interleaver push (src/hfdl.c:1008-1019, 378-392); four symbol loads per lane in flight
 	// (this kernel runs beside the fold, where a dependent global load costs microseconds)
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 			cf x = xs[u];
 			x.x *= flip; x.y *= flip;
 			uint8_t soft[3];
-			psk_soft(mp.arity, x, soft);
+			psk_soft(mp.arity, x, soft, PskTable{l_psk});
 			for (int j = 0; j < mp.arity; j++) {
 				const int k = i * mp.arity + j;
 				const int row = k % 40;
@@ -495,7 +498,7 @@ struct KernelTimer {
 
 static size_t demod_lds_bytes(int cap) { return DemodLds(cap).total; }
 
-static size_t k5_lds_bytes() { return 2 * (size_t)K5_TABLE_BYTES + viterbi_lds_bytes(7560) + 128; }
+static size_t k5_lds_bytes() { return 2 * (size_t)K5_TABLE_BYTES + viterbi_lds_bytes(7560) + DEC_CONST_BYTES; }
 
 static DevTables resolve_tables(const float *d_img, const DemodTables &h)
 {
@@ -514,6 +517,7 @@ static DevTables resolve_tables(const float *d_img, const DemodTables &h)
 	t.c.m1_lo = (const uint64_t *)at(h.m1_lo);
 	t.scrambler = (const uint8_t *)at(h.scrambler);
 	t.c.corr_tab = (const float *)at(h.corr_tab);
+	t.c.psk_pts = (const float *)at(h.psk_pts);
 	t.c.a1_lo = h.a1_lo; t.c.a1_hi = h.a1_hi; t.c.a2_lo = h.a2_lo; t.c.a2_hi = h.a2_hi; t.c.pos_min = h.pos_min;
 	return t;
 }
@@ -580,21 +584,23 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 // burst decoder of launch i may run on another stream than the demodulator of launch i+1; it zeroes the counter of launch i+2,
 // whose previous users (launch i-2) are done and whose next user (the demodulator of launch i+2) is made to wait for this
 // decoder by the caller -- no memset launch per block, no counter shared by two kernels that can overlap.
-int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st)
+int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st, hipEvent_t done, bool frames_free)
 {
 	DemodPriv *pv = priv_of(this);
 	if (!pv) return HFDL_GPU_EINVAL;
 	(void)buf;
 	DemodBuffers B;
 	const uint64_t i = launches++;          // per demodulator launch (not per block: channelize-only blocks launch none)
-	if (separate_decode && ev_dec[i & 1]) D_TRY(hipStreamWaitEvent(st, ev_dec[i & 1], 0));      // the decoder of launch i-2 has read this frame queue
+	// the decoder of launch i-2 has read this frame queue.  Every wait or record is a barrier packet of its own in the queue
+	// (~5 us of idle stream each): on the demodulator-bound geometries the caller moves this one to the channelizer's stream
+	if (separate_decode && !frames_free && ev_dec[i & 1]) D_TRY(hipStreamWaitEvent(st, ev_dec[i & 1], 0));
 	B.states = d_states; B.data = (cf *)d_data; B.frames = d_frames + (size_t)(i & 1) * nch; B.counts = d_counts;
 	B.frame_count = d_counts + 4 + (int)(i & 3); B.frame_cap = nch;
 	const bool tw = taps_on && taps_enabled;
 	B.tap_rs = tw ? (cf *)d_tap_rs : nullptr; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
 	B.cap = cap;
-	if (tw) hipLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)nch), dim3(DM_THREADS), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
-	else hipLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)nch), dim3(DM_THREADS), lds_bytes, st, pv->t, B, (const cf *)chan_out, out_count, outs);
+	if (tw) hipExtLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, nullptr, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs);
+	else hipExtLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, nullptr, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs);
 	D_TRY(hipGetLastError());
 	return 0;
 }
@@ -803,8 +809,8 @@ int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const i
 	}
 	DevBuf d_scr, d_fr, d_data, d_counts, d_freqs, d_pdus;
 	int counts[8] = { 0, 0, 0, 0, nframes, 0, 0, 0 };
-	D_TRY(d_scr.alloc(128));
-	D_TRY(hipMemcpy(d_scr.p, h.scrambler, 120, hipMemcpyHostToDevice));
+	D_TRY(d_scr.alloc(DEC_CONST_BYTES));
+	D_TRY(hipMemcpy(d_scr.p, h.scrambler, DEC_CONST_BYTES, hipMemcpyHostToDevice));
 	D_TRY(d_fr.alloc(sizeof(FrameRec) * fr.size()));
 	D_TRY(hipMemcpy(d_fr.p, fr.data(), sizeof(FrameRec) * fr.size(), hipMemcpyHostToDevice));
 	D_TRY(d_data.alloc(sizeof(cf) * data.size()));

@@ -91,6 +91,7 @@ struct DemodConst {
 	uint64_t a_hi, a_lo;
 	const uint64_t *m1_hi, *m1_lo; // [8]
 	const float *corr_tab;         // [128]: 2.0f * m / 127.0f - 1.0f for m matching bits (the reference's expression, src/hfdl.c:781)
+	const float *psk_pts;          // [16][2]: the PSK constellations by linear index (demod_tables.h)
 	int32_t a1_lo, a1_hi, a2_lo, a2_hi, pos_min;      // the A1 / A2 thresholds on corr_tab as match counts (demod_tables.h)
 };
 
@@ -129,18 +130,17 @@ HFDL_HD void chan_state_init(ChanState &st, const float *eq_h0)
 HFDL_FN uint32_t gray_enc(uint32_t b) { return b ^ (b >> 1); }
 HFDL_FN uint32_t gray_dec(uint32_t g) { uint32_t b = g; while (g >>= 1) b ^= g; return b; }
 
-HFDL_FN cf psk_point(int arity, uint32_t sym)
-{
-	cf y;
-	if (arity == 1) { y.x = sym ? -1.0f : 1.0f; y.y = 0.0f; return y; }
-	const uint32_t M = 1u << arity;
-	const float alpha = (float)M_PI / (float)M;
-	const float ang = (float)gray_dec(sym) * 2 * alpha;
-	y.x = cosf(ang); y.y = sinf(ang);
-	return y;
-}
+// The constellation point of LINEAR index lin (modem_modulate_psk of gray_enc(lin)) comes from a 16-entry table made on the
+// host (demod_tables.h psk_pts); `pts(i)` returns entry i -- two v_readlane in the carrier wave, a memory read elsewhere.
+HFDL_FN int psk_entry(int arity, uint32_t lin) { return (1 << arity) - 2 + (int)lin; }
 
-HFDL_FN uint32_t psk_slice(int arity, cf x, float *phase_error)
+struct PskTable {                  // the table in memory (burst decoder, stage entry points, the CPU harness)
+	const float *p;
+	HFDL_FN cf operator()(int i) const { cf y; y.x = p[2 * i]; y.y = p[2 * i + 1]; return y; }
+};
+
+template <class Pts>
+HFDL_FN uint32_t psk_slice(int arity, cf x, float *phase_error, const Pts &pts)
 {
 	uint32_t sym;
 	cf xh;
@@ -161,7 +161,7 @@ HFDL_FN uint32_t psk_slice(int arity, cf x, float *phase_error)
 			if (v > 0) { s |= 1; v -= ref; } else { v += ref; }
 		}
 		sym = gray_enc(s);
-		xh = psk_point(arity, sym);
+		xh = pts(psk_entry(arity, s));             // = modem_modulate_psk(sym): gray_dec(gray_enc(s)) == s
 	}
 	if (phase_error) *phase_error = x.y * xh.x - x.x * xh.y;
 	return sym;
@@ -174,28 +174,30 @@ HFDL_FN uint8_t soft_clamp(float v)
 }
 
 // modem_demodulate_soft: 255 = confident '1', soft[0] = MSB of the symbol
-HFDL_FN void psk_soft(int arity, cf x, uint8_t *soft)
+template <class Pts>
+HFDL_FN void psk_soft(int arity, cf x, uint8_t *soft, const Pts &pts)
 {
 	if (arity == 1) {
 		const float llr = -2.0f * x.x * 4.0f;
 		soft[0] = soft_clamp(llr * 16);
 		return;
 	}
-	const uint32_t sym = psk_slice(arity, x, nullptr);
+	const uint32_t sym = psk_slice(arity, x, nullptr, pts);
 	if (arity == 2) { soft[0] = (sym & 2) ? 255 : 0; soft[1] = (sym & 1) ? 255 : 0; return; }
 	const uint32_t M = 1u << arity;
 	const float gamma = 1.2f * (float)M;
 	float d0[3], d1[3];
-	cf c = psk_point(arity, sym);
+	const uint32_t lin = gray_dec(sym);
+	cf c = pts(psk_entry(arity, lin));
 	float er = x.x - c.x, ei = x.y - c.y;
 	float d = er * er + ei * ei;
 	for (int k = 0; k < arity; k++) {
 		if ((sym >> (arity - k - 1)) & 1) { d0[k] = 4.0f; d1[k] = d; } else { d0[k] = d; d1[k] = 4.0f; }
 	}
-	const uint32_t lin = gray_dec(sym);
 	for (int nb = 0; nb < 2; nb++) {
-		const uint32_t ns = gray_enc((lin + (nb ? 1 : M - 1)) % M);
-		c = psk_point(arity, ns);
+		const uint32_t nl = (lin + (nb ? 1 : M - 1)) % M;
+		const uint32_t ns = gray_enc(nl);
+		c = pts(psk_entry(arity, nl));
 		er = x.x - c.x; ei = x.y - c.y;
 		d = er * er + ei * ei;
 		for (int k = 0; k < arity; k++) {
@@ -356,10 +358,11 @@ HFDL_FN float t_symbol(int idx)          // T = 0x9AF, bit 14 first; BPSK 0 -> +
 }
 
 // everything after the equaliser for one on-time symbol: src/hfdl.c:737-891
-HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, cf sym, float level)
+template <class Pts>
+HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, cf sym, float level, const Pts &pts)
 {
 	float perr;
-	uint32_t bits = psk_slice(s.cur_arity, sym, &perr);
+	uint32_t bits = psk_slice(s.cur_arity, sym, &perr, pts);
 	{   // costas_cccf_adjust, :276-281
 		const float e = 0.5f * (fabsf(perr + 1.0f) - fabsf(perr - 1.0f));
 		s.err = e;

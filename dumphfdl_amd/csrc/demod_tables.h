@@ -9,6 +9,7 @@
 //   bsequence A / M1[8], descrambler LFSR                 src/hfdl.c:300-347,419-459
 #pragma once
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -19,6 +20,8 @@ constexpr int RS_NPFB = 256, RS_TAPS = 14;
 constexpr int SS_NPFB = 16, SS_TAPS = 18;
 constexpr int EQ_TAPS = 15, MF_TAPS = 19;
 
+constexpr int DEC_PSK_OFFSET = 128, DEC_CONST_BYTES = 256;      // burst decoder constants: scrambler bits, then psk_pts
+
 struct DemodTables {
 	float rs_h[RS_NPFB * RS_TAPS];
 	uint32_t rs_step;
@@ -27,13 +30,21 @@ struct DemodTables {
 	float lf_b0, lf_a1, ss_rate_adj;
 	float eq_h0[EQ_TAPS];
 	uint64_t a_hi, a_lo, m1_hi[8], m1_lo[8];
-	uint8_t scrambler[120];
+	// scrambler and constellations are adjacent on purpose: the burst decoder takes ONE pointer (scrambler) and finds the
+	// constellation table DEC_PSK_OFFSET bytes after it
+	uint8_t scrambler[120], scr_pad[8];
+	// the PSK constellations as modem_modulate_psk makes them, cexpjf(s * 2 * pi / M) for the LINEAR (Gray-decoded) index s, entry
+	// (1 << arity) - 2 + s = {re, im}: arity 1 at [0..1], 2 at [2..5], 3 at [6..13].  The slicer re-modulates its decision once
+	// per symbol on the carrier loop's critical path; two v_readlane instead of a sinf + a cosf.
+	float psk_pts[16][2];
 	float corr_tab[128];
 	// the preamble thresholds of src/hfdl.c:42-44 as match counts: |corr_tab[m]| > 0.36 <=> m <= a1_lo or m >= a1_hi (the
 	// table is monotonic in m), same for 0.30 (A2); corr_tab[m] > 0 <=> m >= pos_min.  Derived FROM the fp32 table, so the
 	// integer tests decide exactly as the reference's float comparisons do.
 	int32_t a1_lo, a1_hi, a2_lo, a2_hi, pos_min, thr_pad;
 };
+
+static_assert(offsetof(DemodTables, psk_pts) - offsetof(DemodTables, scrambler) == DEC_PSK_OFFSET, "decoder constants layout");
 
 namespace tables_detail {
 
@@ -154,6 +165,17 @@ inline void build_demod_tables(DemodTables &t, float resamp_rate)
 		if (std::fabs(c) > 0.36f) { if (c < 0.f) t.a1_lo = m; else if (m < t.a1_hi) t.a1_hi = m; }
 		if (std::fabs(c) > 0.3f) { if (c < 0.f) t.a2_lo = m; else if (m < t.a2_hi) t.a2_hi = m; }
 		if (c > 0.f && m < t.pos_min) t.pos_min = m;
+	}
+	// --- PSK constellations, in the modem's own fp32 expressions (alpha = pi / M as float, angle = s * 2 * alpha)
+	t.psk_pts[0][0] = 1.0f; t.psk_pts[1][0] = -1.0f;
+	for (int arity = 2; arity <= 3; arity++) {
+		const uint32_t M = 1u << arity;
+		const float alpha = (float)M_PI / (float)M;
+		for (uint32_t k = 0; k < M; k++) {
+			const float ang = (float)k * 2 * alpha;
+			t.psk_pts[M - 2 + k][0] = cosf(ang);
+			t.psk_pts[M - 2 + k][1] = sinf(ang);
+		}
 	}
 	// --- descrambler: x^15 + x + 1 LFSR, fill 0x4d4b, 120-symbol period
 	{

@@ -146,6 +146,7 @@ struct hfdl_gpu_frontend {
 	uint64_t blocks = 0;
 	FftOutLayout tap_layout;
 	int pending_demod_buf = -1;         // block whose demodulator launch is held back until the next forward FFT is queued
+	bool frames_wait_on_a = false;      // stream A has waited for the frame queue the next demodulator launch reuses
 	hipEvent_t ev_fft = nullptr;
 	uint64_t demod_blocks = 0;          // value of `blocks` after the last block that went through the demodulator
 	int demod_buf = -1;                 // ... and the buffer / snapshot slot it used
@@ -452,9 +453,11 @@ static int launch_demod(hfdl_gpu_frontend *fe, int buf, bool after_fft)
 	// the forward FFT of the next block follows this block's inverse FFT on stream A, so its event covers ev_chan too
 	if (after_fft) HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_fft, 0));
 	else HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
-	int rc = fe->demod.enqueue_demod(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b);
+	// ev_dm rides on the kernel's dispatch; with the decoder on its own stream the channelizer has already waited for the frame
+	// queue (enqueue_channelizer), so on the demodulator-bound geometries ONE barrier packet separates consecutive demodulators
+	int rc = fe->demod.enqueue_demod(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b, fe->ev_dm[buf], fe->frames_wait_on_a);
+	fe->frames_wait_on_a = false;
 	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
-	HIP_TRY(hipEventRecord(fe->ev_dm[buf], fe->stream_b));
 	if (fe->own_decode_stream) HIP_TRY(hipStreamWaitEvent(fe->stream_d, fe->ev_dm[buf], 0));
 	rc = fe->demod.enqueue_decode(buf, fe->stream_d);
 	if (rc) return fail(rc, "burst decoder enqueue failed: %s", hipGetErrorString(hipGetLastError()));
@@ -472,7 +475,7 @@ static int flush_pending_demod(hfdl_gpu_frontend *fe, bool after_fft)
 
 // Stream A runs the channelizer of block k into buffer k&1; stream B demodulates it.  A's inverse FFT may not overwrite
 // a buffer before B has finished with it (two blocks ago); B may not start before A has filled it.
-static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx, int *buf_out)
+static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx, int *buf_out, bool with_demod)
 {
 	const Geometry &g = fe->geo;
 	const int buf = (int)(fe->blocks & 1);
@@ -503,6 +506,13 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
 	}
 	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm[buf], 0));          // chan_out[buf] is free once demod(k-2) has read it
+	if (with_demod && fe->own_decode_stream) {
+		// this block's demodulator (launched right after this kernel, on stream B) reuses the frame queue the decoder of two
+		// launches ago read: wait for it HERE, where the stream has slack, instead of in front of the demodulator
+		hipEvent_t e = fe->demod.frames_free_event();
+		if (e) HIP_TRY(hipStreamWaitEvent(fe->stream, e, 0));
+		fe->frames_wait_on_a = true;
+	}
 	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_ph, fe->d_tw_m, fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream, fe->ev_chan[buf]);
 	HIP_TRY(hipGetLastError());
 	fe->blocks++;
@@ -517,7 +527,7 @@ extern "C" int hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const f
 	int sidx = -1;
 	int rc = stage_input(fe, iq, nsamples, SFMT_CF32, on_device, &fresh, &sidx);
 	if (rc) return rc;
-	return enqueue_channelizer(fe, fresh, SFMT_CF32, sidx, nullptr);
+	return enqueue_channelizer(fe, fresh, SFMT_CF32, sidx, nullptr, false);
 }
 
 static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int fmt, int on_device)
@@ -526,7 +536,7 @@ static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int
 	int buf = 0, sidx = -1;
 	int rc = stage_input(fe, raw, nsamples, fmt, on_device, &fresh, &sidx);
 	if (rc) return rc;
-	if ((rc = enqueue_channelizer(fe, fresh, fmt, sidx, &buf))) return rc;
+	if ((rc = enqueue_channelizer(fe, fresh, fmt, sidx, &buf, true))) return rc;
 	if (fe->own_decode_stream) {
 		// demodulator-bound geometry (few channels): the fold is short, there is nothing to place the demodulator under, and
 		// holding it back until the NEXT block's forward FFT would put that block's host -> device copy on the demodulator's

@@ -267,9 +267,22 @@ static void *frontend_thread(void *ctx)
 			pthread_cond_wait(ring->cond, ring->mutex);
 		}
 		const void *blk = ok ? hfdl_ring_peek(ring->buf, leased * need, need) : NULL;
-		if (ok && blk == NULL) {                    /* a block that wraps around the end of a foreign ring: one copy */
+		if (ok && blk == NULL) {
+			/* a block that wraps around the end of a ring this library did not size: one copy.  The blocks still leased
+			 * to the DMA engine sit in front of it; they go back to the producer first. */
+			while (leased > 0) {
+				pthread_mutex_unlock(ring->mutex);
+				hfdl_gpu_frontend_input_done_upto(fe, k - leased);
+				pthread_mutex_lock(ring->mutex);
+				hfdl_ring_drop(ring->buf, need);
+				leased--;
+			}
 			if (bounce == NULL) bounce = hfdl_xcalloc(need, sizeof(float complex));
-			hfdl_ring_read(ring->buf, bounce, need);
+			if (hfdl_ring_read(ring->buf, bounce, need) != need) {      /* only a cf32 ring can be copied out of */
+				fprintf(stderr, "GPU front end: input ring holds raw samples in blocks that are not contiguous\n");
+				do_exit = 1;
+				ok = 0;
+			}
 		}
 		if (!ok) hfdl_ring_drop(ring->buf, hfdl_ring_size(ring->buf));
 		const bool backlog = hfdl_ring_size(ring->buf) >= (leased + 2) * need || (blk == NULL && hfdl_ring_size(ring->buf) >= need);   /* another whole block is already waiting */
@@ -281,6 +294,7 @@ static void *frontend_thread(void *ctx)
 			fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
 			do_exit = 1;
 			ok = 0;
+			leased = 0;
 			continue;
 		}
 		k++;

@@ -90,7 +90,10 @@ static struct input *file_create(struct input_cfg *cfg)
 
 static void file_destroy(struct input *in)
 {
-	if (in) free(container_of(in, struct file_input, input));
+	if (in == NULL) return;
+	struct file_input *fi = container_of(in, struct file_input, input);
+	if (fi->fd >= 0 && fi->fd != STDIN_FILENO) close(fi->fd);      /* opened by init, thread never ran */
+	free(fi);
 }
 
 static int32_t file_init(struct input *in)
@@ -273,19 +276,26 @@ static void file_loop_converting(struct input *in, struct file_input *fi, struct
 	float complex *conv = hfdl_xcalloc(bufsize / (size_t)in->bytes_per_sample, sizeof(float complex));
 	size_t len;
 	int loops_left = g_file_loops;
-	do {
+	for (;;) {
 		len = read_fully(fi->fd, raw, bufsize);
-		if (len < bufsize && fi->seekable && --loops_left > 0) { lseek(fi->fd, 0, SEEK_SET); if (len == 0) continue; }
-		for (;;) {              /* back-pressure: poll for ring space, 100 ms naps (src/input-file.c:53-61) */
-			pthread_mutex_lock(cb->mutex);
-			size_t room = hfdl_ring_space_available(cb->buf);
-			pthread_mutex_unlock(cb->mutex);
-			if (room * (size_t)in->bytes_per_sample >= len) break;
-			usleep(100000);
+		bool at_end = len < bufsize;                 /* fread() is short only at end of input */
+		if (len > 0) {
+			for (;;) {          /* back-pressure: poll for ring space, 100 ms naps (src/input-file.c:53-61) */
+				pthread_mutex_lock(cb->mutex);
+				size_t room = hfdl_ring_space_available(cb->buf);
+				pthread_mutex_unlock(cb->mutex);
+				if (room * (size_t)in->bytes_per_sample >= len || do_exit) break;
+				usleep(100000);
+			}
+			in->convert_sample_buffer(in, raw, len, conv);
+			complex_samples_produce(cb, conv, len / (size_t)in->bytes_per_sample);
 		}
-		in->convert_sample_buffer(in, raw, len, conv);
-		complex_samples_produce(cb, conv, len / (size_t)in->bytes_per_sample);
-	} while (len > 0 && do_exit == 0);
+		if (do_exit) break;
+		if (at_end) {
+			if (!fi->seekable || --loops_left <= 0) break;
+			if (lseek(fi->fd, 0, SEEK_SET) != 0) break;     /* --loop: replay the file from the start */
+		}
+	}
 	free(raw);
 	free(conv);
 }

@@ -60,6 +60,7 @@ int    hfdl_ring_is_pinned(const struct hfdl_ring *r) { return r->pinned; }
 static size_t ring_write_bytes(struct hfdl_ring *r, const void *src, size_t n)
 {
 	if (n > r->cap - r->count) n = r->cap - r->count;
+	if (n == 0) return 0;                          /* full, or a ring of capacity 0 */
 	size_t tail = (r->head + r->count) % r->cap;
 	size_t first = n < r->cap - tail ? n : r->cap - tail;
 	memcpy(r->data + tail * r->elem, src, first * r->elem);
@@ -78,6 +79,7 @@ size_t hfdl_ring_read(struct hfdl_ring *r, float complex *dst, size_t n)
 {
 	if (r->elem != sizeof(float complex)) return 0;
 	if (n > r->count) n = r->count;
+	if (n == 0) return 0;
 	size_t first = n < r->cap - r->head ? n : r->cap - r->head;
 	memcpy(dst, r->data + r->head * r->elem, first * r->elem);
 	memcpy(dst + first, r->data, (n - first) * r->elem);
@@ -129,6 +131,7 @@ const void *hfdl_ring_peek(const struct hfdl_ring *r, size_t offset, size_t n)
 size_t hfdl_ring_drop(struct hfdl_ring *r, size_t n)
 {
 	if (n > r->count) n = r->count;
+	if (n == 0) return 0;
 	r->head = (r->head + n) % r->cap;
 	r->count -= n;
 	return n;

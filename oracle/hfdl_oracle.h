@@ -101,6 +101,8 @@ void    orc_deinterleave_maps(int mode, int32_t *push_pos, int32_t *pop_pos);
 int32_t orc_decode_user_data(int mode, const orc_cf *symbols, int bitmask_lsb, uint8_t *octets);
 /* liquid modem soft demod restatement (a16) */
 void    orc_modem_demod_soft(int arity, orc_cf x, uint8_t *soft);
+orc_cf  orc_modem_modulate(int arity, uint32_t sym);                 /* modem_modulate_psk: cexpjf(gray_decode(sym) * 2 * pi / M) */
+uint32_t orc_modem_demod_hard(int arity, orc_cf x, float *phase_error);
 uint32_t orc_modem_demod_hard(int arity, orc_cf x, float *phase_error);
 orc_cf  orc_modem_modulate(int arity, uint32_t sym);
 

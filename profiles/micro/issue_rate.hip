@@ -21,7 +21,7 @@ __global__ void k(unsigned long long *out, float seed)
 	t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[1] = t1 - t0;
 	// (2) dependent s_add_u32 chain
 	t0 = __builtin_amdgcn_s_memtime();
-	for (int i = 0; i < 4096; i++) { REP64(asm volatile("s_add_u32 %0, %0, 1" : "+s"(si));) }
+	for (int i = 0; i < 4096; i++) { REP64(asm volatile("s_add_u32 %0, %0, 1" : "+s"(si) : : "scc");) }
 	t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[2] = t1 - t0;
 	// (3) v_readlane -> v_mov (VALU -> SGPR -> VALU ping-pong, dependent)
 	t0 = __builtin_amdgcn_s_memtime();
@@ -42,18 +42,33 @@ __global__ void k(unsigned long long *out, float seed)
 	t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[6] = t1 - t0;      // 16 round trips per iteration
 	// (7) alternating SALU / VALU independent
 	t0 = __builtin_amdgcn_s_memtime();
-	for (int i = 0; i < 4096; i++) { REP16(asm volatile("s_add_u32 %1, %1, 1\n v_add_f32 %0, %0, %0\n s_add_u32 %1, %1, 1\n v_add_f32 %2, %2, %2" : "+v"(a), "+s"(si), "+v"(b));) }
+	for (int i = 0; i < 4096; i++) { REP16(asm volatile("s_add_u32 %1, %1, 1\n v_add_f32 %0, %0, %0\n s_add_u32 %1, %1, 1\n v_add_f32 %2, %2, %2" : "+v"(a), "+s"(si), "+v"(b) : : "scc");) }
 	t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[7] = t1 - t0;
+	// (8) taken forward scalar branch over one instruction: s_cmp + s_cbranch_scc1 (2 instructions issued per group)
+	t0 = __builtin_amdgcn_s_memtime();
+	for (int i = 0; i < 4096; i++) { REP16(asm volatile("s_cmp_eq_u32 %0, %0\n s_cbranch_scc1 1f\n v_add_f32 %1, %1, %1\n1:\n v_add_f32 %2, %2, %2\n s_add_u32 %0, %0, 1" : "+s"(si), "+v"(a), "+v"(b) : : "scc");) }
+	t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[9] = t1 - t0;      // 16 groups of 4 issued instructions
+	// (9) the same with the branch NOT taken (5 instructions issued per group)
+	t0 = __builtin_amdgcn_s_memtime();
+	for (int i = 0; i < 4096; i++) { REP16(asm volatile("s_cmp_lg_u32 %0, %0\n s_cbranch_scc1 1f\n v_add_f32 %1, %1, %1\n1:\n v_add_f32 %2, %2, %2\n s_add_u32 %0, %0, 1" : "+s"(si), "+v"(a), "+v"(b) : : "scc");) }
+	t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[10] = t1 - t0;
+	// (10) the branch-free form of the same choice: v_cmp + v_cndmask on the value (4 instructions)
+	t0 = __builtin_amdgcn_s_memtime();
+	for (int i = 0; i < 4096; i++) { REP16(asm volatile("v_add_f32 %3, %1, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cndmask_b32 %1, %1, %3, vcc\n v_add_f32 %2, %2, %2" : "+s"(si), "+v"(a), "+v"(b), "+v"(c) : : "vcc");) }
+	t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[11] = t1 - t0;
 	if (threadIdx.x == 0) { int sv; asm volatile("v_mov_b32 %0, %1" : "=v"(sv) : "s"(si)); out[8] = (unsigned long long)(a + b + c + d) + (unsigned)sv; }
 }
 int main()
 {
-	unsigned long long *d, h[9];
+	unsigned long long *d, h[12];
 	(void)hipMalloc(&d, sizeof(h));
 	for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d, 1.0f); (void)hipDeviceSynchronize(); }
 	(void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
 	const char *names[8] = { "dependent v_add_f32", "4 independent v_add_f32 chains", "dependent s_add_u32", "v_readlane -> s_nop 3 -> v_mov -> v_add (4 instr group)",
 		"dependent DPP adds with s_nop 1 (per pair of instr)", "dependent v_sin_f32", "LDS write->read round trip (per trip, /16)", "alternating independent SALU / VALU" };
 	for (int i = 0; i < 8; i++) printf("%-62s %8.2f cycles per instruction (s_memtime ticks)\n", names[i], (double)h[i] / (4096.0 * (i == 6 ? 16 : 64)));
+	printf("%-62s %8.2f cycles per group (cmp, branch taken over 1 instr, v_add, s_add)\n", "taken forward s_cbranch_scc1", (double)h[9] / (4096.0 * 16));
+	printf("%-62s %8.2f cycles per group (cmp, branch not taken, 2 v_add, s_add)\n", "not-taken s_cbranch_scc1", (double)h[10] / (4096.0 * 16));
+	printf("%-62s %8.2f cycles per group (v_add, v_cmp, v_cndmask, v_add)\n", "branch-free select", (double)h[11] / (4096.0 * 16));
 	return 0;
 }

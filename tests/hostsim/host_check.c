@@ -39,8 +39,9 @@ static int check_ring(void)
 	return 0;
 }
 
-static int check_file(const char *path, const char *fmt, int bufsize, const char *out_path)
+static int check_file(const char *path, const char *fmt, int bufsize, const char *out_path, int loops)
 {
+	hfdl_file_input_set_loops(loops);
 	struct input_cfg *cfg = input_cfg_create();
 	cfg->type = INPUT_TYPE_FILE;
 	cfg->source = (char *)path;
@@ -233,7 +234,7 @@ int main(int argc, char **argv)
 {
 	int rc = 99;
 	if (argc >= 2 && !strcmp(argv[1], "ring")) rc = check_ring();
-	else if (argc >= 6 && !strcmp(argv[1], "file")) rc = check_file(argv[2], argv[3], atoi(argv[4]), argv[5]);
+	else if (argc >= 6 && !strcmp(argv[1], "file")) rc = check_file(argv[2], argv[3], atoi(argv[4]), argv[5], argc >= 7 ? atoi(argv[6]) : 1);
 	else if (argc >= 2 && !strcmp(argv[1], "graph")) rc = check_graph();
 	else if (argc >= 2 && !strcmp(argv[1], "plugin")) rc = check_plugin();
 	else if (argc >= 6 && !strcmp(argv[1], "direct")) rc = check_direct(argv[2], argv[3], argv[4], atoi(argv[5]));

@@ -42,7 +42,7 @@ Sim *sim_create(float resamp_rate, int cap)
 	s->K.ss_mf = s->tab.ss_mf; s->K.ss_dmf = s->tab.ss_dmf;
 	s->K.lf_b0 = s->tab.lf_b0; s->K.lf_a1 = s->tab.lf_a1; s->K.ss_rate_adj = s->tab.ss_rate_adj;
 	s->K.eq_h0 = s->tab.eq_h0; s->K.a_hi = s->tab.a_hi; s->K.a_lo = s->tab.a_lo;
-	s->K.m1_hi = s->tab.m1_hi; s->K.m1_lo = s->tab.m1_lo; s->K.corr_tab = s->tab.corr_tab;
+	s->K.m1_hi = s->tab.m1_hi; s->K.m1_lo = s->tab.m1_lo; s->K.corr_tab = s->tab.corr_tab; s->K.psk_pts = &s->tab.psk_pts[0][0];
 	s->K.a1_lo = s->tab.a1_lo; s->K.a1_hi = s->tab.a1_hi; s->K.a2_lo = s->tab.a2_lo; s->K.a2_hi = s->tab.a2_hi; s->K.pos_min = s->tab.pos_min;
 	chan_state_init(s->st, s->tab.eq_h0);
 	s->cap = cap;
@@ -83,7 +83,14 @@ int sim_taps(Sim *s, float *rs, float *mf, float *sym, float *lvl, int *counts)
 	return 0;
 }
 
-void sim_psk_soft(int arity, float re, float im, uint8_t *soft) { cf x; x.x = re; x.y = im; psk_soft(arity, x, soft); }
+void sim_psk_soft(int arity, float re, float im, uint8_t *soft)
+{
+	static DemodTables tab;
+	static bool made = false;
+	if (!made) { build_demod_tables(tab, 0.6912f); made = true; }
+	cf x; x.x = re; x.y = im;
+	psk_soft(arity, x, soft, PskTable{&tab.psk_pts[0][0]});
+}
 
 int sim_pdu_triage(const uint8_t *buf, uint32_t len, int *kind, uint32_t *hdr_len) { return pdu_triage(buf, len, kind, hdr_len); }
 

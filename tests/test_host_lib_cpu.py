@@ -59,6 +59,20 @@ def test_file_input_conversion(host_check, tmp_path, fmt, bufsize):
     assert ("max_tu %d " % (bufsize // {"CF32": 8, "CS16": 4, "CU8": 2}[fmt])) in out.stdout
 
 
+@pytest.mark.parametrize("n", [5 * 1024, 30011])
+def test_file_input_converting_loop_replays(host_check, tmp_path, n):
+    """--loop through the converting reader (a cs16 file in front of a cf32 ring): the file is replayed from the start, also
+    when its length is a whole number of read buffers (the read that hits end of file then returns nothing)."""
+    raw = np.random.default_rng(4).integers(-32768, 32768, 2 * n).astype(np.int16)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.cf32"
+    raw.tofile(src)
+    out = subprocess.run([host_check, "file", str(src), "CS16", "4096", str(dst), "3"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    got = np.fromfile(dst, np.complex64)
+    want = np.tile((raw.astype(np.float32) / np.float32(32767.5)).view(np.complex64), 3)
+    assert len(got) == len(want) and np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("fmt,loops", [("CS16", 1), ("CU8", 1), ("CF32", 1), ("CS16", 3)])
 def test_file_input_direct_into_frontend_ring(host_check, tmp_path, fmt, loops):
     """In front of the GPU front-end block the ring carries the file's RAW samples (the device converts them), is a whole

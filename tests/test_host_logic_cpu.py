@@ -111,7 +111,7 @@ def test_demod_tables_match_oracle(sim, oracle):
         _fields_ = [("rs_h", C.c_float * (256 * 14)), ("rs_step", C.c_uint32), ("mf", C.c_float * 19),
                     ("ss_mf", C.c_float * 288), ("ss_dmf", C.c_float * 288), ("lf_b0", C.c_float), ("lf_a1", C.c_float),
                     ("ss_rate_adj", C.c_float), ("eq_h0", C.c_float * 15), ("a_hi", C.c_uint64), ("a_lo", C.c_uint64),
-                    ("m1_hi", C.c_uint64 * 8), ("m1_lo", C.c_uint64 * 8), ("scrambler", C.c_uint8 * 120),
+                    ("m1_hi", C.c_uint64 * 8), ("m1_lo", C.c_uint64 * 8), ("scrambler", C.c_uint8 * 120), ("scr_pad", C.c_uint8 * 8), ("psk_pts", C.c_float * 32),
                     ("corr_tab", C.c_float * 128), ("a1_lo", C.c_int32), ("a1_hi", C.c_int32), ("a2_lo", C.c_int32),
                     ("a2_hi", C.c_int32), ("pos_min", C.c_int32), ("thr_pad", C.c_int32)]
     sim.sim_sizeof_tables.restype = C.c_size_t
@@ -133,6 +133,16 @@ def test_demod_tables_match_oracle(sim, oracle):
     sb = np.zeros(120, np.uint8)
     oracle.lib().orc_scrambler_bits(sb.ctypes.data, 120)
     assert bytes(t.scrambler) == bytes(sb)
+    # the constellation table = the oracle's modem_modulate_psk of every symbol, by linear (Gray-decoded) index
+    class CF(C.Structure):
+        _fields_ = [("re", C.c_float), ("im", C.c_float)]
+    oracle.lib().orc_modem_modulate.restype = CF
+    oracle.lib().orc_modem_modulate.argtypes = [C.c_int, C.c_uint32]
+    pts = np.frombuffer(t.psk_pts, np.float32).reshape(16, 2)
+    for arity in (1, 2, 3):
+        for lin in range(1 << arity):
+            p = oracle.lib().orc_modem_modulate(arity, lin ^ (lin >> 1))
+            assert (np.float32(p.re), np.float32(p.im)) == tuple(pts[(1 << arity) - 2 + lin]), (arity, lin)
     m = np.arange(128, dtype=np.float32)
     corr = np.float32(2.0) * m / np.float32(127) - np.float32(1.0)
     assert np.array_equal(np.frombuffer(t.corr_tab, np.float32), corr)
