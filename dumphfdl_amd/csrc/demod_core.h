@@ -55,6 +55,16 @@ __device__ __forceinline__ float row_scan_sum(float v)
 	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));
 	return __int_as_float(x);
 }
+// inclusive scan-max inside every 16-lane row (lanes shifted in from outside the row read 0, so the result is max(0, ...))
+__device__ __forceinline__ float row_scan_max(float v)
+{
+	int x = __float_as_int(v);
+	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true))));
+	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true))));
+	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true))));
+	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true))));
+	return __int_as_float(x);
+}
 // x / 3.0f, correctly rounded, without the IEEE division sequence (12 instructions on the timing loop's output path): reciprocal
 // multiply plus one FMA residual correction (Markstein); checked against true division over 6e4 random floats
 __device__ __forceinline__ float div3(float x)
@@ -235,9 +245,37 @@ struct CarrierRegs {
 	float px, py;                  // lane i < 16: PSK constellation entry i (demod_tables.h psk_pts)
 };
 
-struct PskLanes {                  // the constellation table held across the lanes of the carrier wave
-	float px, py;
-	__device__ __forceinline__ cf operator()(int i) const { cf y; y.x = lane_value(px, i); y.y = lane_value(py, i); return y; }
+// The carrier wave's slicer.  modem_demodulate_psk takes arg(x), subtracts pi (1 - 1/M) and walks a binary reference ladder:
+// that IS the nearest constellation point by angle, i.e. the point with the largest Re(x conj(p)).  Here every lane of row 0
+// holds one point of the table (demod_tables.h psk_pts): one multiply-add per lane, a row max, a compare -- instead of atan2f
+// and the ladder (~45 instructions of the carrier loop's per-symbol critical path).  Decisions can differ from the atan2f form
+// only when x is within rounding of a decision boundary, exactly as two atan2f implementations differ from each other; what
+// leaves this function into the loop is the phase error against the chosen point.  (The decoded bits of data symbols come from
+// the burst decoder's own soft de-mapper, which keeps the reference's arg() form.)
+struct LaneSlicer {
+	float px, py;                  // lane i < 16: table entry i
+	int lane;
+	__device__ __forceinline__ uint32_t operator()(int arity, cf x, float *phase_error) const
+	{
+		uint32_t sym;
+		cf xh;
+		if (arity == 1) {
+			sym = (x.x > 0) ? 0 : 1;
+			xh.x = sym ? -1.0f : 1.0f; xh.y = 0.0f;
+		} else {
+			const int M = 1 << arity, base = M - 2;
+			const bool mine = lane >= base && lane < base + M;
+			const float d = mine ? x.x * px + x.y * py : -1.0f;
+			const float best = lane_value(row_scan_max(d), 15);        // >= 0: some point is within 90 degrees of x
+			const unsigned long long hit = __ballot(mine && d == best);
+			int win = hit ? (int)__builtin_ctzll(hit) : base;           // NaN input: no lane compares equal
+			const uint32_t lin = (uint32_t)(win - base);
+			sym = lin ^ (lin >> 1);
+			xh.x = lane_value(px, win); xh.y = lane_value(py, win);
+		}
+		if (phase_error) *phase_error = x.y * xh.x - x.x * xh.y;
+		return sym;
+	}
 };
 
 __device__ __forceinline__ void carrier_load(CarrierRegs &c, const ChanScalars &s, const ChanArrays &a, const DemodConst &T, int lane)
@@ -343,7 +381,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				}
 				if (TAPS && lane == 0) io.tap_symbols[nsym] = y;
 				nsym++;
-				on_symbol(s, a, T, io, y, level, PskLanes{c.px, c.py});
+				on_symbol(s, a, T, io, y, level, LaneSlicer{c.px, c.py, lane});
 				runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
 			}
 			if (__builtin_expect((s.ev_flags & EV_EQ_RESET) != 0, 0)) {      // eqlms_cccf_reset ran (framer reset): mirror it in the register window

@@ -173,6 +173,11 @@ HFDL_FN uint8_t soft_clamp(float v)
 	return (uint8_t)(s > 255 ? 255 : (s < 0 ? 0 : s));
 }
 
+struct TableSlicer {               // psk_slice() with the table in memory, as on_symbol()'s slicer
+	const float *p;
+	HFDL_FN uint32_t operator()(int arity, cf x, float *phase_error) const { return psk_slice(arity, x, phase_error, PskTable{p}); }
+};
+
 // modem_demodulate_soft: 255 = confident '1', soft[0] = MSB of the symbol
 template <class Pts>
 HFDL_FN void psk_soft(int arity, cf x, uint8_t *soft, const Pts &pts)
@@ -358,11 +363,13 @@ HFDL_FN float t_symbol(int idx)          // T = 0x9AF, bit 14 first; BPSK 0 -> +
 }
 
 // everything after the equaliser for one on-time symbol: src/hfdl.c:737-891
-template <class Pts>
-HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, cf sym, float level, const Pts &pts)
+// `slice(arity, x, &phase_error)` = modem_demodulate + the demodulator phase error (psk_slice() above, or the carrier wave's
+// lane-parallel form of the same decision)
+template <class Slicer>
+HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, cf sym, float level, const Slicer &slice)
 {
 	float perr;
-	uint32_t bits = psk_slice(s.cur_arity, sym, &perr, pts);
+	uint32_t bits = slice(s.cur_arity, sym, &perr);
 	{   // costas_cccf_adjust, :276-281
 		const float e = 0.5f * (fabsf(perr + 1.0f) - fabsf(perr - 1.0f));
 		s.err = e;
