@@ -120,6 +120,9 @@ struct hfdl_gpu_frontend {
 	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
 	hipEvent_t ev_stage_ready[2] = { nullptr, nullptr }, ev_stage_free[2] = { nullptr, nullptr };
 	uint64_t host_blocks = 0;
+	hipEvent_t ev_copy[4] = { nullptr, nullptr, nullptr, nullptr };   // copy of host block j done (j & 3): what input_done_upto() waits for
+	const void *prefetched = nullptr;   // host pointer whose copy hfdl_gpu_frontend_prefetch_block_raw() already queued ...
+	int prefetched_sb = -1, prefetched_fmt = 0;      // ... into this staging buffer, from this sample format
 	int last_buf = 0;
 	int32_t sample_rate = 0, centerfreq = 0, decimation = 0;
 	float tbw = 0;
@@ -162,7 +165,7 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamSynchronize(fe->stream_d);
 	if (fe->stream_c) (void)hipStreamSynchronize(fe->stream_c);
 	for (int i = 0; i < 2; i++)
-		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_dm[i], fe->ev_stage_ready[i], fe->ev_stage_free[i] }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_dm[i], fe->ev_stage_ready[i], fe->ev_stage_free[i], fe->ev_copy[i], fe->ev_copy[i + 2] }) if (e) (void)hipEventDestroy(e);
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	if (fe->ev_fft) (void)hipEventDestroy(fe->ev_fft);
 	if (fe->ev_first_fold) (void)hipEventDestroy(fe->ev_first_fold);
@@ -302,6 +305,8 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	for (int i = 0; i < 2; i++) {
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_ready[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_free[i], hipEventDisableTiming));
+		FE_TRY(hipEventCreateWithFlags(&fe->ev_copy[i], hipEventDisableTiming));
+		FE_TRY(hipEventCreateWithFlags(&fe->ev_copy[i + 2], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_chan[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_demod[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_dm[i], hipEventDisableTiming));
@@ -411,6 +416,29 @@ extern "C" void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe) { return fe ? (
 
 static size_t sample_bytes(int fmt) { return fmt == SFMT_CS16 ? 4 : fmt == SFMT_CU8 ? 2 : 8; }
 
+// queue the host -> device copy of the next host block on stream C into staging buffer (host_blocks & 1)
+static int queue_input_copy(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, int fmt, int *sb_out)
+{
+	const uint64_t j = fe->host_blocks++;
+	const int sb = (int)(j & 1);
+	if (fe->stage_cap[sb] < nsamples) {
+		HIP_TRY(hipStreamSynchronize(fe->stream));
+		if (fe->d_stage[sb]) (void)hipFree(fe->d_stage[sb]);
+		fe->d_stage[sb] = nullptr; fe->stage_cap[sb] = 0;
+		HIP_TRY(hipMalloc(&fe->d_stage[sb], sizeof(float2) * nsamples));
+		fe->stage_cap[sb] = nsamples;
+	}
+	HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_stage_free[sb], 0));     // stream A finished reading this buffer two blocks ago
+	HIP_TRY(hipMemcpyAsync(fe->d_stage[sb], iq, sample_bytes(fmt) * nsamples, hipMemcpyHostToDevice, fe->stream_c));
+	HIP_TRY(hipEventRecord(fe->ev_stage_ready[sb], fe->stream_c));
+	HIP_TRY(hipEventRecord(fe->ev_copy[j & 3], fe->stream_c));
+	// a buffer this library did not allocate may be reused by the caller as soon as we return (include/hfdl_gpu.h): do not
+	// rely on the runtime staging pageable memory synchronously -- wait for the copy (the kernels of the previous block keep running)
+	if (!is_library_pinned(iq, sample_bytes(fmt) * nsamples)) HIP_TRY(hipStreamSynchronize(fe->stream_c));
+	*sb_out = sb;
+	return 0;
+}
+
 // Host input is double-buffered in HBM: the copy of block k+1 (stream C) runs while block k computes (stream A).
 // *stage_idx = staging buffer used (-1 for device input): the caller records ev_stage_free once stream A has read it.
 static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, int fmt, int on_device, const void **dev, int *stage_idx)
@@ -422,20 +450,16 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 		return fail(HFDL_GPU_EINVAL, "a block is exactly %d samples (got %zu)", fe->plan.input_size, nsamples);
 	HIP_TRY(hipSetDevice(fe->device));
 	if (on_device) { *dev = iq; return 0; }
-	const int sb = (int)(fe->host_blocks++ & 1);
-	if (fe->stage_cap[sb] < nsamples) {
-		HIP_TRY(hipStreamSynchronize(fe->stream));
-		if (fe->d_stage[sb]) (void)hipFree(fe->d_stage[sb]);
-		fe->d_stage[sb] = nullptr; fe->stage_cap[sb] = 0;
-		HIP_TRY(hipMalloc(&fe->d_stage[sb], sizeof(float2) * nsamples));
-		fe->stage_cap[sb] = nsamples;
+	int sb;
+	if (fe->prefetched != nullptr) {
+		// the copy of this block was queued ahead by hfdl_gpu_frontend_prefetch_block_raw()
+		if (fe->prefetched != iq || fe->prefetched_fmt != fmt) return fail(HFDL_GPU_EINVAL, "the block pushed after a prefetch must be the prefetched one");
+		sb = fe->prefetched_sb;
+		fe->prefetched = nullptr;
+	} else {
+		int rc = queue_input_copy(fe, iq, nsamples, fmt, &sb);
+		if (rc) return rc;
 	}
-	HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_stage_free[sb], 0));     // stream A finished reading this buffer two blocks ago
-	HIP_TRY(hipMemcpyAsync(fe->d_stage[sb], iq, sample_bytes(fmt) * nsamples, hipMemcpyHostToDevice, fe->stream_c));
-	HIP_TRY(hipEventRecord(fe->ev_stage_ready[sb], fe->stream_c));
-	// a buffer this library did not allocate may be reused by the caller as soon as we return (include/hfdl_gpu.h): do not
-	// rely on the runtime staging pageable memory synchronously -- wait for the copy (the kernels of the previous block keep running)
-	if (!is_library_pinned(iq, sample_bytes(fmt) * nsamples)) HIP_TRY(hipStreamSynchronize(fe->stream_c));
 	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_stage_ready[sb], 0));
 	*dev = fe->d_stage[sb];
 	*stage_idx = sb;
@@ -606,10 +630,28 @@ extern "C" int hfdl_gpu_frontend_input_done_upto(hfdl_gpu_frontend *fe, uint64_t
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	if (host_block >= fe->host_blocks) return fail(HFDL_GPU_EINVAL, "host block %llu has not been pushed (%llu so far)", (unsigned long long)host_block, (unsigned long long)fe->host_blocks);
-	// the copy of host block j signals ev_stage_ready[j & 1]; an event re-recorded by a later block implies the earlier copy is done
-	if (host_block + 2 < fe->host_blocks) return 0;
+	// The copy of host block j signals ev_copy[j & 3].  Copies run in order on one stream, so for a block more than three behind
+	// the newest (its event has been re-recorded since) the oldest event still its own block's implies it.
+	const uint64_t newest = fe->host_blocks - 1;
+	const uint64_t j = newest - host_block <= 3 ? host_block : newest - 3;
 	HIP_TRY(hipSetDevice(fe->device));
-	HIP_TRY(hipEventSynchronize(fe->ev_stage_ready[host_block & 1]));
+	HIP_TRY(hipEventSynchronize(fe->ev_copy[j & 3]));
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_prefetch_block_raw(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int sample_format)
+{
+	if (!fe || !raw) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (sample_format != SFMT_CF32 && sample_format != SFMT_CS16 && sample_format != SFMT_CU8) return fail(HFDL_GPU_EINVAL, "unknown sample format %d", sample_format);
+	if (nsamples != (size_t)fe->plan.input_size)
+		return fail(HFDL_GPU_EINVAL, "a block is exactly %d samples (got %zu)", fe->plan.input_size, nsamples);
+	if (fe->prefetched != nullptr) return fail(HFDL_GPU_EINVAL, "one block can be prefetched at a time");
+	if (!is_library_pinned(raw, sample_bytes(sample_format) * nsamples)) return fail(HFDL_GPU_EINVAL, "only buffers from hfdl_gpu_host_alloc() can be prefetched");
+	HIP_TRY(hipSetDevice(fe->device));
+	int sb = -1;
+	int rc = queue_input_copy(fe, raw, nsamples, sample_format, &sb);
+	if (rc) return rc;
+	fe->prefetched = raw; fe->prefetched_sb = sb; fe->prefetched_fmt = sample_format;
 	return 0;
 }
 

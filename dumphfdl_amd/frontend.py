@@ -60,7 +60,7 @@ EXPORTS = [
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_input_done_upto", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
-    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk",
+    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk", "hfdl_gpu_frontend_prefetch_block_raw",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
 
@@ -115,6 +115,7 @@ def load():
     L.hfdl_gpu_crc16_ccitt.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint16, C.POINTER(C.c_uint16)]
     L.hfdl_gpu_pdu_triage.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hfdl_gpu_lpdu_walk.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.hfdl_gpu_frontend_prefetch_block_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     _lib = L
     return L
 
@@ -195,8 +196,15 @@ class Frontend:
         """ptr: address of a (page-locked) host buffer holding one block; valid until input_done() / sync()."""
         _check(load().hfdl_gpu_frontend_push_block_raw(self._h, C.c_void_p(ptr), self.geometry.input_size, sample_format, 0))
 
+    def prefetch_host_ptr(self, ptr, sample_format=SFMT_CF32):
+        """Queue the copy of the block that push_host_ptr(ptr, sample_format) will push next."""
+        _check(load().hfdl_gpu_frontend_prefetch_block_raw(self._h, C.c_void_p(ptr), self.geometry.input_size, sample_format))
+
     def input_done(self):
         _check(load().hfdl_gpu_frontend_input_done(self._h))
+
+    def input_done_upto(self, host_block):
+        _check(load().hfdl_gpu_frontend_input_done_upto(self._h, C.c_uint64(host_block)))
 
     def sync(self):
         _check(load().hfdl_gpu_frontend_sync(self._h))

@@ -257,22 +257,26 @@ static void *frontend_thread(void *ctx)
 	uint64_t k = 0, npdus = 0;
 	double t_first = 0, t_last = 0, t_published = 0;
 	double s_wait = 0, s_push = 0, s_poll = 0, s_release = 0;      /* where this thread's time went (seconds) */
-	size_t leased = 0;                       /* blocks handed to the GPU whose ring slots are not released yet (0..2), oldest first */
+	size_t leased = 0;                       /* ring slots the GPU may still read (0..3), oldest first: pushed blocks, then a prefetched one */
+	bool prefetched = false;                 /* the newest leased slot has been uploaded ahead (prefetch) but not pushed yet */
+	uint64_t uploads = 0;                    /* host blocks whose copy has been queued, as the GPU library numbers them */
 	for (;;) {
 		const double tw0 = now_s();
+		const size_t pushed_leases = leased - (prefetched ? 1 : 0);
 		pthread_mutex_lock(ring->mutex);
 		/* shutdown is honoured only when there is not a whole block left, so buffered samples are flushed (src/fft.c:39-48) */
-		while (hfdl_ring_size(ring->buf) < (leased + 1) * need) {
+		while (hfdl_ring_size(ring->buf) < (pushed_leases + 1) * need) {
 			if (block_connection_is_shutdown_signaled(block->consumer.in)) { pthread_mutex_unlock(ring->mutex); goto shutdown; }
 			pthread_cond_wait(ring->cond, ring->mutex);
 		}
-		const void *blk = ok ? hfdl_ring_peek(ring->buf, leased * need, need) : NULL;
+		const void *blk = ok ? hfdl_ring_peek(ring->buf, pushed_leases * need, need) : NULL;
 		if (ok && blk == NULL) {
 			/* a block that wraps around the end of a ring this library did not size: one copy.  The blocks still leased
-			 * to the DMA engine sit in front of it; they go back to the producer first. */
+			 * to the DMA engine sit in front of it; they go back to the producer first.  (Never with a prefetch pending: a
+			 * prefetched block was peeked as one contiguous run.) */
 			while (leased > 0) {
 				pthread_mutex_unlock(ring->mutex);
-				hfdl_gpu_frontend_input_done_upto(fe, k - leased);
+				hfdl_gpu_frontend_input_done_upto(fe, uploads - leased);
 				pthread_mutex_lock(ring->mutex);
 				hfdl_ring_drop(ring->buf, need);
 				leased--;
@@ -285,7 +289,9 @@ static void *frontend_thread(void *ctx)
 			}
 		}
 		if (!ok) hfdl_ring_drop(ring->buf, hfdl_ring_size(ring->buf));
-		const bool backlog = hfdl_ring_size(ring->buf) >= (leased + 2) * need || (blk == NULL && hfdl_ring_size(ring->buf) >= need);   /* another whole block is already waiting */
+		/* another whole block is already waiting behind this one: we are behind the source */
+		const bool backlog = hfdl_ring_size(ring->buf) >= (pushed_leases + 2) * need || (blk == NULL && hfdl_ring_size(ring->buf) >= need);
+		const void *next = (ok && blk != NULL && backlog) ? hfdl_ring_peek(ring->buf, (pushed_leases + 1) * need, need) : NULL;
 		pthread_mutex_unlock(ring->mutex);
 		if (!ok) continue;
 		const double tw1 = now_s();
@@ -295,10 +301,16 @@ static void *frontend_thread(void *ctx)
 			do_exit = 1;
 			ok = 0;
 			leased = 0;
+			prefetched = false;
 			continue;
 		}
 		k++;
-		if (blk != NULL) leased++;
+		if (prefetched) prefetched = false;      /* its slot was leased when the copy was queued */
+		else { uploads++; if (blk != NULL) leased++; }
+		/* Behind the source: queue the upload of the FOLLOWING block now, so that it runs beside the blocks still computing
+		 * instead of at the head of that block's own copy -> channelizer -> demodulator chain (on small geometries that chain
+		 * is longer than one demodulator, and with two blocks in flight the GPU would idle on it). */
+		if (next != NULL && hfdl_gpu_frontend_prefetch_block_raw(fe, next, need, gfmt) == 0) { prefetched = true; uploads++; leased++; }
 		const double tw2 = now_s();
 		s_push += tw2 - tw1;
 		/* Keeping up with the source (live radio): wait for this block and deliver its PDUs at once.  Behind (file
@@ -312,11 +324,12 @@ static void *frontend_thread(void *ctx)
 		} while (n == max_pdus);
 		const double tw3 = now_s();
 		s_poll += tw3 - tw2;
-		/* Ring slots go back to the producer when the DMA engine has read them.  Two blocks are leased at most: with a
-		 * backlog the copy of the block just pushed is NOT waited for -- only the one before it (done long ago), so the copy
-		 * engine never idles on this thread; without a backlog the pipeline was drained above and both are free. */
-		while (leased > (backlog ? 1u : 0u)) {
-			hfdl_gpu_frontend_input_done_upto(fe, k - leased);          /* the oldest leased block, as the GPU library numbers host blocks */
+		/* Ring slots go back to the producer when the DMA engine has read them.  With a backlog the copies of the block just
+		 * pushed and of the prefetched one are NOT waited for -- only older ones (done long ago), so the copy engine never
+		 * idles on this thread; without a backlog the pipeline was drained above and everything is free. */
+		const size_t keep = backlog ? (prefetched ? 2u : 1u) : 0u;
+		while (leased > keep) {
+			hfdl_gpu_frontend_input_done_upto(fe, uploads - leased);    /* the oldest leased block, as the GPU library numbers host blocks */
 			pthread_mutex_lock(ring->mutex);
 			hfdl_ring_drop(ring->buf, need);
 			pthread_mutex_unlock(ring->mutex);

@@ -126,6 +126,12 @@ int  hfdl_gpu_frontend_input_done(hfdl_gpu_frontend *fe);
  * waiting for the blocks pushed after it: a caller that leases two page-locked buffers pushes block k+1, then waits for block k and
  * reuses its buffer -- the copy engine never idles on the host thread */
 int  hfdl_gpu_frontend_input_done_upto(hfdl_gpu_frontend *fe, uint64_t host_block);
+/* Queue the host -> device copy of the block that will be pushed NEXT (a buffer from hfdl_gpu_host_alloc(), host pointer) without
+ * pushing it: the copy then runs beside the blocks still computing, and the following hfdl_gpu_frontend_push_block_raw() of the
+ * same pointer and format only queues kernels.  On small geometries (7 MB blocks) copy + channelizer of a block take longer than
+ * one demodulator; with the copy taken off that chain two blocks in flight keep the GPU busy.  The prefetched block counts as a
+ * host block for hfdl_gpu_frontend_input_done_upto() from this call on.  One block at a time; pushing anything else next is EINVAL. */
+int  hfdl_gpu_frontend_prefetch_block_raw(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int sample_format);
 /* Same, for raw recorder / SDR samples converted on the device inside the overlap-assembly load of the forward FFT
  * (convert_cs16 / convert_cu8 / convert_cf32, src/input-helpers.c:10-78): interleaved I,Q int16 (full scale 32767.5),
  * uint8 (offset 63.5, full scale 127) or float32.  Halves / quarters the host->device bytes per sample. */

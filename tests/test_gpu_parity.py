@@ -584,6 +584,53 @@ def test_collect_without_draining_the_pipeline(gpu, oracle, monkeypatch, ring):
     fe.close()
 
 
+def test_prefetched_uploads_same_pdus(gpu, oracle):
+    """hfdl_gpu_frontend_prefetch_block_raw: the upload of block k+1 is queued while block k is pushed (page-locked buffer,
+    cs16 converted on the device), slots are released through input_done_upto() with three host blocks outstanding.  Same
+    PDUs as the oracle fed the same quantised samples; misuse (another pointer pushed after a prefetch, a second prefetch, a
+    buffer that is not page-locked) is EINVAL and leaves the front end usable."""
+    import ctypes
+    fs, cf = 250000, 10_000_000
+    freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000]
+    dur = 10.0
+    bursts = synth.plan_traffic(freqs, dur, seed=41, dense=True, gap_s=0.15, amp=(0.03, 0.1))
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.01, seed=41)
+    raw = np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16)
+    xq = (raw.astype(np.float32) / np.float32(32767.5)).view(np.complex64)          # convert_cs16, src/input-helpers.c:56-66
+    fe = gpu.Frontend(fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs)
+    n = fe.input_size
+    nb = len(x) // n
+    hbuf = gpu.host_alloc(raw.nbytes)
+    ctypes.memmove(hbuf, raw.ctypes.data, raw.nbytes)
+    ptr = lambda b: hbuf + 4 * b * n
+    got = []
+    fe.prefetch_host_ptr(ptr(0), F.SFMT_CS16)
+    with pytest.raises(gpu.GpuError):
+        fe.prefetch_host_ptr(ptr(1), F.SFMT_CS16)                       # one at a time
+    with pytest.raises(gpu.GpuError):
+        fe.push_host_ptr(ptr(1), F.SFMT_CS16)                           # not the prefetched block
+    for b in range(nb):
+        fe.push_host_ptr(ptr(b), F.SFMT_CS16)
+        if b + 1 < nb:
+            fe.prefetch_host_ptr(ptr(b + 1), F.SFMT_CS16)
+        if b >= 1:
+            fe.input_done_upto(b - 1)                                   # three host blocks outstanding: b-1, b, b+1
+        got += fe.poll_pdus(max_in_flight=1)
+        ora.push_block(xq[b * n:(b + 1) * n])
+    got += fe.poll_pdus()
+    with pytest.raises(gpu.GpuError):
+        fe.input_done_upto(nb)                                          # never uploaded
+    fe.input_done_upto(0)                                               # long overwritten events: still answers
+    pageable = np.zeros(2 * n, np.int16)
+    with pytest.raises(gpu.GpuError):
+        fe.prefetch_host_ptr(pageable.ctypes.data, F.SFMT_CS16)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, ora.pdus)) and len(got) >= len(bursts) - 1
+    fe.close()
+    gpu.host_free(hbuf)
+
+
 def test_full_pdu_ring_drops_and_counts(gpu, oracle, monkeypatch):
     """More frames finishing in one block than the device ring holds: the surplus is dropped and counted, what is
     delivered is intact, and the ring keeps working afterwards."""
