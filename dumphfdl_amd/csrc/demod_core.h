@@ -241,7 +241,7 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 // ---------------- wave 2: carrier loop, equaliser, slicer, framer (src/hfdl.c:709-891) ----------------
 
 struct CarrierRegs {
-	float eu, ev, ex2, ewx, ewy;   // equaliser: lane t < 15 of rows 0 and 1 = tap t (0 oldest); row 0 holds (x, y), row 1 (y, -x)
+	float eu, ev, ex2, ewx, ewy;   // equaliser: lane 1 + t (t < 15) of rows 0 and 1 = tap t (0 oldest); row 0 holds (x, y), row 1 (y, -x)
 	float px, py;                  // lane i < 16: PSK constellation entry i (demod_tables.h psk_pts)
 };
 
@@ -282,8 +282,8 @@ __device__ __forceinline__ void carrier_load(CarrierRegs &c, const ChanScalars &
 {
 	c.px = lane < 16 ? T.psk_pts[2 * lane] : 0.f;
 	c.py = lane < 16 ? T.psk_pts[2 * lane + 1] : 0.f;
-	const int t = lane & 15;
-	const bool act = t < D_EQ && lane < 32, row1 = (lane >> 4) & 1;
+	const int t = (lane & 15) - 1;                 // the window sits in lanes 1..15 of a row: a push is ONE row shift whose vacated lane 15 takes the new sample
+	const bool act = t >= 0 && lane < 32, row1 = (lane >> 4) & 1;
 	int j = s.eq_head + t; if (j >= D_EQ) j -= D_EQ;
 	const cf e = act ? a.eq_buf[j] : cf{0.f, 0.f};
 	c.eu = row1 ? e.y : e.x;
@@ -295,11 +295,11 @@ __device__ __forceinline__ void carrier_load(CarrierRegs &c, const ChanScalars &
 
 __device__ __forceinline__ void carrier_store(const CarrierRegs &c, ChanArrays &a, int lane)
 {
-	if (lane < D_EQ) {
+	if (lane >= 1 && lane <= D_EQ) {
 		cf e; e.x = c.eu; e.y = c.ev;
-		a.eq_buf[lane] = e; a.eq_x2[lane] = c.ex2;
+		a.eq_buf[lane - 1] = e; a.eq_x2[lane - 1] = c.ex2;
 		cf w; w.x = c.ewx; w.y = c.ewy;
-		a.eq_w[lane] = w;
+		a.eq_w[lane - 1] = w;
 	}
 }
 
@@ -309,8 +309,8 @@ template <bool TAPS>
 __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, const DemodShared &sh,
 		int k0, int k1, int &nsym, int lane)
 {
-	const int t = lane & 15;
-	const bool row1 = (lane >> 4) & 1, act = t < D_EQ && lane < 32, ins = t == D_EQ;
+	const int t = (lane & 15) - 1;
+	const bool row1 = (lane >> 4) & 1, act = t >= 0 && lane < 32;
 	// the chunk's levels, output counts and (up to 64) timing-recovery outputs, one per lane: the loop below takes them with
 	// v_readlane instead of a dependent LDS round trip per sample
 	const float lv_l = (k0 + lane < k1) ? io.lvl[k0 + lane] : 0.f;
@@ -349,15 +349,14 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				symsync_reset(s, a);
 				runaway = false;
 			}
-			// eqlms_cccf_push: park the new sample in lane 15 of the row, then shift the row down one lane
+			// eqlms_cccf_push: the row moves down one lane and lane 15, which has no source inside the row, takes the new sample
 			{
 				const float x2n = r.x * r.x + r.y * r.y;
-				const float x2o = lane_value(c.ex2, 0);
+				const float x2o = lane_value(c.ex2, 1);
 				const float nu = row1 ? r.y : r.x, nv = row1 ? -r.x : r.y;
-				const float su = ins ? nu : c.eu, sv = ins ? nv : c.ev, sx = ins ? x2n : c.ex2;
-				c.eu = dpp_row_shl1(su, su);         // lane 15 of a row (outside the 15-tap window) keeps the parked sample: don't care
-				c.ev = dpp_row_shl1(sv, sv);
-				c.ex2 = dpp_row_shl1(sx, sx);
+				c.eu = dpp_row_shl1(nu, c.eu);
+				c.ev = dpp_row_shl1(nv, c.ev);
+				c.ex2 = dpp_row_shl1(x2n, c.ex2);
 				s.eq_x2sum = s.eq_x2sum + x2n - x2o;
 				s.eq_count++;
 			}
@@ -386,7 +385,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 			}
 			if (__builtin_expect((s.ev_flags & EV_EQ_RESET) != 0, 0)) {      // eqlms_cccf_reset ran (framer reset): mirror it in the register window
 				c.eu = 0.f; c.ev = 0.f; c.ex2 = 0.f;
-				c.ewx = act ? T.eq_h0[t < D_EQ ? t : 0] : 0.f; c.ewy = 0.f;
+				c.ewx = act ? T.eq_h0[t >= 0 ? t : 0] : 0.f; c.ewy = 0.f;
 				s.ev_flags &= ~(uint32_t)EV_EQ_RESET;
 			}
 		}
