@@ -54,6 +54,7 @@ struct Demod {
 int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out, double *kernel_ms = nullptr);
 int demod_crc16(const uint8_t *data, uint32_t len, uint16_t crc_init, uint16_t *crc);
 int demod_pdu_triage_batch(const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride, uint8_t *fcs_status, uint8_t *kind, uint16_t *hdr_len);
+int demod_psk_slice_batch(int arity, const float *xy, int32_t n, uint32_t *sym, float *phase_error);
 int demod_lpdu_walk_batch(const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride, uint8_t *counts);
 int demod_burst_decode_batch(const float *symbols, const int32_t *modes, const int32_t *bitmask_lsb, int32_t nframes,
 		uint8_t *octets, int32_t *lens, double *kernel_ms = nullptr);

@@ -470,6 +470,27 @@ __global__ void pdu_triage_kernel(const uint8_t *__restrict__ octets, const int3
 	hdr_len[i] = (uint16_t)hl;
 }
 
+// the carrier wave's slicer (demod_core.h LaneSlicer) on its own: every wave walks its share of the symbols one at a time, the
+// way the carrier loop meets them (the symbol is wave-uniform, the constellation sits one point per lane)
+__global__ __launch_bounds__(64) void psk_slice_kernel(int arity, const cf *__restrict__ x, int n, const float *__restrict__ pts, uint32_t *__restrict__ sym, float *__restrict__ perr)
+{
+	const int lane = (int)threadIdx.x;
+	const LaneSlicer slice{lane < 16 ? pts[2 * lane] : 0.f, lane < 16 ? pts[2 * lane + 1] : 0.f, lane};
+	const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x, i0 = (int)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+	for (int base = i0; base < i1; base += 64) {
+		const cf mine = base + lane < i1 ? x[base + lane] : cf{0.f, 0.f};
+		uint32_t s_l = 0;
+		float e_l = 0.f;
+		for (int k = 0; k < 64 && base + k < i1; k++) {
+			cf v; v.x = lane_value(mine.x, k); v.y = lane_value(mine.y, k);
+			float e;
+			const uint32_t sy = slice(arity, v, &e);
+			if (lane == k) { s_l = sy; e_l = e; }
+		}
+		if (base + lane < i1) { sym[base + lane] = s_l; perr[base + lane] = e_l; }
+	}
+}
+
 __global__ void lpdu_walk_kernel(const uint8_t *__restrict__ octets, const int32_t *__restrict__ lens, int npdus, int stride, uint8_t *__restrict__ counts)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -768,6 +789,26 @@ int demod_pdu_triage_batch(const uint8_t *octets, const int32_t *lens, int32_t n
 	D_TRY(hipMemcpy(fcs_status, d_fcs.p, n, hipMemcpyDeviceToHost));
 	D_TRY(hipMemcpy(kind, d_kind.p, n, hipMemcpyDeviceToHost));
 	D_TRY(hipMemcpy(hdr_len, d_hl.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int demod_psk_slice_batch(int arity, const float *xy, int32_t n, uint32_t *sym, float *phase_error)
+{
+	DemodTables h;
+	build_demod_tables(h, 0.6912f);
+	DevBuf d_x, d_pts, d_sym, d_err;
+	D_TRY(d_x.alloc(sizeof(cf) * (size_t)n));
+	D_TRY(d_pts.alloc(sizeof(h.psk_pts)));
+	D_TRY(d_sym.alloc(sizeof(uint32_t) * (size_t)n));
+	D_TRY(d_err.alloc(sizeof(float) * (size_t)n));
+	D_TRY(hipMemcpy(d_x.p, xy, sizeof(cf) * (size_t)n, hipMemcpyHostToDevice));
+	D_TRY(hipMemcpy(d_pts.p, h.psk_pts, sizeof(h.psk_pts), hipMemcpyHostToDevice));
+	const int waves = n < 64 * 256 ? (n + 63) / 64 : 256;
+	hipLaunchKernelGGL(psk_slice_kernel, dim3((unsigned)waves), dim3(64), 0, nullptr, arity, d_x.as<const cf>(), n, d_pts.as<const float>(), d_sym.as<uint32_t>(), d_err.as<float>());
+	D_TRY(hipDeviceSynchronize());
+	D_TRY(hipGetLastError());
+	D_TRY(hipMemcpy(sym, d_sym.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+	D_TRY(hipMemcpy(phase_error, d_err.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
 	return 0;
 }
 

@@ -942,3 +942,14 @@ extern "C" int hfdl_gpu_lpdu_walk(int device, const uint8_t *octets, const int32
 	if (rc) return fail(rc, "lpdu walk failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;
 }
+
+extern "C" int hfdl_gpu_psk_slice(int device, int32_t arity, const float *xy, int32_t n, uint32_t *sym, float *phase_error)
+{
+	if (!xy || !sym || !phase_error || n <= 0) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	if (arity < 1 || arity > 3) return fail(HFDL_GPU_EINVAL, "arity %d: HFDL uses BPSK, QPSK and 8-PSK (1..3 bits per symbol)", arity);
+	int rc = select_device(device);
+	if (rc) return rc;
+	rc = demod_psk_slice_batch(arity, xy, n, sym, phase_error);
+	if (rc) return fail(rc, "psk slice failed: %s", hipGetErrorString(hipGetLastError()));
+	return 0;
+}

@@ -60,7 +60,7 @@ EXPORTS = [
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_input_done_upto", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
-    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk", "hfdl_gpu_frontend_prefetch_block_raw",
+    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk", "hfdl_gpu_frontend_prefetch_block_raw", "hfdl_gpu_psk_slice",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
 
@@ -115,6 +115,7 @@ def load():
     L.hfdl_gpu_crc16_ccitt.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint16, C.POINTER(C.c_uint16)]
     L.hfdl_gpu_pdu_triage.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hfdl_gpu_lpdu_walk.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.hfdl_gpu_psk_slice.argtypes = [C.c_int, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.hfdl_gpu_frontend_prefetch_block_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     _lib = L
     return L
@@ -370,3 +371,12 @@ def lpdu_walk(pdus, device=0):
     counts = np.zeros((n, 5), np.uint8)
     _check(load().hfdl_gpu_lpdu_walk(device, _p(octets), _p(lens), n, stride, _p(counts)))
     return [tuple(int(v) for v in counts[i]) for i in range(n)]
+
+
+def psk_slice(arity, symbols, device=0):
+    """symbols: complex64 array -> (Gray-coded decisions uint32, phase errors float32) from the carrier loop's slicer."""
+    x = np.ascontiguousarray(symbols, dtype=np.complex64)
+    sym = np.zeros(len(x), np.uint32)
+    err = np.zeros(len(x), np.float32)
+    _check(load().hfdl_gpu_psk_slice(device, arity, _p(x), len(x), _p(sym), _p(err)))
+    return sym, err

@@ -19,6 +19,7 @@
  *   decimating_shift_addition_init / _cc           src/libcsdr_gpl.h:43-44, src/libcsdr_gpl.c:26-74 -> hfdl_gpu_nco_decimate
  *   crc16_ccitt                                    src/crc.h, src/crc.c:4-47            -> hfdl_gpu_crc16_ccitt
  *   hfdl_pdu_fcs_check + header length rules       src/pdu.c:68-79, src/mpdu.c:56-79, src/spdu.c:55-62 -> hfdl_gpu_pdu_triage
+ *   modem_demodulate + phase error (liquid PSK)    src/hfdl.c:737-741                   -> hfdl_gpu_psk_slice (the carrier loop's slicer)
  *   parse_lpdu_list + lpdu_parse's FCS check       src/mpdu.c:92-158, src/lpdu.c:136-149 -> hfdl_gpu_lpdu_walk (and hfdl_gpu_pdu.lpdus_*)
  *
  * All functions return 0 on success or a negative HFDL_GPU_E* code (the reference's constructors
@@ -236,6 +237,12 @@ int  hfdl_gpu_pdu_triage(int device, const uint8_t *octets, const int32_t *lens,
 /* the LPDU list walk of `npdus` PDUs (must be MPDUs or SPDUs as they come out of the decoder): counts[i * 5 + 0..4] = lpdus processed,
  * good, bad FCS, too short, truncated flag -- zeros when the header triage of PDU i is not "FCS good" */
 int  hfdl_gpu_lpdu_walk(int device, const uint8_t *octets, const int32_t *lens, int32_t npdus, int32_t stride, uint8_t *counts);
+
+/* The carrier loop's slicer on `n` equalised symbols (interleaved re, im): modem_demodulate of liquid's PSK modem (arity 1..3 bits
+ * per symbol: the Gray-coded symbol) and its demodulator phase error Im(x conj(x_hat)), src/hfdl.c:737-741.  The device decides by
+ * the nearest constellation point (largest Re(x conj(p))), which is what arg() + the reference ladder computes; the two can differ
+ * only for x within rounding of a decision boundary. */
+int  hfdl_gpu_psk_slice(int device, int32_t arity, const float *xy, int32_t n, uint32_t *sym, float *phase_error);
 
 /* kernel time in ms of the last hfdl_gpu_fft_forward / _viterbi27 / _burst_decode call made by this thread (HIP events
  * around the launch; allocation and host <-> device copies excluded) */

@@ -234,6 +234,21 @@ def pdu_triage(octets):
     return st, kind.value, hl.value
 
 
+def modem_demod_hard(arity, symbols):
+    """liquid's modem_demodulate + get_demodulator_phase_error as restated (fec_restated.c): (symbols uint32, phase errors float32)."""
+    L = lib()
+    L.orc_modem_demod_hard.restype = C.c_uint32
+    L.orc_modem_demod_hard.argtypes = [C.c_int, Cf, C.POINTER(C.c_float)]
+    x = np.ascontiguousarray(symbols, dtype=np.complex64)
+    sym = np.zeros(len(x), np.uint32)
+    err = np.zeros(len(x), np.float32)
+    e = C.c_float(0)
+    for i, v in enumerate(x):
+        sym[i] = L.orc_modem_demod_hard(arity, Cf(float(v.real), float(v.imag)), C.byref(e))
+        err[i] = e.value
+    return sym, err
+
+
 def lpdu_walk(octets):
     """(processed, good, bad_fcs, too_short, truncated) of the PDU's LPDU list."""
     a = np.frombuffer(bytes(octets), np.uint8).copy()
