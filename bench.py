@@ -17,6 +17,8 @@ The JSON line carries, next to the driver's contract fields:
                   PCIe-inclusive, never `value`
   host_path       the same workload through the C host library (file input -> block graph -> GPU front end ->
                   pdu_decoder_queue_push), i.e. what a dumphfdl user gets (dumphfdl_amd/hfdl_replay --bench)
+  pdus_*          every PDU of the timed region is checked against the sent traffic: payload + mode, on-device header FCS,
+                  and the device's LPDU walk (every announced LPDU found with a good FCS; the traffic carries real LPDU lists)
   fec             trellis steps/s: demanded by the run, and the burst decoder's own capacity on a resident batch
   parity          same-run gate: the channels the CPU baseline decodes, decoded by the GPU from the same blocks --
                   channelizer error RMS / signal RMS and the (freq, sample_index, mode, octets) multisets
@@ -80,11 +82,30 @@ def make_input(w, geom_input_size, rank, world, shard_mode="streams"):
     return x, bursts
 
 
+def make_payload(rng, mode):
+    """What a burst carries: an SPDU (half of the 66-octet frames) or an MPDU with a REAL LPDU list -- down- or uplink, every
+    LPDU ending in its own FCS -- so that the device's LPDU walk (hfdl_gpu_pdu.lpdus_*) has something to count and the run can
+    check it.  Returns (octets, LPDUs sent or None for an SPDU)."""
+    from dumphfdl_amd import synth
+    n = synth.mode_sizes(mode)["max_payload"]
+    if n == 66 and rng.random() < 0.5:
+        return synth.make_spdu(rng), None
+    octets, cnt = synth.make_mpdu_with_lpdus(rng, n, uplink=bool(rng.random() < 0.25))
+    return octets, cnt
+
+
 def plan_bursts(w, freqs, dur, seed):
     """The traffic of a workload: one single-slot burst per channel, or (dense) as many back-to-back bursts as fit."""
     from dumphfdl_amd import synth
     rng = np.random.default_rng(seed)
     bursts = []
+
+    def burst(f, mode, t0):
+        octets, lpdus = make_payload(rng, mode)
+        return dict(freq=f, mode=mode, octets=octets, lpdus=lpdus, t0=t0,
+                    amp=float(rng.uniform(0.01, 0.03)),        # ~19..29 dB in-channel SNR
+                    cfo=float(rng.uniform(-15, 15)))
+
     for i, f in enumerate(freqs):
         if w.get("dense"):
             # as many bursts as fit the resident stretch, modes cycling 0..7 from a per-channel offset
@@ -97,16 +118,13 @@ def plan_bursts(w, freqs, dur, seed):
                         k += 4
                         continue
                     break
-                bursts.append(dict(freq=f, mode=mode, octets=synth.make_pdu(rng, mode), t0=t,
-                                   amp=float(rng.uniform(0.01, 0.03)), cfo=float(rng.uniform(-15, 15))))
+                bursts.append(burst(f, mode, t))
                 t += length + float(rng.uniform(0.05, 0.15))
                 k += 1
             continue
         mode = i % 4
         t0 = float(rng.uniform(0.02, max(0.03, dur - synth.burst_symbols_len(mode) / 1800 - 0.05)))
-        bursts.append(dict(freq=f, mode=mode, octets=synth.make_pdu(rng, mode), t0=t0,
-                           amp=float(rng.uniform(0.01, 0.03)),        # ~19..29 dB in-channel SNR
-                           cfo=float(rng.uniform(-15, 15))))
+        bursts.append(burst(f, mode, t0))
     return bursts
 
 
@@ -116,6 +134,15 @@ def pdu_key(p):
 
 def matches_sent(p, bursts_by_freq):
     return any(p["octets"][:len(b["octets"])] == b["octets"] and p["mode"] == b["mode"] for b in bursts_by_freq.get(p["freq"], ()))
+
+
+def lpdu_walk_matches_sent(p, bursts_by_freq):
+    """The device's LPDU walk of this PDU = what was put on the air: every announced LPDU found with a good FCS (none for an SPDU)."""
+    for b in bursts_by_freq.get(p["freq"], ()):
+        if p["octets"][:len(b["octets"])] == b["octets"] and p["mode"] == b["mode"]:
+            want = (0, 0, 0, 0, 0) if b.get("lpdus") is None else (b["lpdus"], b["lpdus"], 0, 0, 0)
+            return tuple(p["lpdus"]) == want
+    return False
 
 
 def probe_cpu_libs():
@@ -422,12 +449,14 @@ def main():
     period_ms = fe.step_period_ms()
     barrier()
     good = sum(1 for p in pdus if matches_sent(p, bursts_by_freq))
+    lpdu_ok = sum(1 for p in pdus if lpdu_walk_matches_sent(p, bursts_by_freq))
+    lpdus_good = sum(p["lpdus"][1] for p in pdus)
     trellis = sum(NBITS[p["mode"]] for p in pdus)
     my_samples = args.steps * g.input_size
     if args.shard == "channels" and rank != 0:
         my_samples = 0                               # ONE stream: its samples count once
     elapsed_max, total_samples, total_pdus = shard.reduce_job(elapsed, my_samples, npdus, dist, device=red_device)
-    total_good, total_trellis = shard.reduce_sums([good, trellis], dist, device=red_device)
+    total_good, total_trellis, total_lpdu_ok, total_lpdus = shard.reduce_sums([good, trellis, lpdu_ok, lpdus_good], dist, device=red_device)
     seeds = shard.gather_ints(my_seed, dist, device=red_device)
     if args.dump_pdus:
         json.dump(sorted(pdu_key(p) for p in pdus), open("%s.rank%d.json" % (args.dump_pdus, rank), "w"))
@@ -475,6 +504,8 @@ def main():
                        "stream_seeds": seeds, "shard": args.shard, "parallelism": par},
             "frames_per_s": total_pdus / elapsed_max, "pdus_in_timed_region": total_pdus,
             "pdus_matching_sent_payload": total_good,
+            "pdus_lpdu_walk_matching_sent": total_lpdu_ok,      # device-side parse_lpdu_list + per-LPDU FCS = what was sent
+            "lpdus_good_on_device": total_lpdus,
             "pdus_rank0_fcs_good_on_device": sum(1 for p in pdus if p["fcs_status"] == 0),
             # fill / drain kept visible at any --steps: the steady-state period comes from the fold launches' own start events
             "steady_state_ms_per_step": period_ms,
