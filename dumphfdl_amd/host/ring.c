@@ -122,7 +122,7 @@ void hfdl_ring_discard_partial(struct hfdl_ring *r) { r->carry = 0; }
  * there or wrap around the end of the storage (never, when capacity and every read are multiples of the same block size) */
 const void *hfdl_ring_peek(const struct hfdl_ring *r, size_t offset, size_t n)
 {
-	if (offset + n > r->count) return NULL;
+	if (offset + n > r->count || r->cap == 0) return NULL;
 	size_t at = (r->head + offset) % r->cap;
 	if (at + n > r->cap) return NULL;
 	return r->data + at * r->elem;

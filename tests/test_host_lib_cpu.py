@@ -107,3 +107,94 @@ def test_planner_abi_without_device():
         (8388608, 4096, 7340032, 3584, 512, 1792)
     with pytest.raises(hf.GpuError):
         hf.plan_geometry(0, 0.001)
+
+
+def test_ring_against_a_model(host_check):
+    """The sample ring (classic cf32 and raw-sample forms) driven through random sequences of its operations -- copying
+    writes / reads, in-place producer (acquire / commit with partial samples carried over), in-place consumer (peek / drop) --
+    against a byte-FIFO model: sizes, contents and the contiguity contract of peek() hold after every step."""
+    import ctypes as C
+    from hypothesis import given, settings, strategies as st
+    L = C.CDLL(os.path.join(PKG, "libhfdl_host.so"))
+    L.hfdl_ring_create_ex.restype = C.c_void_p
+    L.hfdl_ring_create_ex.argtypes = [C.c_size_t, C.c_int, C.c_int]
+    L.hfdl_ring_destroy.argtypes = [C.c_void_p]
+    for name in ("hfdl_ring_size", "hfdl_ring_space_available", "hfdl_ring_capacity", "hfdl_ring_elem_size"):
+        getattr(L, name).restype = C.c_size_t
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.hfdl_ring_write.restype = C.c_size_t
+    L.hfdl_ring_write.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.hfdl_ring_read.restype = C.c_size_t
+    L.hfdl_ring_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.hfdl_ring_write_acquire.restype = C.c_size_t
+    L.hfdl_ring_write_acquire.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.hfdl_ring_write_commit.restype = C.c_size_t
+    L.hfdl_ring_write_commit.argtypes = [C.c_void_p, C.c_size_t]
+    L.hfdl_ring_discard_partial.argtypes = [C.c_void_p]
+    L.hfdl_ring_peek.restype = C.c_void_p
+    L.hfdl_ring_peek.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+    L.hfdl_ring_drop.restype = C.c_size_t
+    L.hfdl_ring_drop.argtypes = [C.c_void_p, C.c_size_t]
+    SFMT = {2: 1, 4: 2, 8: 3}                                    # element bytes -> sample_format (CU8, CS16, CF32)
+    op = st.tuples(st.sampled_from(["write", "read", "fill", "peek", "drop", "discard"]), st.integers(0, 40), st.integers(0, 7))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.sampled_from([2, 4, 8]), st.integers(0, 24), st.lists(op, max_size=60), st.randoms(use_true_random=False))
+    def run(elem, cap, ops, rnd):
+        r = L.hfdl_ring_create_ex(cap, SFMT[elem], 0)
+        assert L.hfdl_ring_capacity(r) == cap and L.hfdl_ring_elem_size(r) == elem
+        model = bytearray()                                    # whole samples readable
+        carry = bytearray()                                    # bytes of an incomplete sample behind them
+        fresh = lambda n: bytes(rnd.getrandbits(8) for _ in range(n))
+        for kind, n, frag in ops:
+            if kind == "write":                                # copying producer: cf32 rings only, a raw ring refuses it
+                if carry:
+                    continue                                   # (mixing it with a pending in-place fragment is not a supported use)
+                data = fresh(n * elem)
+                took = L.hfdl_ring_write(r, data, n)
+                assert took == (min(n, cap - len(model) // elem) if elem == 8 else 0)
+                model += data[:took * elem]
+            elif kind == "read":
+                buf = C.create_string_buffer(max(1, n * elem))
+                got = L.hfdl_ring_read(r, buf, n)
+                if elem == 8:
+                    assert got == min(n, len(model) // elem) and buf.raw[:got * elem] == bytes(model[:got * elem])
+                    del model[:got * elem]
+                else:
+                    assert got == 0
+            elif kind == "fill":                               # in-place producer: some bytes, possibly ending mid-sample
+                ptr = C.c_void_p()
+                room = L.hfdl_ring_write_acquire(r, C.byref(ptr))
+                free_samples = cap - len(model) // elem
+                assert (room == 0) == (free_samples == 0)
+                if room:
+                    assert 0 < room <= free_samples * elem - len(carry)
+                    nbytes = min(room, n * elem + frag % elem)
+                    data = fresh(nbytes)
+                    C.memmove(ptr.value, data, nbytes)
+                    made = L.hfdl_ring_write_commit(r, nbytes)
+                    carry += data
+                    whole = len(carry) // elem
+                    assert made == whole
+                    model += carry[:whole * elem]
+                    del carry[:whole * elem]
+            elif kind == "peek":
+                avail = len(model) // elem
+                off = n % (avail + 1)
+                cnt = frag % (avail - off + 1)
+                p = L.hfdl_ring_peek(r, off, cnt)
+                if p:                                            # contiguous: exactly the model's bytes
+                    assert C.string_at(p, cnt * elem) == bytes(model[off * elem:(off + cnt) * elem])
+                assert L.hfdl_ring_peek(r, avail, 1) is None     # never beyond what is readable
+            elif kind == "drop":
+                got = L.hfdl_ring_drop(r, n)
+                assert got == min(n, len(model) // elem)
+                del model[:got * elem]
+            else:
+                L.hfdl_ring_discard_partial(r)
+                carry.clear()
+            assert L.hfdl_ring_size(r) == len(model) // elem
+            assert L.hfdl_ring_space_available(r) == cap - len(model) // elem
+        L.hfdl_ring_destroy(r)
+
+    run()
