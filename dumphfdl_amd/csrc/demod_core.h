@@ -380,7 +380,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				}
 				if (TAPS && lane == 0) io.tap_symbols[nsym] = y;
 				nsym++;
-				on_symbol(s, a, T, io, y, level, LaneSlicer{c.px, c.py, lane});
+				on_symbol(s, *sh.S, a, T, io, y, level, LaneSlicer{c.px, c.py, lane});
 				runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
 			}
 			if (__builtin_expect((s.ev_flags & EV_EQ_RESET) != 0, 0)) {      // eqlms_cccf_reset ran (framer reset): mirror it in the register window
@@ -511,16 +511,13 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 			S.eq_x2sum = s3.eq_x2sum; S.eq_count = s3.eq_count; S.eq_full = s3.eq_full; S.eq_head = 0;
 			S.bits_hi = s3.bits_hi; S.bits_lo = s3.bits_lo;
 			S.training_n = s3.training_n; S.data_n = s3.data_n; S.use_data = s3.use_data; S.data_slot = s3.data_slot;
-			S.symbol_cnt = s3.symbol_cnt; S.sample_cnt = s3.sample_cnt; S.pdu_sample_index = s3.pdu_sample_index;
-			S.s_state = s3.s_state; S.fr_state = s3.fr_state; S.data_arity = s3.data_arity; S.cur_arity = s3.cur_arity;
-			S.symbols_wanted = s3.symbols_wanted; S.search_retries = s3.search_retries;
-			S.eq_train_seq_cnt = s3.eq_train_seq_cnt; S.data_segment_cnt = s3.data_segment_cnt;
-			S.train_total = s3.train_total; S.train_bad = s3.train_bad; S.T_idx = s3.T_idx; S.M1 = s3.M1;
+			S.symbol_cnt = s3.symbol_cnt; S.sample_cnt = s3.sample_cnt;
+			S.s_state = s3.s_state; S.fr_state = s3.fr_state; S.cur_arity = s3.cur_arity;
+			S.symbols_wanted = s3.symbols_wanted; S.T_idx = s3.T_idx;
 			S.bitmask = s3.bitmask; S.symsync_out_idx = s3.symsync_out_idx; S.nf_clk = s3.nf_clk;
-			S.frame_symbol_cnt = s3.frame_symbol_cnt; S.freq_err_hz = s3.freq_err_hz; S.signal_level = s3.signal_level;
+			S.frame_symbol_cnt = s3.frame_symbol_cnt; S.signal_level = s3.signal_level;
 			S.noise_floor = s3.noise_floor;
-			S.cnt_a2_found = s3.cnt_a2_found; S.cnt_m1_found = s3.cnt_m1_found; S.cnt_m1_not_found = s3.cnt_m1_not_found;
-			S.cnt_frames = s3.cnt_frames;
+			// (the fields only the framer's rare transitions touch were updated in place: on_symbol()'s `c`)
 			S.ev_flags = 0;
 			if (TAPS) io.tap_counts[1] = nsym;
 		}

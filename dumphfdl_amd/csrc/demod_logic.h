@@ -334,13 +334,14 @@ HFDL_FN void eq_reset(ChanScalars &s, ChanArrays &a, const float *eq_h0)
 	s.ev_flags |= EV_EQ_RESET;
 }
 
-HFDL_FN void framer_reset(ChanScalars &s, ChanArrays &a, const float *eq_h0)      // src/hfdl.c:968-991
+// `c`: where the fields only the framer's rare transitions touch live (see on_symbol)
+HFDL_FN void framer_reset(ChanScalars &s, ChanScalars &c, ChanArrays &a, const float *eq_h0)      // src/hfdl.c:968-991
 {
 	s.fr_state = FR_A1;
 	s.symbols_wanted = 1;
-	s.search_retries = 0;
+	c.search_retries = 0;
 	s.cur_arity = 1;
-	s.train_total = s.train_bad = 0;
+	c.train_total = c.train_bad = 0;
 	s.T_idx = 0;
 	s.use_data = 0;
 	eq_reset(s, a, eq_h0);
@@ -363,10 +364,14 @@ HFDL_FN float t_symbol(int idx)          // T = 0x9AF, bit 14 first; BPSK 0 -> +
 }
 
 // everything after the equaliser for one on-time symbol: src/hfdl.c:737-891
+// `s` / `c`: the channel's scalars in two places.  The carrier wave keeps `s` in registers; the dozen fields that only the framer's rare
+// transitions read or write (search_retries, the preamble / frame counters, M1, the training tallies, ...) are reached through `c`,
+// which there is the copy in LDS -- the wave is short of scalar registers, and every live value it does not need in its loop is a
+// spill inside it.  Everywhere else `c` is `s` itself.
 // `slice(arity, x, &phase_error)` = modem_demodulate + the demodulator phase error (psk_slice() above, or the carrier wave's
 // lane-parallel form of the same decision)
 template <class Slicer>
-HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, cf sym, float level, const Slicer &slice)
+HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const DemodConst &T, const BlockIo &io, cf sym, float level, const Slicer &slice)
 {
 	float perr;
 	uint32_t bits = slice(s.cur_arity, sym, &perr);
@@ -414,21 +419,21 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 			s.signal_level = level;
 			s.frame_symbol_cnt = 1.0f;
 			s.symbols_wanted = A_LEN;
-			s.search_retries = 0;
+			c.search_retries = 0;
 			s.fr_state = FR_A2;
 		}
 		break; }
 	case FR_A2: {
 		const int m = bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo);
 		if (m <= T.a2_lo || m >= T.a2_hi) {
-			s.cnt_a2_found++;                    // statsd "demod.preamble.A2_found"
-			s.pdu_sample_index = s.sample_cnt;
-			s.freq_err_hz = (float)((double)(s.dphi * 1800) / (2.0 * M_PI));
+			c.cnt_a2_found++;                    // statsd "demod.preamble.A2_found"
+			c.pdu_sample_index = s.sample_cnt;
+			c.freq_err_hz = (float)((double)(s.dphi * 1800) / (2.0 * M_PI));
 			s.symbols_wanted = M1_LEN;
-			s.search_retries = 0;
+			c.search_retries = 0;
 			s.fr_state = FR_M1;
-		} else if (++s.search_retries >= 3) {
-			framer_reset(s, a, T.eq_h0);
+		} else if (++c.search_retries >= 3) {
+			framer_reset(s, c, a, T.eq_h0);
 		}
 		break; }
 	case FR_M1: {
@@ -440,23 +445,23 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 		}
 		if (fabsf(best) > 0.3f) {
 			const ModeParams mp = mode_params(best_idx);
-			s.cnt_m1_found++;                    // "demod.preamble.M1_found"
-			s.data_segment_cnt = mp.segments;
-			s.data_arity = mp.arity;
-			s.M1 = best_idx;
+			c.cnt_m1_found++;                    // "demod.preamble.M1_found"
+			c.data_segment_cnt = mp.segments;
+			c.data_arity = mp.arity;
+			c.M1 = best_idx;
 			s.symbols_wanted = M2_LEN;
-			s.search_retries = 0;
+			c.search_retries = 0;
 			s.fr_state = FR_M2_SKIP;
 			s.s_state = SAMPLER_SKIP;
 		} else {
-			s.cnt_m1_not_found++;                // "demod.preamble.errors.M1_not_found"
-			framer_reset(s, a, T.eq_h0);
+			c.cnt_m1_not_found++;                // "demod.preamble.errors.M1_not_found"
+			framer_reset(s, c, a, T.eq_h0);
 		}
 		break; }
 	case FR_M2_SKIP:
 		s.training_n = 0;
 		s.symbols_wanted = T_LEN;
-		s.eq_train_seq_cnt = 9;
+		c.eq_train_seq_cnt = 9;
 		s.fr_state = FR_EQ_TRAIN;
 		s.s_state = SAMPLER_SYMBOLS;
 		break;
@@ -468,17 +473,17 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 			bit ^= (s.bitmask & 1u);
 			seq = (seq << 1) | bit;
 		}
-		s.train_total += T_LEN;
-		s.train_bad += __popc(0x9AFu ^ seq);
+		c.train_total += T_LEN;
+		c.train_bad += __popc(0x9AFu ^ seq);
 		s.training_n = 0;
-		if (s.eq_train_seq_cnt > 1) {
-			s.eq_train_seq_cnt--;
+		if (c.eq_train_seq_cnt > 1) {
+			c.eq_train_seq_cnt--;
 			s.symbols_wanted = T_LEN;
 			s.T_idx = 0;
-		} else if (s.data_segment_cnt > 0) {
+		} else if (c.data_segment_cnt > 0) {
 			s.symbols_wanted = DATA_FRAME_LEN / 2;
 			s.fr_state = FR_DATA_1;
-			s.cur_arity = s.data_arity;
+			s.cur_arity = c.data_arity;
 			s.use_data = 1;
 		} else {
 			// end of frame: queue it for the burst decoder (decode_user_data + dispatch_pdu, :993-1080)
@@ -486,16 +491,16 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 				const int slot = atomicAdd(io.frame_count, 1);
 				if (slot < io.frame_cap) {
 					FrameRec fr;
-					fr.channel = io.channel; fr.slot = s.data_slot; fr.mode = s.M1; fr.bitmask_lsb = (int32_t)(s.bitmask & 1u);
-					fr.freq_err_hz = s.freq_err_hz; fr.signal_level = s.signal_level; fr.noise_floor = s.noise_floor;
-					fr.train_bad = s.train_bad; fr.train_total = s.train_total; fr.pad = 0;
-					fr.sample_index = s.pdu_sample_index;
+					fr.channel = io.channel; fr.slot = s.data_slot; fr.mode = c.M1; fr.bitmask_lsb = (int32_t)(s.bitmask & 1u);
+					fr.freq_err_hz = c.freq_err_hz; fr.signal_level = s.signal_level; fr.noise_floor = s.noise_floor;
+					fr.train_bad = c.train_bad; fr.train_total = c.train_total; fr.pad = 0;
+					fr.sample_index = c.pdu_sample_index;
 					io.frames[slot] = fr;
 				}
 			}
 			s.data_slot ^= 1;
-			s.cnt_frames++;
-			framer_reset(s, a, T.eq_h0);
+			c.cnt_frames++;
+			framer_reset(s, c, a, T.eq_h0);
 			s.symbol_cnt = 0;
 		}
 		break; }
@@ -504,11 +509,11 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanArrays &a, const DemodConst &T, const
 		s.fr_state = FR_DATA_2;
 		break;
 	case FR_DATA_2:
-		s.data_segment_cnt--;
+		c.data_segment_cnt--;
 		s.cur_arity = 1;
 		s.use_data = 0;
 		s.fr_state = FR_EQ_TRAIN;
-		s.eq_train_seq_cnt = 1;
+		c.eq_train_seq_cnt = 1;
 		s.symbols_wanted = T_LEN;
 		s.T_idx = 0;
 		break;

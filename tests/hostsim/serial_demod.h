@@ -187,7 +187,7 @@ static inline int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodC
 			}
 			if (io.tap_symbols) io.tap_symbols[nsym] = y;
 			nsym++;
-			on_symbol(s, a, T, io, y, level, TableSlicer{T.psk_pts});
+			on_symbol(s, s, a, T, io, y, level, TableSlicer{T.psk_pts});
 		}
 	}
 	if (io.tap_counts) io.tap_counts[1] = nsym;
