@@ -236,18 +236,33 @@ def cpu_baseline(w, x, input_size, target_seconds=20.0):
     C = ctypes
     spec = np.empty(fe.ddc.fft_size, np.complex64)
     buf = np.zeros(fe.ddc.fft_size, np.complex64)
+    # dumphfdl runs its forward FFT on FFT_THREAD_CNT_DEFAULT = 4 FFTW threads (src/fft.h:15, src/fft_fftw.c:9-20): the restated
+    # transform is timed on 1 and on 4 threads (six-step split, oracle/csdr_restated.c) and the faster of the two is the baseline's
+    fft_try = {}
+    first = np.ascontiguousarray(x[:input_size])
+    for nt in (1, 4):
+        L.orc_set_fft_threads(nt)
+        best = 1e9
+        for _ in range(3):
+            t1 = time.time()
+            L.orc_forward_block(buf.ctypes.data_as(C.c_void_p), first.ctypes.data_as(C.c_void_p), C.byref(fe.ddc), spec.ctypes.data_as(C.c_void_p))
+            best = min(best, time.time() - t1)
+        fft_try[nt] = best
+    fft_threads = min(fft_try, key=fft_try.get)
+    L.orc_set_fft_threads(fft_threads)
+    buf[:] = 0
     while nblk < 2 or (t_all < target_seconds / 2 and nblk < w["blocks"] - 1):
         blk = np.ascontiguousarray(x[(nblk + 1) * input_size:(nblk + 2) * input_size])
         t1 = time.time()
         fe.push_block(blk, nthreads=cores)
         t_all += time.time() - t1
-        t1 = time.time()            # the shared forward FFT alone (1 thread, like --fft-threads 1)
+        t1 = time.time()            # the shared forward FFT alone, on the thread count chosen above
         L.orc_forward_block(buf.ctypes.data_as(C.c_void_p), blk.ctypes.data_as(C.c_void_p), C.byref(fe.ddc), spec.ctypes.data_as(C.c_void_p))
         t_fft += time.time() - t1
         nblk += 1
     per_blk, fft_blk = t_all / nblk, t_fft / nblk
     chan_blk = max(per_blk - fft_blk, 1e-9)          # cs channels on `cores` threads
-    fft_used, fft_kind = fft_blk, "oracle radix-4 FFT, 1 thread"
+    fft_used, fft_kind = fft_blk, "oracle radix-4 FFT, %d thread%s (1 thread %.3f s, 4 threads %.3f s)" % (fft_threads, "s" if fft_threads > 1 else "", fft_try[1], fft_try[4])
     if libs["fftw3f"]:
         try:
             fft_used, fft_kind = fftw_forward_seconds(fe.ddc.fft_size, libs["fftw3f"]), "FFTW3f (%s), FFTW_ESTIMATE, 1 thread" % libs["fftw3f"]
@@ -257,14 +272,16 @@ def cpu_baseline(w, x, input_size, target_seconds=20.0):
     frames = len(fe.pdus)
     fft_size = fe.ddc.fft_size
     fe.close()
+    L.orc_set_fft_threads(1)
     pyoracle.select_build("strict")
-    return dict(value=input_size / full / 1e6, unit="Msamples/s", cores=cores, kind="port",
+    return dict(value=input_size / full / 1e6, unit="Msamples/s", cores=cores, kind="port", fft_threads=fft_threads,
                 fftw_found=libs["fftw3f"], liquid_found=libs["liquid"],
                 build="gcc -O3 -DNDEBUG -ffast-math (the reference's cmake Release flags, CMakeLists.txt:12-15, src/CMakeLists.txt:39-42)",
-                forward_fft="%s: %.3f s per %d-point block -- the shared forward FFT is single-threaded and DOMINATES the CPU block time "
-                            "(FFT-bound); the per-channel part runs on all threads" % (fft_kind, fft_used, fft_size),
+                forward_fft="%s: %.3f s per %d-point block -- the reference's shape: ONE forward FFT per block (FFTW on 4 threads there) shared by "
+                            "all channels, ahead of the per-channel part, which runs on all threads; the FFT is %.0f %% of the CPU block time"
+                            % (fft_kind, fft_used, fft_size, 100.0 * fft_used / full),
                 sample="oracle (C restatement; dlopen probe: FFTW3f %s, liquid-dsp %s): %d of %d channels x %d blocks of %d samples on %d "
-                       "threads, %.3f s/block measured (forward FFT %.3f s on 1 thread, channel part %.3f s), channel part scaled x%.1f to %d channels; "
+                       "threads, %.3f s/block measured (forward FFT %.3f s, channel part %.3f s), channel part scaled x%.1f to %d channels; "
                        "init %.1f s untimed; %d PDUs decoded in the sample"
                        % ("found" if libs["fftw3f"] else "not found", "found" if libs["liquid"] else "not found",
                           cs, len(freqs), nblk, input_size, cores, per_blk, fft_blk, chan_blk, len(freqs) / cs, len(freqs), t_init, frames))

@@ -145,6 +145,9 @@ static pthread_mutex_t tw_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static const double *twiddles(int32_t n)
 {
+	/* fast path without the lock (entries are only ever added; tw is published before n): the threaded transform asks per column */
+	for (int i = 0; i < TW_CACHE; i++)
+		if (__atomic_load_n(&tw_cache[i].n, __ATOMIC_ACQUIRE) == n) return tw_cache[i].tw;
 	pthread_mutex_lock(&tw_lock);
 	int slot = -1;
 	for (int i = 0; i < TW_CACHE; i++) {
@@ -157,7 +160,7 @@ static const double *twiddles(int32_t n)
 		tw[2 * k] = cos(a);
 		tw[2 * k + 1] = sin(a);
 	}
-	if (slot >= 0) { tw_cache[slot].n = n; tw_cache[slot].tw = tw; }   /* else: leaked, small */
+	if (slot >= 0) { tw_cache[slot].tw = tw; __atomic_store_n(&tw_cache[slot].n, n, __ATOMIC_RELEASE); }   /* else: leaked, small */
 	pthread_mutex_unlock(&tw_lock);
 	return tw;
 }
@@ -231,6 +234,91 @@ void orc_fft_f64(const double *in, double *out, int32_t n, int sign)
 	if (n == 1) { out[0] = in[0]; out[1] = in[1]; free(a); free(b); return; }
 	fft_core_f64(a, b, n, sign, out);
 	free(a); free(b);
+}
+
+/* ---- the forward FFT on several threads, TIMING ONLY (bench.py's cpu_baseline) ----
+ * dumphfdl plans its forward FFT with fftwf_plan_with_nthreads(FFT_THREAD_CNT_DEFAULT = 4) (src/fft.h:15, src/fft_fftw.c:9-20).
+ * FFTW is not available here; to give the CPU baseline the reference's threading shape the transform is split the six-step way,
+ * n = n1 * n2:  X[k1 + n1 k2] = sum_n2 W_n2^(n2 k2) W_n^(n2 k1) sum_n1 x[n2 + n2_total n1] W_n1^(n1 k1),
+ * columns and rows done by the single-thread kernel above on `threads` pthreads.  Same mathematics, another order of rounding:
+ * the parity checks never use it (orc_fft_threads stays 1 unless the timing leg raises it). */
+static int orc_fft_threads = 1;
+void orc_set_fft_threads(int n) { orc_fft_threads = n < 1 ? 1 : (n > 64 ? 64 : n); }
+int  orc_get_fft_threads(void) { return orc_fft_threads; }
+
+struct mt_job { const float *in; float *mid, *out; int32_t n, n1, n2; int sign, phase, t, nt; };
+
+#define MT_TILE 16      /* columns / rows handled together, so that every pass over the big arrays moves 128-byte runs */
+
+static void *mt_worker(void *ctx)
+{
+	struct mt_job *j = ctx;
+	const int32_t n1 = j->n1, n2 = j->n2;
+	const double *tw = twiddles(j->n);
+	const float sg = (float)j->sign;
+	const int32_t len = j->phase == 0 ? n1 : n2;
+	float *tile = malloc(sizeof(float) * 2 * (size_t)len * MT_TILE), *b = malloc(sizeof(float) * 2 * (size_t)len), *o = malloc(sizeof(float) * 2 * (size_t)len);
+	if (j->phase == 0) {
+		/* columns: for every n2, an n1-point transform over n1 (stride n2), times W_n^(n2 k1); result stored [k1][n2] */
+		for (int32_t c0 = j->t * MT_TILE; c0 < n2; c0 += j->nt * MT_TILE) {
+			for (int32_t r = 0; r < n1; r++)
+				for (int32_t c = 0; c < MT_TILE; c++) {
+					const size_t at = 2 * ((size_t)c0 + c + (size_t)n2 * r);
+					tile[2 * ((size_t)c * n1 + r)] = j->in[at]; tile[2 * ((size_t)c * n1 + r) + 1] = j->in[at + 1];
+				}
+			for (int32_t c = 0; c < MT_TILE; c++) {
+				float *col = tile + 2 * (size_t)c * n1;
+				if (n1 > 1) { fft_core_f32(col, b, n1, j->sign, o); memcpy(col, o, sizeof(float) * 2 * (size_t)n1); }
+			}
+			for (int32_t k1 = 0; k1 < n1; k1++)
+				for (int32_t c = 0; c < MT_TILE; c++) {
+					/* W_n^e, e = n2 k1 (n is a power of two), as W_n^(e_hi * n2) * W_n^(e_lo): the two factors come from n1 + n2
+					 * table entries that stay in cache, instead of one access scattered over the whole table per element */
+					const size_t e = ((size_t)(c0 + c) * (size_t)k1) & (size_t)(j->n - 1);
+					const size_t eh = (e / (size_t)n2) * (size_t)n2, el = e % (size_t)n2;
+					const double ar = tw[2 * eh], ai = tw[2 * eh + 1], br = tw[2 * el], bi = tw[2 * el + 1];
+					const float wr = (float)(ar * br - ai * bi), wi = -sg * (float)(ar * bi + ai * br);
+					const float xr = tile[2 * ((size_t)c * n1 + k1)], xi = tile[2 * ((size_t)c * n1 + k1) + 1];
+					j->mid[2 * ((size_t)k1 * n2 + c0 + c)] = xr * wr - xi * wi;
+					j->mid[2 * ((size_t)k1 * n2 + c0 + c) + 1] = xr * wi + xi * wr;
+				}
+		}
+	} else {
+		/* rows: for every k1, an n2-point transform over n2 (contiguous); X[k1 + n1 k2] */
+		for (int32_t r0 = j->t * MT_TILE; r0 < n1; r0 += j->nt * MT_TILE) {
+			for (int32_t r = 0; r < MT_TILE; r++) {
+				float *row = j->mid + 2 * (size_t)(r0 + r) * n2;
+				if (n2 > 1) fft_core_f32(row, b, n2, j->sign, tile + 2 * (size_t)r * n2); else memcpy(tile + 2 * (size_t)r * n2, row, sizeof(float) * 2);
+			}
+			for (int32_t k2 = 0; k2 < n2; k2++)
+				for (int32_t r = 0; r < MT_TILE; r++) {
+					j->out[2 * ((size_t)r0 + r + (size_t)n1 * k2)] = tile[2 * ((size_t)r * n2 + k2)];
+					j->out[2 * ((size_t)r0 + r + (size_t)n1 * k2) + 1] = tile[2 * ((size_t)r * n2 + k2) + 1];
+				}
+		}
+	}
+	free(tile); free(b); free(o);
+	return NULL;
+}
+
+void orc_fft_f32_mt(const orc_cf *in, orc_cf *out, int32_t n, int sign, int threads)
+{
+	if (threads <= 1 || n < 4096) { orc_fft_f32(in, out, n, sign); return; }
+	int lg = 0;
+	while ((1 << lg) < n) lg++;
+	const int32_t n1 = 1 << (lg / 2), n2 = n / n1;
+	float *mid = malloc(sizeof(float) * 2 * (size_t)n);
+	(void)twiddles(n); (void)twiddles(n1); (void)twiddles(n2);              /* built once, before the threads ask for them */
+	pthread_t th[64];
+	struct mt_job jobs[64];
+	for (int phase = 0; phase < 2; phase++) {
+		for (int t = 0; t < threads; t++) {
+			jobs[t] = (struct mt_job){ (const float *)in, mid, (float *)out, n, n1, n2, sign, phase, t, threads };
+			pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+		}
+		for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+	}
+	free(mid);
 }
 
 /* ---- per-channel frequency-domain taps (src/fastddc.c:217-252) ---- */
@@ -320,6 +408,6 @@ void orc_forward_block(orc_cf *buf, const orc_cf *new_samples, const orc_ddc *d,
 {
 	memmove(buf, buf + d->input_size, sizeof(orc_cf) * (size_t)d->overlap_length);
 	memcpy(buf + d->overlap_length, new_samples, sizeof(orc_cf) * (size_t)d->input_size);
-	orc_fft_f32(buf, spectrum, d->fft_size, -1);
+	orc_fft_f32_mt(buf, spectrum, d->fft_size, -1, orc_fft_threads);      /* 1 thread = orc_fft_f32: every parity check */
 	orc_fft_swap_sides(spectrum, d->fft_size);
 }

@@ -56,6 +56,10 @@ void    orc_firdes_bandpass_c(orc_cf *out, int32_t length, float lowcut, float h
 void    orc_fft_swap_sides(orc_cf *io, int32_t n);                  /* src/fastddc.c:102-112 */
 /* forward (sign=-1) / backward (sign=+1) unnormalised DFT, out of place; src/fft_fftw.c:22-41 contract */
 void    orc_fft_f32(const orc_cf *in, orc_cf *out, int32_t n, int sign);
+/* the forward transform of orc_forward_block on `threads` pthreads (six-step split): cpu_baseline timing only, see csdr_restated.c */
+void    orc_fft_f32_mt(const orc_cf *in, orc_cf *out, int32_t n, int sign, int threads);
+void    orc_set_fft_threads(int n);
+int     orc_get_fft_threads(void);
 void    orc_fft_f64(const double *in_ri, double *out_ri, int32_t n, int sign);
 /* channel taps in the frequency domain, fftshifted: src/fastddc.c:217-252. f64_fft!=0 -> double FFT */
 int     orc_channelizer_taps(const orc_ddc *d, int32_t decimation, float freq_shift, orc_cf *taps_fft, int f64_fft);

@@ -90,6 +90,8 @@ def lib():
         L.orc_fcs_check.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_pdu_triage.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
         L.orc_lpdu_walk.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_set_fft_threads.argtypes = [C.c_int]
+        L.orc_fft_f32_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int]
         L.orc_viterbi27_decode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.orc_conv27_encode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.orc_fft_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int]

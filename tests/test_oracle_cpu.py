@@ -296,3 +296,26 @@ def test_oracle_frontend_end_to_end(oracle):
     for b in range(len(x2) // n):
         fe2.push_block(x2[b * n:(b + 1) * n])
     assert len(fe2.pdus) == 2
+
+
+def test_threaded_forward_fft_is_the_same_transform(oracle):
+    """orc_fft_f32_mt (six-step split on pthreads; used by bench.py's cpu_baseline only, where dumphfdl runs FFTW on 4 threads)
+    computes the DFT of orc_fft_f32 -- another order of rounding, same result to fp32 accuracy -- and the parity oracle stays on
+    the single-thread transform unless told otherwise."""
+    import ctypes as C
+    L = oracle.lib()
+    assert L.orc_get_fft_threads() == 1
+    rng = np.random.default_rng(5)
+    for n in (4096, 1 << 15, 1 << 18):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        ref = np.fft.fft(x.astype(np.complex128))
+        one = np.zeros(n, np.complex64)
+        L.orc_fft_f32(x.ctypes.data_as(C.c_void_p), one.ctypes.data_as(C.c_void_p), n, -1)
+        for threads in (2, 4, 7):
+            y = np.zeros(n, np.complex64)
+            L.orc_fft_f32_mt(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), n, -1, threads)
+            assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 5e-7
+            assert np.linalg.norm(y - one) / np.linalg.norm(ref) < 5e-7
+        back = np.zeros(n, np.complex64)
+        L.orc_fft_f32_mt(one.ctypes.data_as(C.c_void_p), back.ctypes.data_as(C.c_void_p), n, +1, 4)
+        assert np.linalg.norm(back / n - x) / np.linalg.norm(x) < 1e-6
