@@ -262,6 +262,54 @@ def test_lpdu_walk_matches_oracle(sim, oracle):
     assert any(s[4] for s in seen) and any(s[3] for s in seen)
 
 
+def test_lpdu_walk_arbitrary_headers(sim, oracle):
+    """Headers with a GOOD FCS but arbitrary contents -- any LPDU / aircraft counts, any size octets (0 = a 1-octet LPDU, 255 = 256
+    octets), any PDU length from just the header to far beyond the announced LPDUs: the device-side walk and the oracle's agree on
+    every count, and neither reads past the PDU (the buffers end where the PDU ends)."""
+    from hypothesis import given, settings, strategies as st
+    sim.sim_lpdu_walk.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+
+    def with_fcs(hdr):
+        fcs = synth.crc16_x25(bytes(hdr))
+        return bytes(hdr) + bytes([fcs & 0xFF, fcs >> 8])
+
+    sizes = st.lists(st.sampled_from([0, 1, 2, 3, 5, 17, 64, 200, 255]), min_size=0, max_size=15)
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.booleans(), st.lists(sizes, min_size=1, max_size=8), st.integers(0, 700), st.binary(min_size=0, max_size=64), st.integers(0, 3))
+    def run(uplink, groups, body_len, salt, fix_fcs_of):
+        if not uplink:
+            lens = groups[0]
+            hdr = bytearray([0x03 | (len(lens) << 2), 1, 2, 3, 4, 5]) + bytes(lens)
+        else:
+            hdr = bytearray([0x01 | ((len(groups) - 1) << 4), 9])
+            for g in groups:
+                hdr += bytes([7, (len(g) << 4) | 5]) + bytes(g)
+        pdu = bytearray(with_fcs(hdr))
+        body = bytearray((salt * (body_len // max(1, len(salt)) + 1))[:body_len]) if salt else bytearray(body_len)
+        # give the first `fix_fcs_of` LPDUs that fit a good FCS of their own, so that "good" is exercised as well as "bad"
+        at = 0
+        flat = [n for g in (groups if uplink else [groups[0]]) for n in g]
+        for n in flat[:fix_fcs_of]:
+            L = n + 1
+            if L >= 3 and at + L <= len(body):
+                f = synth.crc16_x25(bytes(body[at:at + L - 2]))
+                body[at + L - 2] = f & 0xFF; body[at + L - 1] = f >> 8
+            at += L
+        pdu += body
+        a = np.frombuffer(bytes(pdu), np.uint8).copy()
+        counts = np.zeros(5, np.uint8)
+        sim.sim_lpdu_walk(a.ctypes.data, len(a), counts.ctypes.data)
+        got = tuple(int(v) for v in counts)
+        want = oracle.lpdu_walk(bytes(pdu))
+        assert got == want
+        assert got[0] == got[1] + got[2] + got[3] and got[0] <= len(flat)
+        if not got[4]:
+            assert got[0] == len(flat)                       # nothing truncated: every announced LPDU was looked at
+
+    run()
+
+
 def test_bench_traffic_plans():
     """bench.py's synthetic traffic: bursts of a channel never overlap, all end inside the resident stretch, the burst-dense
     workload cycles all eight modes (BASELINE.json configs[3]) and the plan is a pure function of the seed."""
