@@ -72,6 +72,9 @@ static int check_file(const char *path, const char *fmt, int bufsize, const char
 	while (block_is_running(in)) usleep(1000);
 	struct input *ip = (struct input *)in;
 	printf("samples %zu max_tu %zu bytes_per_sample %d full_scale %.3f\n", total, in->producer.max_tu, ip->bytes_per_sample, ip->full_scale);
+	block_disconnect_one2one(in, &sink);
+	input_destroy(in);
+	input_cfg_destroy(cfg);
 	return 0;
 }
 
@@ -120,6 +123,8 @@ static int check_direct(const char *path, const char *fmt, const char *out_path,
 	printf("samples %zu blocks %zu elem %zu capacity %zu pinned %d\n", total, blocks, elem, hfdl_ring_capacity(cb->buf), hfdl_ring_is_pinned(cb->buf));
 	block_disconnect_one2one(in, fft);
 	fft_destroy(fft);
+	input_destroy(in);
+	input_cfg_destroy(cfg);
 	return 0;
 }
 
