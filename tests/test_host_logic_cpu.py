@@ -17,8 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def sim():
     d = os.path.join(ROOT, "tests", "hostsim")
     so = os.path.join(d, "libhostsim.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so,
-                           os.path.join(d, "hostsim.cpp")])
+    # HOSTSIM_CXXFLAGS: e.g. "-fsanitize=address,undefined -g" (then run pytest with the sanitizer runtimes in LD_PRELOAD)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"] + os.environ.get("HOSTSIM_CXXFLAGS", "").split() +
+                          ["-o", so, os.path.join(d, "hostsim.cpp")])
     H = C.CDLL(so)
     H.sim_create.restype = C.c_void_p
     H.sim_create.argtypes = [C.c_float, C.c_int]
