@@ -176,8 +176,13 @@ int32_t hfdl_nf_stats_thread_start(struct block **channel_block_list, int32_t ch
 
 /* ---- the front-end thread ---- */
 
+static uint64_t g_lpdu_tally[4];      /* MPDUs walked, LPDUs processed / good / bad FCS: front-end thread only, copied into the run stats at shutdown */
+
 static void push_pdu(const hfdl_gpu_pdu *p, const struct timeval *t0)
 {
+	if (p->fcs_status == HFDL_GPU_FCS_GOOD && p->pdu_kind != HFDL_GPU_KIND_SPDU) {
+		g_lpdu_tally[0]++; g_lpdu_tally[1] += p->lpdus_processed; g_lpdu_tally[2] += p->lpdus_good; g_lpdu_tally[3] += p->lpdus_bad_fcs;
+	}
 	struct metadata *m = hfdl_pdu_metadata_create();
 	struct hfdl_pdu_metadata *hm = container_of(m, struct hfdl_pdu_metadata, metadata);
 	hm->version = 1;
@@ -358,6 +363,7 @@ shutdown:
 		g_run.bytes_per_sample = (int32_t)elem; g_run.channels = (int32_t)nch; g_run.block_samples = (int32_t)need;
 		g_run.zero_copy = hfdl_ring_is_pinned(ring->buf);
 		g_run.wait_input_s = s_wait; g_run.push_s = s_push; g_run.collect_s = s_poll; g_run.release_s = s_release;
+		g_run.mpdus_walked = g_lpdu_tally[0]; g_run.lpdus_processed = g_lpdu_tally[1]; g_run.lpdus_good = g_lpdu_tally[2]; g_run.lpdus_bad_fcs = g_lpdu_tally[3];
 		pthread_mutex_unlock(&g_run_lock);
 	}
 	block_connection_one2many_shutdown(down);

@@ -192,6 +192,9 @@ struct hfdl_run_stats {
 	int32_t zero_copy;               /* 1: blocks were DMA'd straight out of the page-locked input ring */
 	double wait_input_s, push_s, collect_s, release_s;   /* the front-end thread's time: waiting for the producer, enqueueing,
 	                                                        collecting PDUs (waits for the previous block), releasing ring slots (waits for DMA) */
+	/* what the device found when it walked the LPDU lists of the MPDUs with a good header FCS (hfdl_gpu_pdu.lpdus_*): informational --
+	 * dumphfdl's own lpdu_parse emits the StatsD events for these downstream */
+	uint64_t mpdus_walked, lpdus_processed, lpdus_good, lpdus_bad_fcs;
 };
 void          hfdl_frontend_run_stats(struct hfdl_run_stats *out);
 /* replay a regular input file this many times back to back (default 1); not in the reference */

@@ -11,5 +11,5 @@ for name in sys.argv[1:] or ("cfg2", "cfg3"):
     x, _ = bench.make_input(w, g.input_size, 0, 1)
     for fmt in ("CF32", "CS16"):
         r = bench.host_path_leg(w, x, bench.channel_plan(w), fmt)
-        print(name, fmt, round(r["value"], 1), r["pdus"], r["thread_s"])
+        print(name, fmt, round(r["value"], 1), r["pdus"], r["lpdu_walk_on_device"], r["file_loops"])
 PY
