@@ -224,7 +224,6 @@ static void pool_stop(struct read_pool *p)
  * no bounce buffers.  Regular files are read a front-end block at a time by the reader pool; a pipe delivers what it has. */
 static void file_loop_direct(struct input *in, struct file_input *fi, struct circ_buffer *cb)
 {
-	const size_t elem = (size_t)in->bytes_per_sample;
 	struct read_pool pool;
 	if (fi->seekable) pool_start(&pool, fi->fd);
 	off_t off = 0;
@@ -236,7 +235,9 @@ static void file_loop_direct(struct input *in, struct file_input *fi, struct cir
 		pthread_mutex_lock(cb->mutex);
 		/* back-pressure: wait for free space; the front end signals the condition when it releases a block, the timeout
 		 * covers consumers that do not (the reference polls with 100 ms naps, src/input-file.c:53-61) */
-		while ((room = hfdl_ring_write_acquire(cb->buf, &dst)) < elem && do_exit == 0) {
+		/* room == 0 only: with a fragment of a sample carried over (pipe input) the run up to the end of the storage can be
+		 * SHORTER than a sample -- exactly the bytes that complete it, after which the tail wraps */
+		while ((room = hfdl_ring_write_acquire(cb->buf, &dst)) == 0 && do_exit == 0) {
 			struct timespec ts;
 			clock_gettime(CLOCK_REALTIME, &ts);
 			ts.tv_nsec += 2000000;

@@ -224,3 +224,40 @@ def test_host_library_under_sanitizers(tmp_path):
                  ["direct", str(b), "CU8", str(tmp_path / "o4"), "1"]):
         out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120, env=env)
         assert out.returncode == 0 and "Sanitizer" not in out.stderr and "runtime error" not in out.stderr, (args, out.stderr[-1500:])
+
+
+@pytest.mark.timeout(90)
+def test_pipe_input_fragment_across_the_ring_wrap(host_check, tmp_path):
+    """Samples arriving through a pipe in pieces that are not whole samples (nc / ssh do that): the fragment of a sample is
+    carried to the next read.  When it sits in the LAST slot of the ring's storage the free run is shorter than a sample --
+    the producer must still read the bytes that complete it (it used to wait for a whole sample of room: forever)."""
+    bps, blk = 4, 28672
+    probe = tmp_path / "probe.bin"
+    np.zeros(2 * blk * bps, np.uint8).tofile(probe)
+    out = subprocess.run([host_check, "direct", str(probe), "CS16", str(tmp_path / "o0"), "1"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    cap = int(out.stdout.split("capacity")[1].split()[0])
+    n = cap + 2 * blk + 77                                        # more than the storage holds: the tail wraps once
+    raw = np.random.default_rng(11).integers(0, 256, n * bps, dtype=np.uint8).tobytes()
+    stop_at = (cap - 1) * bps + 1                                 # one byte into the last sample slot of the storage
+    dst = tmp_path / "out.bin"
+    proc = subprocess.Popen([host_check, "direct", "-", "CS16", str(dst), "1"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    import time
+    pos = 0
+    for size in (4099, 12345, 1):                                 # odd-sized first writes: reads return fragments
+        proc.stdin.write(raw[pos:pos + size]); proc.stdin.flush(); pos += size
+        time.sleep(0.02)
+    proc.stdin.write(raw[pos:stop_at]); proc.stdin.flush(); pos = stop_at
+    time.sleep(0.3)                                               # the reader drains the pipe: fragment pending at the last slot
+    proc.stdin.write(raw[pos:pos + 2]); proc.stdin.flush(); pos += 2
+    time.sleep(0.1)
+    proc.stdin.write(raw[pos:]); proc.stdin.close()
+    try:
+        rc = proc.wait(timeout=30)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        pytest.fail("the pipe reader hung with a sample fragment pending at the ring's wrap point")
+    stdout = proc.stdout.read().decode()
+    assert rc == 0, proc.stderr.read().decode()
+    got = np.fromfile(dst, np.uint8).tobytes()
+    assert got == raw and ("samples %d " % n) in stdout
