@@ -60,7 +60,7 @@ def channel_plan(w):
 
 def make_input(w, geom_input_size, rank, world, shard_mode="streams"):
     """Seeded synthetic wideband stream: one single-slot burst per channel (modes cycle 300/600/1200/1800 bps) + AWGN."""
-    from dumphfdl_amd import synth
+    import hfdl_synth as synth
     from dumphfdl_amd import shard
     seed = shard.stream_seed(w["seed"], rank, world) if shard_mode == "streams" else w["seed"]
     nsamp = w["blocks"] * geom_input_size
@@ -68,17 +68,39 @@ def make_input(w, geom_input_size, rank, world, shard_mode="streams"):
     freqs = channel_plan(w)
     dur = nsamp / w["fs"]
     bursts = plan_bursts(w, freqs, dur, seed)
-    if os.path.exists(cache):
-        x = np.load(cache, mmap_mode="r")
-        if x.shape == (nsamp,):
-            return np.ascontiguousarray(x), bursts
-    x = synth.synth_wideband(w["fs"], w["centerfreq"], nsamp, bursts, noise_sigma=w["noise"], seed=seed)
+    def cached():
+        if os.path.exists(cache):
+            x = np.load(cache, mmap_mode="r")
+            if x.shape == (nsamp,):
+                return np.ascontiguousarray(x)
+        return None
+
+    x = cached()
+    if x is not None:
+        return x, bursts
+    # one synthesis per seed on a node: ranks that share a stream (--shard channels) wait for the first one's file instead of
+    # each running the same ~8 s of numpy beside the others
+    import fcntl
+    lock = None
     try:
-        tmp = cache + ".%d.tmp.npy" % os.getpid()
-        np.save(tmp, x)
-        os.replace(tmp, cache)
+        lock = open(cache + ".lock", "w")
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        x = cached()
     except OSError:
-        pass
+        lock = None
+    try:
+        if x is None:
+            x = synth.synth_wideband(w["fs"], w["centerfreq"], nsamp, bursts, noise_sigma=w["noise"], seed=seed)
+            try:
+                tmp = cache + ".%d.tmp.npy" % os.getpid()
+                np.save(tmp, x)
+                os.replace(tmp, cache)
+            except OSError:
+                pass
+    finally:
+        if lock is not None:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+            lock.close()
     return x, bursts
 
 
@@ -86,7 +108,7 @@ def make_payload(rng, mode):
     """What a burst carries: an SPDU (half of the 66-octet frames) or an MPDU with a REAL LPDU list -- down- or uplink, every
     LPDU ending in its own FCS -- so that the device's LPDU walk (hfdl_gpu_pdu.lpdus_*) has something to count and the run can
     check it.  Returns (octets, LPDUs sent or None for an SPDU)."""
-    from dumphfdl_amd import synth
+    import hfdl_synth as synth
     n = synth.mode_sizes(mode)["max_payload"]
     if n == 66 and rng.random() < 0.5:
         return synth.make_spdu(rng), None
@@ -96,7 +118,7 @@ def make_payload(rng, mode):
 
 def plan_bursts(w, freqs, dur, seed):
     """The traffic of a workload: one single-slot burst per channel, or (dense) as many back-to-back bursts as fit."""
-    from dumphfdl_amd import synth
+    import hfdl_synth as synth
     rng = np.random.default_rng(seed)
     bursts = []
 
@@ -265,7 +287,13 @@ def cpu_baseline(w, x, input_size, target_seconds=20.0):
     fft_used, fft_kind = fft_blk, "oracle radix-4 FFT, %d thread%s (1 thread %.3f s, 4 threads %.3f s)" % (fft_threads, "s" if fft_threads > 1 else "", fft_try[1], fft_try[4])
     if libs["fftw3f"]:
         try:
-            fft_used, fft_kind = fftw_forward_seconds(fe.ddc.fft_size, libs["fftw3f"]), "FFTW3f (%s), FFTW_ESTIMATE, 1 thread" % libs["fftw3f"]
+            # the baseline takes the FASTER of the two: a single-threaded FFTW_ESTIMATE plan must not replace a quicker 4-thread
+            # transform (the reference runs FFTW on 4 threads, src/fft.h:15, src/fft_fftw.c:9-20)
+            t_fftw = fftw_forward_seconds(fe.ddc.fft_size, libs["fftw3f"])
+            if t_fftw < fft_used:
+                fft_used, fft_kind = t_fftw, "FFTW3f (%s), FFTW_ESTIMATE, 1 thread (%.3f s; oracle FFT %.3f s)" % (libs["fftw3f"], t_fftw, fft_blk)
+            else:
+                fft_kind += "; FFTW3f (%s) 1 thread measured slower: %.3f s" % (libs["fftw3f"], t_fftw)
         except Exception as e:            # the probe is best effort: the restated FFT stays the fallback
             fft_kind += " (FFTW found but unusable: %s)" % e
     full = fft_used + chan_blk * (len(freqs) / cs)
@@ -360,6 +388,127 @@ def traffic_record(workload):
         return None, None
 
 
+def alg_bytes_per_block(g):
+    """B = 8*input_size + C*8*N + C*8*(post_input_size/post_decimation) algorithmic bytes per block."""
+    return 8 * g.input_size + g.channels * 8 * g.fft_size + g.channels * 8 * (g.post_input_size // g.post_decimation)
+
+
+def init_dist(torch, dist, backend, dev_index, world):
+    """torch.distributed carries the timing barrier and the final reductions only (no data-path collective).  `nccl` = RCCL for
+    CUDA tensors (with gloo beside it for CPU tensors); if RCCL cannot be brought up the run continues on gloo and says so."""
+    note = None
+    if backend == "nccl":
+        try:
+            dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", dev_index))
+            t = torch.ones(1, device="cuda")
+            dist.all_reduce(t)                      # first RCCL collective: communicator really up, on every rank
+            torch.cuda.synchronize()
+            if int(t.item()) != world:
+                raise RuntimeError("all_reduce over %d ranks returned %s" % (world, t.item()))
+            return "nccl", "cuda", None
+        except Exception as e:                      # noqa: BLE001 -- anything RCCL throws: the measurement itself does not need it
+            note = "nccl (RCCL) could not be used: %s: %s -- barrier / reductions fell back to gloo" % (type(e).__name__, str(e)[:200])
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:                       # noqa: BLE001
+                pass
+    dist.init_process_group("gloo")
+    return "gloo", "cpu", note
+
+
+def timed_blocks(torch, fe, push_fn, steps, first_step, nblocks, prefetch_fn=None):
+    """K blocks through the whole path, PDUs back on the host, device idle at the end.  prefetch_fn(i): queue the upload of block i
+    (host-memory legs) while block i-1 is pushed, as the C host path does."""
+    step = first_step
+    raw = []
+    t_start = time.perf_counter()
+    for i in range(steps):
+        push_fn(step % nblocks); step += 1
+        if prefetch_fn is not None and i + 1 < steps:
+            prefetch_fn(step % nblocks)
+        if i % 256 == 255 and i + 1 < steps:      # long runs: empty the device PDU ring now and then, pipeline kept running
+            raw.append(fe.poll_pdus_raw(16384, max_in_flight=1))
+    raw.append(fe.poll_pdus_raw(16384))     # sync + device->host of every PDU struct produced by the timed blocks (what the C host gets)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t_start, raw, step
+
+
+def host_feed(hf, F, fe, x, g, nblocks, fmt_name):
+    """The stream in page-locked host memory, one pointer per block; returns (buffer, push(i), prefetch(i))."""
+    if fmt_name == "cs16":
+        raw = np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16)
+        fmt, bps = F.SFMT_CS16, 4
+    else:
+        raw, fmt, bps = x.view(np.float32), F.SFMT_CF32, 8
+    hbuf = hf.host_alloc(raw.nbytes)
+    ctypes.memmove(hbuf, raw.ctypes.data, raw.nbytes)
+    hptrs = [hbuf + bps * b * g.input_size for b in range(nblocks)]
+    return hbuf, (lambda i: fe.push_host_ptr(hptrs[i], fmt)), (lambda i: fe.prefetch_host_ptr(hptrs[i], fmt))
+
+
+def host_ram_leg(torch, hf, F, fe, x, g, nblocks, steps):
+    """SURVEY.md 8(d) "input pre-loaded in host RAM": the same blocks from page-locked host memory, the upload of block k+1
+    queued while block k is pushed (hfdl_gpu_frontend_prefetch_block_raw) -- PCIe-inclusive."""
+    hbuf, hpush, hprefetch = host_feed(hf, F, fe, x, g, nblocks, "cf32")
+    k2 = min(steps, 96)
+    for i in range(4):
+        hpush(i % nblocks)
+    fe.poll_pdus()
+    hprefetch(4 % nblocks)
+    el2, raw2, _ = timed_blocks(torch, fe, hpush, k2, 4, nblocks, prefetch_fn=hprefetch)
+    return hbuf, dict(value=k2 * g.input_size / el2 / 1e6, unit="Msamples/s", steps=k2, ms_per_step=el2 / k2 * 1e3,
+                      path="cf32 blocks in page-locked host RAM -> hfdl_gpu_frontend_prefetch_block_raw (copy stream, two HBM staging "
+                           "buffers, one block ahead) -> hfdl_gpu_frontend_push_block_raw -> same kernels; PCIe-inclusive",
+                      pcie_GBs=k2 * g.input_size * 8 / el2 / 1e9, pdus=sum(n for _, n in raw2))
+
+
+def cfg2_leg(torch, hf, F, dev_index, steps=256, warmup=8):
+    """BASELINE.json configs[1] (8 Msps x 32 channels, the demodulator-bound geometry) next to the headline workload, so that the
+    driver's line shows it: resident and host-RAM rates, the demodulator kernel's average from its own dispatch events, the
+    steady-state step against the HBM roofline, and every PDU checked against the sent traffic."""
+    w = WORKLOADS["cfg2"]
+    freqs = channel_plan(w)
+    fe = hf.Frontend(w["fs"], w["centerfreq"], freqs, device=dev_index)
+    g = fe.geometry
+    fe.enable_taps(False)
+    x, bursts = make_input(w, g.input_size, 0, 1)
+    nblocks = len(x) // g.input_size
+    by_freq = {}
+    for b in bursts:
+        by_freq.setdefault(b["freq"], []).append(b)
+    dev = torch.from_numpy(x.view(np.float32)).cuda()
+    ptrs = [dev.data_ptr() + 8 * b * g.input_size for b in range(nblocks)]
+    push = lambda i: fe.push_block(ptrs[i])
+    step = 0
+    for _ in range(warmup):
+        push(step % nblocks); step += 1
+    fe.poll_pdus()
+    fe.reset_timers(True)
+    torch.cuda.synchronize()
+    el, raw, step = timed_blocks(torch, fe, push, steps, step, nblocks)
+    pdus = [p for buf, n in raw for p in fe.pdus_to_dicts(buf, n)]
+    fold_ms, fold_n = fe.fold_time_ms()
+    dm_ms, dm_n = fe.demod_time_ms()
+    period = fe.step_period_ms()
+    fe.reset_timers(False)
+    hbuf, host = host_ram_leg(torch, hf, F, fe, x, g, nblocks, steps)
+    fe.close()
+    del dev
+    hf.host_free(hbuf)
+    ab = alg_bytes_per_block(g)
+    return dict(workload=w["name"], value=steps * g.input_size / el / 1e6, unit="Msamples/s", steps=steps, warmup=warmup, ms_per_step=el / steps * 1e3,
+                steady_state_ms_per_step=period, block_samples=g.input_size, channels=g.channels,
+                demod_kernel_avg_ms=(dm_ms / dm_n) if dm_n else None, demod_kernel_launches=dm_n,
+                fold_kernel_avg_ms=(fold_ms / fold_n) if fold_n else None,
+                algorithmic_bytes_per_block=ab,
+                whole_step_frac_of_hbm_peak=(ab / (period * 1e-3) / 1e9 / HBM_PEAK_GBS) if period else None,
+                bound="demod_kernel: a serial recurrence per channel (latency), not HBM",
+                pdus=len(pdus), pdus_matching_sent_payload=sum(1 for p in pdus if matches_sent(p, by_freq)),
+                pdus_lpdu_walk_matching_sent=sum(1 for p in pdus if lpdu_walk_matches_sent(p, by_freq)),
+                value_host_ram=host["value"], host_ram_input=host)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,12 +516,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and the same-run parity gate")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip host_ram_input / host_path / fec (profiling runs)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip host_ram_input / host_path / fec / cfg2 (profiling runs)")
     ap.add_argument("--host-input", action="store_true",
                     help="feed the TIMED blocks from page-locked HOST memory (PCIe-inclusive rate; then `value` is not the headline figure)")
     ap.add_argument("--sample-format", default="cf32", choices=["cf32", "cs16"], help="with --host-input: raw format pushed over PCIe")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for the barrier / final reduction at N > 1 (nccl = RCCL; gloo for a 1-GPU smoke of the N>1 path)")
+                    help="torch.distributed backend for the barrier / final reduction (nccl = RCCL; gloo for a 1-GPU smoke of the N>1 path)")
     ap.add_argument("--shard", default="streams", choices=["streams", "channels"],
                     help="N > 1: independent stream per rank (weak scaling, BASELINE configs[4]) or ONE stream with its channels split round-robin over the ranks (strong scaling, SURVEY 8e)")
     ap.add_argument("--dump-pdus", default=None, help="write this rank's PDU keys (freq, sample_index, mode, octets) to PATH.rankR.json")
@@ -389,15 +538,19 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     red_device = "cuda"
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group("gloo")
-            red_device = "cpu"
+    # launched by torch.distributed.run (any world size, 1 included): the process group is brought up and every barrier /
+    # reduction below runs through it, so the RCCL path executes on a 1-GPU box exactly as it will on 8
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    dist_info = None
+    if world > 1 or launched:
+        used, red_device, note = init_dist(torch, dist, args.backend, dev_index, world)
+        dist_info = dict(backend=used, requested=args.backend, world_size=world, fallback=note)
+        # all ranks build their filter taps on the host at once: share the cores
+        os.environ.setdefault("HFDL_GPU_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, world))))
     import dumphfdl_amd as hf
     from dumphfdl_amd import shard
     from dumphfdl_amd import frontend as F
+    use_dist = dist if dist_info else None
 
     all_freqs = channel_plan(w)
     freqs = shard.shard_channels(all_freqs, rank, world) if args.shard == "channels" else all_freqs
@@ -415,20 +568,9 @@ def main():
     for b in bursts:
         bursts_by_freq.setdefault(b["freq"], []).append(b)
 
-    def host_feed(fmt_name):
-        if fmt_name == "cs16":
-            raw = np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16)
-            fmt, bps = F.SFMT_CS16, 4
-        else:
-            raw, fmt, bps = x.view(np.float32), F.SFMT_CF32, 8
-        hbuf = hf.host_alloc(raw.nbytes)
-        ctypes.memmove(hbuf, raw.ctypes.data, raw.nbytes)
-        hptrs = [hbuf + bps * b * g.input_size for b in range(nblocks)]
-        return hbuf, (lambda i: fe.push_host_ptr(hptrs[i], fmt))
-
     hbuf = None
     if args.host_input:
-        hbuf, push = host_feed(args.sample_format)
+        hbuf, push, _ = host_feed(hf, F, fe, x, g, nblocks, args.sample_format)
         dev = None
     else:
         dev = torch.from_numpy(x.view(np.float32)).cuda()          # resident in HBM before the timed region
@@ -437,21 +579,9 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-
-    def timed_run(push_fn, steps, first_step):
-        step = first_step
-        raw = []
-        t_start = time.perf_counter()
-        for i in range(steps):
-            push_fn(step % nblocks); step += 1
-            if i % 256 == 255 and i + 1 < steps:      # long runs: empty the device PDU ring now and then, pipeline kept running
-                raw.append(fe.poll_pdus_raw(16384, max_in_flight=1))
-        raw.append(fe.poll_pdus_raw(16384))     # sync + device->host of every PDU struct produced by the timed blocks (what the C host gets)
-        torch.cuda.synchronize()
-        return time.perf_counter() - t_start, raw, step
 
     step = 0
     for _ in range(args.warmup):
@@ -459,12 +589,14 @@ def main():
     fe.poll_pdus()
     fe.reset_timers(True)
     barrier()
-    elapsed, raw, step = timed_run(push, args.steps, step)
+    elapsed, raw, step = timed_blocks(torch, fe, push, args.steps, step, nblocks)
     pdus = [p for buf, n in raw for p in fe.pdus_to_dicts(buf, n)]     # Python-side unpacking for the checks below: not part of the path
     npdus = len(pdus)
     fold_ms, fold_n = fe.fold_time_ms()
+    dm_ms, dm_n = fe.demod_time_ms()
     period_ms = fe.step_period_ms()
     barrier()
+    fe.reset_timers(False)
     good = sum(1 for p in pdus if matches_sent(p, bursts_by_freq))
     lpdu_ok = sum(1 for p in pdus if lpdu_walk_matches_sent(p, bursts_by_freq))
     lpdus_good = sum(p["lpdus"][1] for p in pdus)
@@ -472,9 +604,13 @@ def main():
     my_samples = args.steps * g.input_size
     if args.shard == "channels" and rank != 0:
         my_samples = 0                               # ONE stream: its samples count once
-    elapsed_max, total_samples, total_pdus = shard.reduce_job(elapsed, my_samples, npdus, dist, device=red_device)
-    total_good, total_trellis, total_lpdu_ok, total_lpdus = shard.reduce_sums([good, trellis, lpdu_ok, lpdus_good], dist, device=red_device)
-    seeds = shard.gather_ints(my_seed, dist, device=red_device)
+    elapsed_max, total_samples, total_pdus = shard.reduce_job(elapsed, my_samples, npdus, use_dist, device=red_device)
+    total_good, total_trellis, total_lpdu_ok, total_lpdus = shard.reduce_sums([good, trellis, lpdu_ok, lpdus_good], use_dist, device=red_device)
+    seeds = shard.gather_ints(my_seed, use_dist, device=red_device)
+    fold_avg_ms = fold_ms / max(fold_n, 1)
+    # every rank's own numbers, in rank order: a straggler GPU shows up here, not only in the max
+    per_rank_cols = shard.gather_floats([my_seed, elapsed / args.steps * 1e3, period_ms, fold_avg_ms, (dm_ms / dm_n) if dm_n else 0.0,
+                                         npdus, good, g.channels, t_create, t_gen], use_dist, device=red_device)
     if args.dump_pdus:
         json.dump(sorted(pdu_key(p) for p in pdus), open("%s.rank%d.json" % (args.dump_pdus, rank), "w"))
 
@@ -482,43 +618,50 @@ def main():
     extra = {}
     solo = world == 1 and rank == 0
     if solo and not args.no_extra_legs and not args.host_input:
-        hbuf, hpush = host_feed("cf32")
-        k2 = min(args.steps, 96)
-        for i in range(4):
-            hpush(i % nblocks)
-        fe.poll_pdus()
-        el2, raw2, _ = timed_run(hpush, k2, 4)
-        extra["host_ram_input"] = dict(value=k2 * g.input_size / el2 / 1e6, unit="Msamples/s", steps=k2, ms_per_step=el2 / k2 * 1e3,
-                                       path="cf32 blocks in page-locked host RAM -> hfdl_gpu_frontend_push_block (copy stream, two HBM staging "
-                                            "buffers) -> same kernels; PCIe-inclusive",
-                                       pcie_GBs=k2 * g.input_size * 8 / el2 / 1e9, pdus=sum(n for _, n in raw2))
+        hbuf, extra["host_ram_input"] = host_ram_leg(torch, hf, F, fe, x, g, nblocks, args.steps)
     stream_gbs = fe.stream_read_probe() if rank == 0 else None       # after the timed regions: the board's own read ceiling
     if solo and not args.no_extra_legs:
         extra["fec"] = fec_capacity(hf, dev_index)
+    geom = dict(channels=g.channels, fft_size=g.fft_size, fft_inv_size=g.fft_inv_size, input_size=g.input_size)
+    alg_bytes = alg_bytes_per_block(g)
+    # every rank releases its front end (16 GiB of filter taps each) before the legs that build others / before leaving
+    fe.close()
+    del dev
+    if hbuf:
+        hf.host_free(hbuf)
 
     if rank == 0:
         samples = total_samples
-        # B = 8*input_size + C*8*N + C*8*(post_input_size/post_decimation) algorithmic bytes per block
-        alg_bytes = 8 * g.input_size + g.channels * 8 * g.fft_size + g.channels * 8 * (g.post_input_size // g.post_decimation)
-        fold_avg_ms = fold_ms / max(fold_n, 1)
         achieved = alg_bytes / (fold_avg_ms * 1e-3) / 1e9 if fold_n else None
         traffic, traffic_src = traffic_record(args.workload)
-        par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, g.channels)) if args.shard == "streams" else \
+        par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, geom["channels"])) if args.shard == "streams" else \
               ("ONE %d-channel stream, channels round-robin over %d GPUs (%d on rank 0), every GPU ingests the same block; no collectives"
-               % (len(all_freqs), world, g.channels))
+               % (len(all_freqs), world, geom["channels"]))
+        names = ("stream_seed", "ms_per_step", "steady_state_ms_per_step", "fold_avg_ms", "demod_avg_ms", "pdus", "pdus_matching_sent_payload",
+                 "channels", "frontend_create_s", "input_synthesis_s")
+        per_rank = [dict([("rank", r)] + [(n, (int(v) if n in ("stream_seed", "pdus", "pdus_matching_sent_payload", "channels") else round(v, 4)))
+                                           for n, v in zip(names, row)]) for r, row in enumerate(per_rank_cols)]
+        host_ram_value = extra.get("host_ram_input", {}).get("value")
         out = {
             "metric": "wideband I/Q Msamples/s (cf32 ingest -> decoded HFDL PDUs) at fixed channel count",
             "value": samples / elapsed_max / 1e6, "unit": "Msamples/s",
+            # which of SURVEY.md 8(d)'s two regimes `value` is, and the other one next to it as a first-class key
+            "value_definition": ("input resident in HBM before the timed region (the bench contract's definition); SURVEY.md 8(d) quotes the "
+                                 "metric with the input pre-loaded in HOST RAM: that PCIe-inclusive figure is `value_host_ram`") if not args.host_input
+                                else "input in page-locked host RAM, PCIe-inclusive (--host-input): SURVEY.md 8(d)'s own definition; not the HBM-resident headline",
+            "value_host_ram": (samples / elapsed_max / 1e6) if args.host_input else host_ram_value,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if args.shard == "streams" else "strong", "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic, resident in HBM before the timed region" if not args.host_input
                     else "synthetic, fed from page-locked host memory as %s (PCIe-inclusive)" % args.sample_format,
-            "config": {"workload": w["name"], "sample_rate": w["fs"], "channels": len(all_freqs) if args.shard == "channels" else g.channels,
-                       "channels_rank0": g.channels, "fft_size": g.fft_size,
-                       "fft_inv_size": g.fft_inv_size, "block_samples": g.input_size, "resident_blocks": nblocks,
+            "config": {"workload": w["name"], "sample_rate": w["fs"], "channels": len(all_freqs) if args.shard == "channels" else geom["channels"],
+                       "channels_rank0": geom["channels"], "fft_size": geom["fft_size"],
+                       "fft_inv_size": geom["fft_inv_size"], "block_samples": geom["input_size"], "resident_blocks": nblocks,
                        "stream_seeds": seeds, "shard": args.shard, "parallelism": par},
+            "distributed": dist_info,
+            "per_rank": per_rank,
             "frames_per_s": total_pdus / elapsed_max, "pdus_in_timed_region": total_pdus,
             "pdus_matching_sent_payload": total_good,
             "pdus_lpdu_walk_matching_sent": total_lpdu_ok,      # device-side parse_lpdu_list + per-LPDU FCS = what was sent
@@ -528,29 +671,31 @@ def main():
             "steady_state_ms_per_step": period_ms,
             "fill_drain_ms": max(0.0, elapsed * 1e3 - period_ms * args.steps) if period_ms else None,
             "trellis_steps_per_s_in_run": total_trellis / elapsed_max,
+            "demod_kernel_avg_ms": (dm_ms / dm_n) if dm_n else None,
             "roofline": {"bound": "hbm", "kernel": "fold_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n,
-                         "literal_bytes_per_launch": 16 * g.fft_size * (g.channels + 1),      # SURVEY 8(d) secondary figure
+                         "literal_bytes_per_launch": 16 * geom["fft_size"] * (geom["channels"] + 1),      # SURVEY 8(d) secondary figure
                          "stream_read_GBs": stream_gbs,
                          "frac_of_stream_read": (achieved / stream_gbs) if (achieved and stream_gbs) else None,
                          "whole_step_frac": (alg_bytes / (period_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if period_ms else None},
             "setup_s": {"frontend_create": round(t_create, 2), "input_synthesis": round(t_gen, 2)},
         }
         out.update(extra)
-        fe.close()
-        del dev
-        if hbuf:
-            hf.host_free(hbuf)
         if solo and not args.no_extra_legs:
             out["host_path"] = host_path_leg(w, x, all_freqs, "CF32", dev_index)
+            if args.workload != "cfg2" and not args.host_input:
+                try:
+                    out["cfg2"] = cfg2_leg(torch, hf, F, dev_index)
+                except Exception as e:                  # noqa: BLE001 -- a secondary leg never takes the headline line down
+                    out["cfg2"] = dict(error="%s: %s" % (type(e).__name__, e))
         if solo and not args.no_cpu_baseline:
             cores = max(1, min(os.cpu_count() or 1, 64))
-            out["parity"] = parity_gate(w, x, g.input_size, hf, dev_index, cores)
-            out["cpu_baseline"] = cpu_baseline(w, x, g.input_size)
+            out["parity"] = parity_gate(w, x, geom["input_size"], hf, dev_index, cores)
+            out["cpu_baseline"] = cpu_baseline(w, x, geom["input_size"])
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -38,7 +38,7 @@ struct Demod {
 	int init(int nch, int outs, float resamp_rate, const int32_t *freqs, hipStream_t st);
 	// K4 of a block.  `done` (optional) is signalled by the kernel's own dispatch packet.  frames_free: the caller has already
 	// ordered this launch after the decoder of launch i-2 (frames_free_event()), so no wait is queued in front of the kernel.
-	int enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st, hipEvent_t done = nullptr, bool frames_free = false);
+	int enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st, hipEvent_t done = nullptr, bool frames_free = false, hipEvent_t start = nullptr);
 	hipEvent_t frames_free_event() const { return separate_decode ? ev_dec[launches & 1] : nullptr; }   // of the NEXT launch; may be null
 	int enqueue_decode(int buf, hipStream_t st);                                              // K5 + PDU-ring snapshot of the same block
 	int collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);                    // stream idle: everything produced

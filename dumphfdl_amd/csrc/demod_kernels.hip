@@ -605,7 +605,7 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 // burst decoder of launch i may run on another stream than the demodulator of launch i+1; it zeroes the counter of launch i+2,
 // whose previous users (launch i-2) are done and whose next user (the demodulator of launch i+2) is made to wait for this
 // decoder by the caller -- no memset launch per block, no counter shared by two kernels that can overlap.
-int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st, hipEvent_t done, bool frames_free)
+int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st, hipEvent_t done, bool frames_free, hipEvent_t start)
 {
 	DemodPriv *pv = priv_of(this);
 	if (!pv) return HFDL_GPU_EINVAL;
@@ -620,8 +620,8 @@ int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int buf, 
 	const bool tw = taps_on && taps_enabled;
 	B.tap_rs = tw ? (cf *)d_tap_rs : nullptr; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
 	B.cap = cap;
-	if (tw) hipExtLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, nullptr, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs);
-	else hipExtLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, nullptr, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs);
+	if (tw) hipExtLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, start, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs);
+	else hipExtLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, start, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs);
 	D_TRY(hipGetLastError());
 	return 0;
 }
@@ -705,6 +705,11 @@ static void fill_stats(const ChanScalars &sc, hfdl_gpu_channel_stats *out)
 	out->costas_dphi = sc.dphi;
 	out->framer_state = sc.fr_state;
 	out->sample_cnt = sc.sample_cnt; out->symbol_cnt = sc.symbol_cnt;
+	out->a1_found = sc.cnt_a1_found;
+	out->a1_corr_avg = sc.cnt_a1_found ? (float)sc.sum_a1_dev / 127.0f / (float)sc.cnt_a1_found : 0.f;
+	out->a2_corr_avg = sc.cnt_a2_found ? (float)sc.sum_a2_dev / 127.0f / (float)sc.cnt_a2_found : 0.f;
+	out->m1_corr_avg = sc.cnt_m1_found ? (float)sc.sum_m1_dev / 127.0f / (float)sc.cnt_m1_found : 0.f;
+	out->train_bits_bad = sc.cum_train_bad; out->train_bits_total = sc.cum_train_total;
 }
 
 int Demod::stats(int channel, hfdl_gpu_channel_stats *out)

@@ -57,6 +57,9 @@ struct ChanScalars {
 	float frame_symbol_cnt, freq_err_hz, signal_level, noise_floor;
 	// observability: the per-channel StatsD counters of the reference's hot path (src/hfdl.c:818,828,840; doc/STATSD_METRICS.md)
 	uint32_t cnt_a2_found, cnt_m1_found, cnt_m1_not_found, cnt_frames;
+	// the reference's debug summary (hfdl_print_summary, src/hfdl.c:563-573): A1 detections, the correlation magnitudes at the three
+	// detections as sums of |2 m - 127| over match counts m (|corr| = that / 127), training bits over all frames
+	uint32_t cnt_a1_found, sum_a1_dev, sum_a2_dev, sum_m1_dev, cum_train_bad, cum_train_total;
 	uint32_t ev_flags;             // EV_*: resets that happened inside on_symbol(), for the register-resident device windows
 };
 enum { EV_SS_RESET = 1, EV_EQ_RESET = 2 };
@@ -415,6 +418,8 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 		// |corr| > 0.36 on the fp32 table == a match count outside (a1_lo, a1_hi): no table look-up on the every-symbol path
 		const int m = bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo);
 		if (m <= T.a1_lo || m >= T.a1_hi) {
+			c.cnt_a1_found++;                    // S.A1_found / S.A1_corr_total, :786-787
+			c.sum_a1_dev += (uint32_t)(2 * m > 127 ? 2 * m - 127 : 127 - 2 * m);
 			s.bitmask = m >= T.pos_min ? 0u : ~0u;
 			s.signal_level = level;
 			s.frame_symbol_cnt = 1.0f;
@@ -427,6 +432,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 		const int m = bits_correlate(s.bits_hi, s.bits_lo, T.a_hi, T.a_lo);
 		if (m <= T.a2_lo || m >= T.a2_hi) {
 			c.cnt_a2_found++;                    // statsd "demod.preamble.A2_found"
+			c.sum_a2_dev += (uint32_t)(2 * m > 127 ? 2 * m - 127 : 127 - 2 * m);
 			c.pdu_sample_index = s.sample_cnt;
 			c.freq_err_hz = (float)((double)(s.dphi * 1800) / (2.0 * M_PI));
 			s.symbols_wanted = M1_LEN;
@@ -438,14 +444,16 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 		break; }
 	case FR_M1: {
 		float best = 0.f;
-		int best_idx = -1;
+		int best_idx = -1, best_cnt = 0;
 		for (int m = 0; m < 8; m++) {
-			const float corr = fabsf(T.corr_tab[bits_correlate(s.bits_hi, s.bits_lo, T.m1_hi[m], T.m1_lo[m])]);
-			if (corr > best) { best = corr; best_idx = m; }
+			const int cnt = bits_correlate(s.bits_hi, s.bits_lo, T.m1_hi[m], T.m1_lo[m]);
+			const float corr = fabsf(T.corr_tab[cnt]);
+			if (corr > best) { best = corr; best_idx = m; best_cnt = cnt; }
 		}
 		if (fabsf(best) > 0.3f) {
 			const ModeParams mp = mode_params(best_idx);
 			c.cnt_m1_found++;                    // "demod.preamble.M1_found"
+			c.sum_m1_dev += (uint32_t)(2 * best_cnt > 127 ? 2 * best_cnt - 127 : 127 - 2 * best_cnt);
 			c.data_segment_cnt = mp.segments;
 			c.data_arity = mp.arity;
 			c.M1 = best_idx;
@@ -473,8 +481,11 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 			bit ^= (s.bitmask & 1u);
 			seq = (seq << 1) | bit;
 		}
+		const int train_err = __popc(0x9AFu ^ seq);
 		c.train_total += T_LEN;
-		c.train_bad += __popc(0x9AFu ^ seq);
+		c.train_bad += train_err;
+		c.cum_train_total += T_LEN;              // S.train_bits_total / S.train_bits_bad, :962-963
+		c.cum_train_bad += (uint32_t)train_err;
 		s.training_n = 0;
 		if (c.eq_train_seq_cnt > 1) {
 			c.eq_train_seq_cnt--;

@@ -12,7 +12,11 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 // In-place radix-4 (+ final radix-2) DIF over `ncols` columns held as s[r * pitch + col].
 // On exit position p of a column holds X[bitrev(p)].  DIR = -1 forward, +1 backward (unnormalised).
 // tw[t] = exp(-2 pi i t / R).
-template <int DIR>
+// SKEW: the columns of row r are rotated by r inside the row (element (r, col) at r * pitch + ((col + r) & cols_mask), pitch = number
+// of columns).  A row still fills one aligned run, so the stages' accesses (16 adjacent columns of a row per lane group) stay
+// conflict-free, and a tile FILLED row-major along r (pass 3: consecutive lanes = consecutive r of one column, 128 bytes apart ->
+// every ds_write_b64 lane group on one bank pair, a 16-way conflict) spreads over all banks.
+template <int DIR, bool SKEW = false>
 __device__ void lds_fft_columns(float2 *s, int R, int logR, int pitch, int log_cols, const float2 *tw)
 {
 	const int cols_mask = (1 << log_cols) - 1;
@@ -24,9 +28,14 @@ __device__ void lds_fft_columns(float2 *s, int R, int logR, int pitch, int log_c
 		for (int t = threadIdx.x; t < nb; t += blockDim.x) {
 			const int col = t & cols_mask, b = t >> log_cols;
 			const int j = b & (q - 1), blk = b >> logq;
-			float2 *p = s + (size_t)((blk << loglen) + j) * pitch + col;
+			const int r0 = (blk << loglen) + j;
+			float2 *p = s + (size_t)r0 * pitch + (SKEW ? 0 : col);
 			const int qs = q * pitch;
-			float2 a = p[0], bb = p[qs], c = p[2 * qs], d = p[3 * qs];
+			// SKEW: the four rows r0 + k q hold the column at (col + r0 + k q) & mask
+			const int c0 = SKEW ? ((col + r0) & cols_mask) : 0, c1 = SKEW ? ((col + r0 + q) & cols_mask) : qs;
+			const int c2 = SKEW ? (2 * qs + ((col + r0 + 2 * q) & cols_mask)) : 2 * qs, c3 = SKEW ? (3 * qs + ((col + r0 + 3 * q) & cols_mask)) : 3 * qs;
+			const int c1s = SKEW ? qs + c1 : c1;
+			float2 a = p[c0], bb = p[c1s], c = p[c2], d = p[c3];
 			float2 w1 = tw[j * tstep], w2 = tw[2 * j * tstep], w3 = tw[3 * j * tstep];
 			if (DIR > 0) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
 			float2 apc = make_float2(a.x + c.x, a.y + c.y), amc = make_float2(a.x - c.x, a.y - c.y);
@@ -38,7 +47,7 @@ __device__ void lds_fft_columns(float2 *s, int R, int logR, int pitch, int log_c
 			float2 y1 = cmul(make_float2(amc.x + jb.x, amc.y + jb.y), w1);
 			float2 y3 = cmul(make_float2(amc.x - jb.x, amc.y - jb.y), w3);
 			// order y0,y2,y1,y3 == two radix-2 DIF stages, so the final permutation is a plain bit reversal
-			p[0] = y0; p[qs] = y2; p[2 * qs] = y1; p[3 * qs] = y3;
+			p[c0] = y0; p[c1s] = y2; p[c2] = y1; p[c3] = y3;
 		}
 		__syncthreads();
 		len = q; loglen = logq;
@@ -47,10 +56,11 @@ __device__ void lds_fft_columns(float2 *s, int R, int logR, int pitch, int log_c
 		const int nb = (R >> 1) << log_cols;
 		for (int t = threadIdx.x; t < nb; t += blockDim.x) {
 			const int col = t & cols_mask, b = t >> log_cols;
-			float2 *p = s + (size_t)(2 * b) * pitch + col;
-			float2 a = p[0], bb = p[pitch];
-			p[0] = make_float2(a.x + bb.x, a.y + bb.y);
-			p[pitch] = make_float2(a.x - bb.x, a.y - bb.y);
+			float2 *p = s + (size_t)(2 * b) * pitch + (SKEW ? 0 : col);
+			const int c0 = SKEW ? ((col + 2 * b) & cols_mask) : 0, c1 = pitch + (SKEW ? ((col + 2 * b + 1) & cols_mask) : 0);
+			float2 a = p[c0], bb = p[c1];
+			p[c0] = make_float2(a.x + bb.x, a.y + bb.y);
+			p[c1] = make_float2(a.x - bb.x, a.y - bb.y);
 		}
 		__syncthreads();
 	}

@@ -123,12 +123,12 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restric
 			const int k2 = cc >> p.l1, k1 = cc & (p.r1 - 1);
 			v = in[(size_t)k1 * r23 + (size_t)k2 * p.r3 + n3];
 		}
-		sm[n3 * FFT_TILE + col] = v;
+		sm[n3 * FFT_TILE + ((col + n3) & (FFT_TILE - 1))] = v;      // row-skewed tile (fft_core.h): this transposing fill is conflict-free
 	}
 	float2 *ltw = sm + total;
 	for (int t = threadIdx.x; t < p.r3; t += FFT_THREADS) ltw[t] = p.tw3[t];
 	__syncthreads();
-	lds_fft_columns<-1>(sm, p.r3, p.l3, FFT_TILE, FFT_TILE_LOG, ltw);
+	lds_fft_columns<-1, true>(sm, p.r3, p.l3, FFT_TILE, FFT_TILE_LOG, ltw);
 	const unsigned half = shifted ? (unsigned)(p.n >> 1) : 0u;
 	for (int e = threadIdx.x; e < total; e += FFT_THREADS) {
 		const int k3 = e >> FFT_TILE_LOG, col = e & (FFT_TILE - 1);
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restric
 		const unsigned k = (unsigned)k1 + ((unsigned)k2 << p.l1) + ((unsigned)k3 << (p.l1 + p.l2));
 		const unsigned i = (k + half) & (unsigned)(p.n - 1);
 		const size_t at = lay.row_log ? (size_t)(i >> lay.row_log) * (size_t)lay.row_stride + (i & ((1u << lay.row_log) - 1u)) : (size_t)i;
-		out[at] = sm[bitrev(k3, p.l3) * FFT_TILE + col];
+		const int r = bitrev(k3, p.l3);
+		out[at] = sm[r * FFT_TILE + ((col + r) & (FFT_TILE - 1))];
 	}
 }
 

@@ -278,13 +278,20 @@ void launch_nco_decimate(const float2 *in, int input_size, float cd, float sd, f
 	hipLaunchKernelGGL(nco_decimate_kernel, dim3(1), dim3(IFFT_THREADS), 0, st, in, input_size, cd, sd, rate, q, state, ph, out);
 }
 
+// once per front end: an inverse FFT of 8192 points needs more than the default 64 KiB of dynamic LDS
+hipError_t prepare_ifft_nco(int m)
+{
+	const size_t lds = sizeof(float2) * ((size_t)m + 1);
+	if (lds <= 64 * 1024) return hipSuccess;
+	return hipFuncSetAttribute((const void *)ifft_nco_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco, const float2 *ph,
 		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st, hipEvent_t done)
 {
 	int logm = 0;
 	while ((1 << logm) < g.m) logm++;
 	size_t lds = sizeof(float2) * ((size_t)g.m + 1);
-	if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)ifft_nco_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	hipExtLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(IFFT_THREADS), (unsigned)lds, st, nullptr, done, 0, partial, cc, nco, ph, tw_m, chan_out, out_count, g, logm);
 }
 

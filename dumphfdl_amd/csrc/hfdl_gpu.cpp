@@ -116,6 +116,10 @@ struct hfdl_gpu_frontend {
 	hipStream_t stream_d = nullptr;     // D: burst decoder + PDU snapshot when the demodulator bounds the block (few channels); else == stream_b
 	bool own_decode_stream = false;
 	hipEvent_t ev_dm[2] = { nullptr, nullptr };      // demodulator kernel of the block in buffer 0 / 1 done (chan_out free; the decoder may start)
+	hipEvent_t ev_dm_cur[2] = { nullptr, nullptr };  // the event that stands for it now: ev_dm[i], or (timing on) the stop event of a timed pair
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_dmt;      // timed demodulator launches not yet read
+	double demod_ms = 0;
+	int64_t demod_launches = 0;
 	hipStream_t stream_c = nullptr;     // C: host -> device copies of block k+1 into the other staging buffer
 	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
 	hipEvent_t ev_stage_ready[2] = { nullptr, nullptr }, ev_stage_free[2] = { nullptr, nullptr };
@@ -142,6 +146,7 @@ struct hfdl_gpu_frontend {
 	// fold timing
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;      // timing events made by reset_timers(), outside any timed region
 	double fold_ms = 0;
 	int64_t fold_launches = 0;
 	hipEvent_t ev_first_fold = nullptr;  // start of the first timed fold since reset_timers: anchor of the steady-state step period
@@ -167,6 +172,8 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	for (int i = 0; i < 2; i++)
 		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_dm[i], fe->ev_stage_ready[i], fe->ev_stage_free[i], fe->ev_copy[i], fe->ev_copy[i + 2] }) if (e) (void)hipEventDestroy(e);
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+	for (auto &e : fe->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+	for (auto &e : fe->ev_dmt) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	if (fe->ev_fft) (void)hipEventDestroy(fe->ev_fft);
 	if (fe->ev_first_fold) (void)hipEventDestroy(fe->ev_first_fold);
 	fe->demod.release();
@@ -202,6 +209,10 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	std::vector<std::complex<float>> host((size_t)nch * (size_t)pl.taps_length);
 	fe->cc.resize((size_t)nch);
 	unsigned nthreads = std::max(1u, std::min((unsigned)nch, std::thread::hardware_concurrency()));
+	if (const char *e = getenv("HFDL_GPU_HOST_THREADS")) {      // several front ends created at once on one host (one process per GPU): share the cores
+		const long v = strtol(e, nullptr, 10);
+		if (v >= 1) nthreads = std::min(nthreads, (unsigned)v);
+	}
 	std::atomic<int> next{0};
 	std::atomic<int> bad{0};
 	auto work = [&]() {
@@ -336,6 +347,11 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 		if ((rc = upload_twiddles(pl.m, &tw))) { frontend_free(fe); return rc; }
 		fe->d_tw_m = tw;
 	}
+	if (prepare_ifft_nco(pl.m) != hipSuccess) {
+		rc = fail(HFDL_GPU_EHIP, "inverse FFT of %d points: LDS attribute refused: %s", pl.m, hipGetErrorString(hipGetLastError()));
+		frontend_free(fe);
+		return rc;
+	}
 	if ((rc = build_taps(fe))) { frontend_free(fe); return rc; }
 	FE_TRY(hipMemcpy(fe->d_cc, fe->cc.data(), sizeof(ChanConst) * (size_t)nch, hipMemcpyHostToDevice));
 	float resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)fe->decimation);
@@ -449,7 +465,12 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 	if (nsamples != (size_t)fe->plan.input_size)
 		return fail(HFDL_GPU_EINVAL, "a block is exactly %d samples (got %zu)", fe->plan.input_size, nsamples);
 	HIP_TRY(hipSetDevice(fe->device));
-	if (on_device) { *dev = iq; return 0; }
+	if (on_device) {
+		// the prefetched host block is numbered and staged: a device block slipped in front of it would be processed out of order
+		if (fe->prefetched != nullptr) return fail(HFDL_GPU_EINVAL, "a prefetched block is pending: push it or call hfdl_gpu_frontend_prefetch_cancel()");
+		*dev = iq;
+		return 0;
+	}
 	int sb;
 	if (fe->prefetched != nullptr) {
 		// the copy of this block was queued ahead by hfdl_gpu_frontend_prefetch_block_raw()
@@ -479,10 +500,19 @@ static int launch_demod(hfdl_gpu_frontend *fe, int buf, bool after_fft)
 	else HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
 	// ev_dm rides on the kernel's dispatch; with the decoder on its own stream the channelizer has already waited for the frame
 	// queue (enqueue_channelizer), so on the demodulator-bound geometries ONE barrier packet separates consecutive demodulators
-	int rc = fe->demod.enqueue_demod(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b, fe->ev_dm[buf], fe->frames_wait_on_a);
+	hipEvent_t t_start = nullptr, done = fe->ev_dm[buf];
+	if (fe->timing && !fe->ev_pool.empty()) {
+		// the kernel's own start / stop events (no extra packet): the stop event doubles as this launch's "done" event
+		std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
+		fe->ev_pool.pop_back();
+		t_start = e.first; done = e.second;
+		fe->ev_dmt.push_back(e);
+	}
+	fe->ev_dm_cur[buf] = done;
+	int rc = fe->demod.enqueue_demod(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b, done, fe->frames_wait_on_a, t_start);
 	fe->frames_wait_on_a = false;
 	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
-	if (fe->own_decode_stream) HIP_TRY(hipStreamWaitEvent(fe->stream_d, fe->ev_dm[buf], 0));
+	if (fe->own_decode_stream) HIP_TRY(hipStreamWaitEvent(fe->stream_d, done, 0));
 	rc = fe->demod.enqueue_decode(buf, fe->stream_d);
 	if (rc) return fail(rc, "burst decoder enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_d));
@@ -522,14 +552,19 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 	if (stage_idx >= 0) HIP_TRY(hipEventRecord(fe->ev_stage_free[stage_idx], fe->stream));   // input consumed: the copy stream may refill it
 	if (fe->timing) {
 		std::pair<hipEvent_t, hipEvent_t> e;
-		HIP_TRY(hipEventCreate(&e.first));
-		HIP_TRY(hipEventCreate(&e.second));
+		if (!fe->ev_pool.empty()) {                 // made by reset_timers(): no event creation between the timed launches
+			e = fe->ev_pool.back();
+			fe->ev_pool.pop_back();
+		} else {
+			HIP_TRY(hipEventCreate(&e.first));
+			HIP_TRY(hipEventCreate(&e.second));
+		}
 		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream, e.first, e.second);
 		fe->ev.push_back(e);
 	} else {
 		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
 	}
-	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm[buf], 0));          // chan_out[buf] is free once demod(k-2) has read it
+	if (fe->ev_dm_cur[buf]) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm_cur[buf], 0));          // chan_out[buf] is free once demod(k-2) has read it
 	if (with_demod && fe->own_decode_stream) {
 		// this block's demodulator (launched right after this kernel, on stream B) reuses the frame queue the decoder of two
 		// launches ago read: wait for it HERE, where the stream has slack, instead of in front of the demodulator
@@ -594,14 +629,23 @@ static int drain_events(hfdl_gpu_frontend *fe)
 		fe->fold_launches++;
 		if (!fe->ev_first_fold) {
 			fe->ev_first_fold = e.first;            // kept until the next reset
+			HIP_TRY(hipEventCreate(&e.first));
 		} else {
 			HIP_TRY(hipEventElapsedTime(&ms, fe->ev_first_fold, e.first));
 			fe->span_ms = ms;
-			(void)hipEventDestroy(e.first);
 		}
-		(void)hipEventDestroy(e.second);
+		fe->ev_pool.push_back(e);                   // both events are complete: reused by later launches
 	}
 	fe->ev.clear();
+	for (auto &e : fe->ev_dmt) {
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+		fe->demod_ms += ms;
+		fe->demod_launches++;
+		fe->ev_pool.push_back(e);
+	}
+	fe->ev_dmt.clear();
+	fe->ev_dm_cur[0] = fe->ev_dm[0]; fe->ev_dm_cur[1] = fe->ev_dm[1];      // everything is complete: the pooled events may be reused
 	return 0;
 }
 
@@ -655,14 +699,35 @@ extern "C" int hfdl_gpu_frontend_prefetch_block_raw(hfdl_gpu_frontend *fe, const
 	return 0;
 }
 
+extern "C" int hfdl_gpu_frontend_prefetch_cancel(hfdl_gpu_frontend *fe)
+{
+	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (fe->prefetched == nullptr) return 0;
+	HIP_TRY(hipSetDevice(fe->device));
+	// the copy is in flight on stream C: let it finish (the caller gets its buffer back), then forget the block.  It keeps its host
+	// block number -- input_done_upto() of that number returns at once -- and its staging buffer is simply refilled by the next
+	// copy: ev_stage_free of that buffer was last recorded by the block that used it before, which stream C has already waited for.
+	HIP_TRY(hipStreamSynchronize(fe->stream_c));
+	fe->prefetched = nullptr; fe->prefetched_sb = -1;
+	return 0;
+}
+
 extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
 	fe->fold_ms = 0; fe->fold_launches = 0; fe->timing = enable != 0;
+	fe->demod_ms = 0; fe->demod_launches = 0;
 	if (fe->ev_first_fold) { (void)hipEventDestroy(fe->ev_first_fold); fe->ev_first_fold = nullptr; }
 	fe->span_ms = 0;
+	// enough event pairs for the launches between two drains (a sync / poll recycles them): created here, not in the timed loop
+	while (enable && fe->ev_pool.size() < 640) {
+		std::pair<hipEvent_t, hipEvent_t> e;
+		HIP_TRY(hipEventCreate(&e.first));
+		HIP_TRY(hipEventCreate(&e.second));
+		fe->ev_pool.push_back(e);
+	}
 	return 0;
 }
 
@@ -705,6 +770,16 @@ extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *tot
 	if (rc) return rc;
 	if (total_ms) *total_ms = fe->fold_ms;
 	if (launches) *launches = fe->fold_launches;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches)
+{
+	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	if (total_ms) *total_ms = fe->demod_ms;
+	if (launches) *launches = fe->demod_launches;
 	return 0;
 }
 

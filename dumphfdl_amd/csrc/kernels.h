@@ -75,6 +75,7 @@ void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh,
 // optional events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL): no separate barrier packets in the queue
 void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st,
 		hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+hipError_t prepare_ifft_nco(int m);     // LDS attribute of the inverse-FFT kernel for this size (checked at create time)
 // `ph`: the block's phasor table [outs][nch] (NcoJob riders of the forward FFT)
 void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco, const float2 *ph,
 		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st, hipEvent_t done = nullptr);

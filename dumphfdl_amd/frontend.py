@@ -40,7 +40,9 @@ class Pdu(C.Structure):
 class ChannelStats(C.Structure):
     _fields_ = [("freq", C.c_int32), ("a2_found", C.c_uint32), ("m1_found", C.c_uint32), ("m1_not_found", C.c_uint32),
                 ("frames", C.c_uint32), ("noise_floor_db", C.c_float), ("agc_level", C.c_float), ("costas_dphi", C.c_float),
-                ("framer_state", C.c_int32), ("sample_cnt", C.c_uint64), ("symbol_cnt", C.c_uint64)]
+                ("framer_state", C.c_int32), ("sample_cnt", C.c_uint64), ("symbol_cnt", C.c_uint64),
+                ("a1_found", C.c_uint32), ("a1_corr_avg", C.c_float), ("a2_corr_avg", C.c_float), ("m1_corr_avg", C.c_float),
+                ("train_bits_bad", C.c_uint32), ("train_bits_total", C.c_uint32)]
 
 
 class FrontendCounters(C.Structure):
@@ -59,8 +61,8 @@ EXPORTS = [
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_input_done_upto", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
-    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
-    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk", "hfdl_gpu_frontend_prefetch_block_raw", "hfdl_gpu_psk_slice",
+    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_demod_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
+    "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk", "hfdl_gpu_frontend_prefetch_block_raw", "hfdl_gpu_frontend_prefetch_cancel", "hfdl_gpu_psk_slice",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
 
@@ -103,6 +105,7 @@ def load():
     L.hfdl_gpu_frontend_enable_taps.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_frontend_channel_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ChannelStats)]
     L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.hfdl_gpu_frontend_demod_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_frontend_stream_read_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.hfdl_gpu_fft_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
@@ -117,6 +120,7 @@ def load():
     L.hfdl_gpu_lpdu_walk.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.hfdl_gpu_psk_slice.argtypes = [C.c_int, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.hfdl_gpu_frontend_prefetch_block_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hfdl_gpu_frontend_prefetch_cancel.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -201,6 +205,9 @@ class Frontend:
         """Queue the copy of the block that push_host_ptr(ptr, sample_format) will push next."""
         _check(load().hfdl_gpu_frontend_prefetch_block_raw(self._h, C.c_void_p(ptr), self.geometry.input_size, sample_format))
 
+    def prefetch_cancel(self):
+        _check(load().hfdl_gpu_frontend_prefetch_cancel(self._h))
+
     def input_done(self):
         _check(load().hfdl_gpu_frontend_input_done(self._h))
 
@@ -273,6 +280,12 @@ class Frontend:
         ms = C.c_double(0)
         n = C.c_int64(0)
         _check(load().hfdl_gpu_frontend_fold_time_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def demod_time_ms(self):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        _check(load().hfdl_gpu_frontend_demod_time_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def step_period_ms(self):

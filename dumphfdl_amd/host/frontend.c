@@ -135,12 +135,26 @@ static void publish_counters(hfdl_gpu_frontend *fe, hfdl_gpu_channel_stats *now,
 	pthread_mutex_unlock(&g_obs.lock);
 }
 
+/* the reference's debug summary, same lines (src/hfdl.c:563-573): totals over all channels from the newest device snapshot; the
+ * correlation averages are weighted by each channel's detection count, as one global S.A1_corr_total / S.A1_found is */
 void hfdl_print_summary(void)
 {
 #ifdef DEBUG
 	pthread_mutex_lock(&g_obs.lock);
-	fprintf(stderr, "A2_found:\t\t%llu\nM1_found:\t\t%llu\nM1_not_found:\t\t%llu\nframes:\t\t\t%llu\n",
-			(unsigned long long)g_obs.a2, (unsigned long long)g_obs.m1, (unsigned long long)g_obs.m1_missing, (unsigned long long)g_obs.frames);
+	uint64_t a1 = 0, a2 = 0, m1 = 0, bad = 0, total = 0;
+	double c1 = 0, c2 = 0, cm = 0;
+	for (int32_t i = 0; i < g_obs.cnt; i++) {
+		const hfdl_gpu_channel_stats *s = &g_obs.last[i];
+		a1 += s->a1_found; a2 += s->a2_found; m1 += s->m1_found;
+		c1 += (double)s->a1_corr_avg * s->a1_found; c2 += (double)s->a2_corr_avg * s->a2_found; cm += (double)s->m1_corr_avg * s->m1_found;
+		bad += s->train_bits_bad; total += s->train_bits_total;
+	}
+	fprintf(stderr, "A1_found:\t\t%llu\nA2_found:\t\t%llu\nM1_found:\t\t%llu\n", (unsigned long long)a1, (unsigned long long)a2, (unsigned long long)m1);
+	fprintf(stderr, "A1_corr_avg:\t\t%4.3f\n", a1 > 0 ? c1 / (double)a1 : 0.0);
+	fprintf(stderr, "A2_corr_avg:\t\t%4.3f\n", a2 > 0 ? c2 / (double)a2 : 0.0);
+	fprintf(stderr, "M1_corr_avg:\t\t%4.3f\n", m1 > 0 ? cm / (double)m1 : 0.0);
+	fprintf(stderr, "train_bits_bad/total:\t%llu/%llu (%f%%)\n", (unsigned long long)bad, (unsigned long long)total,
+			(float)bad / (float)total * 100.f);
 	pthread_mutex_unlock(&g_obs.lock);
 #endif
 }
@@ -281,13 +295,20 @@ static void *frontend_thread(void *ctx)
 			 * prefetched block was peeked as one contiguous run.) */
 			while (leased > 0) {
 				pthread_mutex_unlock(ring->mutex);
-				hfdl_gpu_frontend_input_done_upto(fe, uploads - leased);
+				/* a slot goes back only when the DMA engine is known to be done with it; if that cannot be established, wait for
+				 * every copy instead of handing the producer memory that may still be read */
+				if (hfdl_gpu_frontend_input_done_upto(fe, uploads - leased) != 0 && hfdl_gpu_frontend_input_done(fe) != 0) {
+					fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
+					do_exit = 1;
+					ok = 0;
+				}
 				pthread_mutex_lock(ring->mutex);
+				if (!ok) break;
 				hfdl_ring_drop(ring->buf, need);
 				leased--;
 			}
-			if (bounce == NULL) bounce = hfdl_xcalloc(need, sizeof(float complex));
-			if (hfdl_ring_read(ring->buf, bounce, need) != need) {      /* only a cf32 ring can be copied out of */
+			if (ok && bounce == NULL) bounce = hfdl_xcalloc(need, sizeof(float complex));
+			if (ok && hfdl_ring_read(ring->buf, bounce, need) != need) {      /* only a cf32 ring can be copied out of */
 				fprintf(stderr, "GPU front end: input ring holds raw samples in blocks that are not contiguous\n");
 				do_exit = 1;
 				ok = 0;
@@ -334,7 +355,14 @@ static void *frontend_thread(void *ctx)
 		 * idles on this thread; without a backlog the pipeline was drained above and everything is free. */
 		const size_t keep = backlog ? (prefetched ? 2u : 1u) : 0u;
 		while (leased > keep) {
-			hfdl_gpu_frontend_input_done_upto(fe, uploads - leased);    /* the oldest leased block, as the GPU library numbers host blocks */
+			/* the oldest leased block, as the GPU library numbers host blocks; on failure fall back to waiting for every copy, and
+			 * stop (slot kept) if even that fails: the producer must never overwrite memory the DMA engine may still read */
+			if (hfdl_gpu_frontend_input_done_upto(fe, uploads - leased) != 0 && hfdl_gpu_frontend_input_done(fe) != 0) {
+				fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
+				do_exit = 1;
+				ok = 0;
+				break;
+			}
 			pthread_mutex_lock(ring->mutex);
 			hfdl_ring_drop(ring->buf, need);
 			pthread_mutex_unlock(ring->mutex);

@@ -23,7 +23,7 @@ def shard_channels(freqs, rank, world):
 
 def reduce_job(elapsed_s, samples, pdus, dist=None, device="cpu"):
     """Whole-job aggregate: time = max over ranks, samples and PDUs = sum over ranks."""
-    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_available() or not dist.is_initialized():
         return float(elapsed_s), int(samples), int(pdus)
     import torch
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
@@ -35,7 +35,7 @@ def reduce_job(elapsed_s, samples, pdus, dist=None, device="cpu"):
 
 def reduce_sums(values, dist=None, device="cpu"):
     """Sum each of `values` (ints) over the ranks."""
-    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_available() or not dist.is_initialized():
         return [int(v) for v in values]
     import torch
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
@@ -45,10 +45,22 @@ def reduce_sums(values, dist=None, device="cpu"):
 
 def gather_ints(value, dist=None, device="cpu"):
     """One int per rank, in rank order, on every rank (a one-hot sum: no object collectives needed on RCCL)."""
-    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_available() or not dist.is_initialized():
         return [int(value)]
     import torch
     t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device)
     t[dist.get_rank()] = float(value)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(v) for v in t.tolist()]
+
+
+def gather_floats(values, dist=None, device="cpu"):
+    """A row of floats per rank, in rank order, on every rank: result[r] = rank r's `values` (one-hot rows summed: plain all_reduce,
+    the same on RCCL and gloo)."""
+    if dist is None or not dist.is_available() or not dist.is_initialized():
+        return [[float(v) for v in values]]
+    import torch
+    t = torch.zeros(dist.get_world_size(), len(values), dtype=torch.float64, device=device)
+    t[dist.get_rank()] = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [[float(v) for v in row] for row in t.tolist()]

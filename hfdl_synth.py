@@ -3,7 +3,7 @@
 Builds valid HFDL bursts (prekey + preamble + interleaved/FEC-coded/scrambled M-PSK data, SURVEY.md
 Appendix B) and mixes any number of channels into one wideband cf32 stream by FFT interpolation, so
 that the bench and the parity tests have a seeded, reproducible input of the shape
-BASELINE.json's configs name.  numpy only; used by tests/ and bench.py.
+BASELINE.json's configs name.  numpy only; TEST AND BENCH INFRASTRUCTURE (used by tests/, bench.py, __graft_entry__.smoke()); not part of the product package.
 """
 import numpy as np
 

@@ -133,6 +133,11 @@ int  hfdl_gpu_frontend_input_done_upto(hfdl_gpu_frontend *fe, uint64_t host_bloc
  * one demodulator; with the copy taken off that chain two blocks in flight keep the GPU busy.  The prefetched block counts as a
  * host block for hfdl_gpu_frontend_input_done_upto() from this call on.  One block at a time; pushing anything else next is EINVAL. */
 int  hfdl_gpu_frontend_prefetch_block_raw(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int sample_format);
+/* Forget the prefetched block (a caller that hit an error between the prefetch and its push): waits for the copy, after which the
+ * buffer is the caller's again and any block may be pushed next.  The block keeps its host block number.  No-op without a prefetch.
+ * While a prefetch is pending, a push of anything but the prefetched block -- another pointer, another format, a device block --
+ * is HFDL_GPU_EINVAL and leaves the prefetch in place. */
+int  hfdl_gpu_frontend_prefetch_cancel(hfdl_gpu_frontend *fe);
 /* Same, for raw recorder / SDR samples converted on the device inside the overlap-assembly load of the forward FFT
  * (convert_cs16 / convert_cu8 / convert_cf32, src/input-helpers.c:10-78): interleaved I,Q int16 (full scale 32767.5),
  * uint8 (offset 63.5, full scale 127) or float32.  Halves / quarters the host->device bytes per sample. */
@@ -175,6 +180,11 @@ typedef struct {
 	float    agc_level, costas_dphi;
 	int32_t  framer_state;           /* 1 = A1 search ... 7 = DATA_2 (src/hfdl.c:54-62) */
 	uint64_t sample_cnt, symbol_cnt;
+	/* the reference's debug summary (hfdl_print_summary, src/hfdl.c:563-573), per channel: A1 detections, mean |correlation| at the
+	 * A1 / A2 / M1 detections (0 when there were none), training bits of all frames received */
+	uint32_t a1_found;
+	float    a1_corr_avg, a2_corr_avg, m1_corr_avg;
+	uint32_t train_bits_bad, train_bits_total;
 } hfdl_gpu_channel_stats;
 int  hfdl_gpu_frontend_channel_stats(hfdl_gpu_frontend *fe, int32_t channel, hfdl_gpu_channel_stats *out);
 /* every channel in one strided device read, WITHOUT waiting for blocks in flight: each field is read whole, the set may
@@ -204,6 +214,8 @@ int  hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel
 /* timing of the dominant kernel (fold) measured with HIP events on the front end's stream */
 int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
 int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
+/* the same for the demodulator kernel (the kernel that bounds the small geometries), from its dispatch's own start / stop events */
+int  hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
 /* steady-state period of one block: (start of the last timed fold launch - start of the first) / (launches - 1), free of
  * the pipeline fill before the first block and the demodulator / burst-decoder drain after the last */
 int  hfdl_gpu_frontend_step_period_ms(hfdl_gpu_frontend *fe, double *period_ms);

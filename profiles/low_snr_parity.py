@@ -4,7 +4,7 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dumphfdl_amd as hf
-from dumphfdl_amd import synth
+import hfdl_synth as synth
 from oracle import pyoracle
 
 fs, cf = 1_000_000, 10_000_000

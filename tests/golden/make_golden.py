@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import pyoracle as O  # noqa: E402
-from dumphfdl_amd import synth  # noqa: E402
+import hfdl_synth as synth  # noqa: E402
 
 R = O.ref()
 assert R is not None, "needs /root/reference (oracle/_ref/libhfdl_ref.so)"

@@ -3,7 +3,7 @@ checked against the plain-C oracle on the same seeded input."""
 import numpy as np
 import pytest
 
-from dumphfdl_amd import synth
+import hfdl_synth as synth
 from dumphfdl_amd import frontend as F
 
 pytestmark = pytest.mark.gpu

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from dumphfdl_amd import synth
+import hfdl_synth as synth
 import dumphfdl_amd as hf
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -315,7 +315,7 @@ def test_bench_traffic_plans():
     """bench.py's synthetic traffic: bursts of a channel never overlap, all end inside the resident stretch, the burst-dense
     workload cycles all eight modes (BASELINE.json configs[3]) and the plan is a pure function of the seed."""
     import bench
-    from dumphfdl_amd import synth
+    import hfdl_synth as synth
     for name, input_size in (("cfg3", 7340032), ("cfg4", 7340032), ("cfg2", 917504)):
         w = bench.WORKLOADS[name]
         freqs = bench.channel_plan(w)

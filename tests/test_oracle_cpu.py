@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from dumphfdl_amd import synth
+import hfdl_synth as synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
