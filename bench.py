@@ -489,7 +489,7 @@ def cfg2_leg(torch, hf, F, dev_index, steps=256, warmup=8):
     el, raw, step = timed_blocks(torch, fe, push, steps, step, nblocks)
     pdus = [p for buf, n in raw for p in fe.pdus_to_dicts(buf, n)]
     fold_ms, fold_n = fe.fold_time_ms()
-    dm_ms, dm_n = fe.demod_time_ms()
+    dm_ms, dm_n, dm_blk = fe.demod_time_ms()
     period = fe.step_period_ms()
     fe.reset_timers(False)
     hbuf, host = host_ram_leg(torch, hf, F, fe, x, g, nblocks, steps)
@@ -499,7 +499,7 @@ def cfg2_leg(torch, hf, F, dev_index, steps=256, warmup=8):
     ab = alg_bytes_per_block(g)
     return dict(workload=w["name"], value=steps * g.input_size / el / 1e6, unit="Msamples/s", steps=steps, warmup=warmup, ms_per_step=el / steps * 1e3,
                 steady_state_ms_per_step=period, block_samples=g.input_size, channels=g.channels,
-                demod_kernel_avg_ms=(dm_ms / dm_n) if dm_n else None, demod_kernel_launches=dm_n,
+                demod_kernel_ms_per_block=(dm_ms / dm_blk) if dm_blk else None, demod_kernel_launches=dm_n, demod_blocks_per_launch=g.demod_batch,
                 fold_kernel_avg_ms=(fold_ms / fold_n) if fold_n else None,
                 algorithmic_bytes_per_block=ab,
                 whole_step_frac_of_hbm_peak=(ab / (period * 1e-3) / 1e9 / HBM_PEAK_GBS) if period else None,
@@ -593,7 +593,7 @@ def main():
     pdus = [p for buf, n in raw for p in fe.pdus_to_dicts(buf, n)]     # Python-side unpacking for the checks below: not part of the path
     npdus = len(pdus)
     fold_ms, fold_n = fe.fold_time_ms()
-    dm_ms, dm_n = fe.demod_time_ms()
+    dm_ms, dm_n, dm_blk = fe.demod_time_ms()
     period_ms = fe.step_period_ms()
     barrier()
     fe.reset_timers(False)
@@ -609,7 +609,7 @@ def main():
     seeds = shard.gather_ints(my_seed, use_dist, device=red_device)
     fold_avg_ms = fold_ms / max(fold_n, 1)
     # every rank's own numbers, in rank order: a straggler GPU shows up here, not only in the max
-    per_rank_cols = shard.gather_floats([my_seed, elapsed / args.steps * 1e3, period_ms, fold_avg_ms, (dm_ms / dm_n) if dm_n else 0.0,
+    per_rank_cols = shard.gather_floats([my_seed, elapsed / args.steps * 1e3, period_ms, fold_avg_ms, (dm_ms / dm_blk) if dm_blk else 0.0,
                                          npdus, good, g.channels, t_create, t_gen], use_dist, device=red_device)
     if args.dump_pdus:
         json.dump(sorted(pdu_key(p) for p in pdus), open("%s.rank%d.json" % (args.dump_pdus, rank), "w"))
@@ -623,6 +623,7 @@ def main():
     if solo and not args.no_extra_legs:
         extra["fec"] = fec_capacity(hf, dev_index)
     geom = dict(channels=g.channels, fft_size=g.fft_size, fft_inv_size=g.fft_inv_size, input_size=g.input_size)
+    demod_batch = g.demod_batch
     alg_bytes = alg_bytes_per_block(g)
     # every rank releases its front end (16 GiB of filter taps each) before the legs that build others / before leaving
     fe.close()
@@ -637,7 +638,7 @@ def main():
         par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, geom["channels"])) if args.shard == "streams" else \
               ("ONE %d-channel stream, channels round-robin over %d GPUs (%d on rank 0), every GPU ingests the same block; no collectives"
                % (len(all_freqs), world, geom["channels"]))
-        names = ("stream_seed", "ms_per_step", "steady_state_ms_per_step", "fold_avg_ms", "demod_avg_ms", "pdus", "pdus_matching_sent_payload",
+        names = ("stream_seed", "ms_per_step", "steady_state_ms_per_step", "fold_avg_ms", "demod_ms_per_block", "pdus", "pdus_matching_sent_payload",
                  "channels", "frontend_create_s", "input_synthesis_s")
         per_rank = [dict([("rank", r)] + [(n, (int(v) if n in ("stream_seed", "pdus", "pdus_matching_sent_payload", "channels") else round(v, 4)))
                                            for n, v in zip(names, row)]) for r, row in enumerate(per_rank_cols)]
@@ -671,7 +672,7 @@ def main():
             "steady_state_ms_per_step": period_ms,
             "fill_drain_ms": max(0.0, elapsed * 1e3 - period_ms * args.steps) if period_ms else None,
             "trellis_steps_per_s_in_run": total_trellis / elapsed_max,
-            "demod_kernel_avg_ms": (dm_ms / dm_n) if dm_n else None,
+            "demod_kernel_ms_per_block": (dm_ms / dm_blk) if dm_blk else None, "demod_blocks_per_launch": demod_batch,
             "roofline": {"bound": "hbm", "kernel": "fold_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n,

@@ -12,7 +12,8 @@ struct ChanState;
 struct FrameRec;
 
 struct Demod {
-	int nch = 0, outs = 0, cap = 0;         // cap = max 5400-sps samples per block
+	int nch = 0, outs = 0, cap = 0;         // cap = max 5400-sps samples per demodulator launch (`batch` blocks)
+	int batch = 1;                          // blocks a launch can take: what was asked for, cut down to what fits the LDS
 	float *d_tables = nullptr;              // packed DemodTables image
 	ChanState *d_states = nullptr;
 	float2 *d_data = nullptr;               // [nch][2][5040] equalised data symbols
@@ -35,10 +36,11 @@ struct Demod {
 	size_t lds_bytes = 0;
 	void *priv = nullptr;                   // DemodPriv (host image of the tables + resolved device pointers)
 
-	int init(int nch, int outs, float resamp_rate, const int32_t *freqs, hipStream_t st);
+	int init(int nch, int outs, float resamp_rate, const int32_t *freqs, hipStream_t st, int batch_want = 1);
 	// K4 of a block.  `done` (optional) is signalled by the kernel's own dispatch packet.  frames_free: the caller has already
 	// ordered this launch after the decoder of launch i-2 (frames_free_event()), so no wait is queued in front of the kernel.
-	int enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st, hipEvent_t done = nullptr, bool frames_free = false, hipEvent_t start = nullptr);
+	// chan_out / out_count: `nblk` consecutive blocks, [nblk][nch][outs] and [nblk][nch]
+	int enqueue_demod(const float2 *chan_out, const int *out_count, int nblk, hipStream_t st, hipEvent_t done = nullptr, bool frames_free = false, hipEvent_t start = nullptr);
 	hipEvent_t frames_free_event() const { return separate_decode ? ev_dec[launches & 1] : nullptr; }   // of the NEXT launch; may be null
 	int enqueue_decode(int buf, hipStream_t st);                                              // K5 + PDU-ring snapshot of the same block
 	int collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);                    // stream idle: everything produced

@@ -87,7 +87,7 @@ struct DemodLds {
 // of scratch spills: scratch is memory, and beside a kernel that saturates HBM every spill reload is a multi-microsecond stall.
 template <bool TAPS>
 __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
-		const int *__restrict__ n_in, int outs_stride)
+		const int *__restrict__ n_in, int outs_stride, int nblk, int nch)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const int c = blockIdx.x, tid = threadIdx.x;
@@ -104,11 +104,16 @@ __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, Demod
 	cf *l_in = (cf *)(lds + L.agc);
 
 	ChanState *gs = B.states + c;
-	const int n_block = n_in[c];
 	// prologue copies with 8 loads of a lane in flight at a time: beside the fold kernel a dependent load costs microseconds
 	stage_copy<DM_THREADS>((uint32_t *)A, (const uint32_t *)&gs->a, (int)(sizeof(ChanArrays) / 4), tid);
 	stage_copy<DM_THREADS>((uint32_t *)S, (const uint32_t *)&gs->s, (int)(sizeof(ChanScalars) / 4), tid);
-	stage_copy<DM_THREADS>(l_in, chan_out + (size_t)c * outs_stride, n_block, tid);
+	// the launch's blocks ([nblk][nch][outs]; one block unless the host batches) end to end: one stretch of channelizer output
+	int n_block = 0;
+	for (int b = 0; b < nblk; b++) {
+		const int nb = n_in[b * nch + c];
+		stage_copy<DM_THREADS>(l_in + n_block, chan_out + ((size_t)b * nch + c) * outs_stride, nb, tid);
+		n_block += nb;
+	}
 	stage_copy<DM_THREADS>((float4 *)l_rs_h, (const float4 *)T.c.rs_h, D_RS_NPFB * D_RS_TAPS / 4, tid);
 	// symsync taps in the lane order of the timing-recovery wave: entry [bank][lane] = {tap t, tap t + 16} of the lane's row
 	for (int e = tid; e < D_SS_NPFB * 64; e += DM_THREADS) {
@@ -552,11 +557,16 @@ static int set_big_lds(const void *fn, size_t bytes)
 	return 0;
 }
 
-int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hipStream_t st)
+int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hipStream_t st, int batch_want)
 {
 	nch = nch_; outs = outs_;
-	cap = (int)((double)outs * (resamp_rate < 1.0f ? (double)resamp_rate : 1.0) + 8);
 	if (resamp_rate <= 0.5f || resamp_rate > 1.0f) return HFDL_GPU_ERANGE;   // one arbitrary stage, no half-band stages
+	// blocks per launch: the per-launch sample buffers live in LDS (~46 bytes per 5400-sps sample next to ~25 KiB of tables and state)
+	batch = batch_want < 1 ? 1 : batch_want;
+	for (;; batch--) {
+		cap = (int)((double)outs * (double)batch * (double)resamp_rate + 8);
+		if (batch == 1 || (demod_lds_bytes(cap) <= 160 * 1024 && 2 * cap <= 65535)) break;      // cum[] counts outputs in 16 bits
+	}
 	auto *pv = new DemodPriv();
 	build_demod_tables(pv->h, resamp_rate);
 	priv = pv;
@@ -605,11 +615,10 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 // burst decoder of launch i may run on another stream than the demodulator of launch i+1; it zeroes the counter of launch i+2,
 // whose previous users (launch i-2) are done and whose next user (the demodulator of launch i+2) is made to wait for this
 // decoder by the caller -- no memset launch per block, no counter shared by two kernels that can overlap.
-int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int buf, hipStream_t st, hipEvent_t done, bool frames_free, hipEvent_t start)
+int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int nblk, hipStream_t st, hipEvent_t done, bool frames_free, hipEvent_t start)
 {
 	DemodPriv *pv = priv_of(this);
-	if (!pv) return HFDL_GPU_EINVAL;
-	(void)buf;
+	if (!pv || nblk < 1 || nblk > batch) return HFDL_GPU_EINVAL;
 	DemodBuffers B;
 	const uint64_t i = launches++;          // per demodulator launch (not per block: channelize-only blocks launch none)
 	// the decoder of launch i-2 has read this frame queue.  Every wait or record is a barrier packet of its own in the queue
@@ -620,8 +629,8 @@ int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int buf, 
 	const bool tw = taps_on && taps_enabled;
 	B.tap_rs = tw ? (cf *)d_tap_rs : nullptr; B.tap_mf = (cf *)d_tap_mf; B.tap_sym = (cf *)d_tap_sym; B.tap_lvl = d_tap_lvl; B.tap_counts = d_tap_counts;
 	B.cap = cap;
-	if (tw) hipExtLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, start, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs);
-	else hipExtLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, start, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs);
+	if (tw) hipExtLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, start, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs, nblk, nch);
+	else hipExtLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)nch), dim3(DM_THREADS), (unsigned)lds_bytes, st, start, done, 0, pv->t, B, (const cf *)chan_out, out_count, outs, nblk, nch);
 	D_TRY(hipGetLastError());
 	return 0;
 }

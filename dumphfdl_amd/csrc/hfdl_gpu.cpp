@@ -119,7 +119,7 @@ struct hfdl_gpu_frontend {
 	hipEvent_t ev_dm_cur[2] = { nullptr, nullptr };  // the event that stands for it now: ev_dm[i], or (timing on) the stop event of a timed pair
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_dmt;      // timed demodulator launches not yet read
 	double demod_ms = 0;
-	int64_t demod_launches = 0;
+	int64_t demod_launches = 0, demod_timed_blocks = 0;
 	hipStream_t stream_c = nullptr;     // C: host -> device copies of block k+1 into the other staging buffer
 	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
 	hipEvent_t ev_stage_ready[2] = { nullptr, nullptr }, ev_stage_free[2] = { nullptr, nullptr };
@@ -127,7 +127,6 @@ struct hfdl_gpu_frontend {
 	hipEvent_t ev_copy[4] = { nullptr, nullptr, nullptr, nullptr };   // copy of host block j done (j & 3): what input_done_upto() waits for
 	const void *prefetched = nullptr;   // host pointer whose copy hfdl_gpu_frontend_prefetch_block_raw() already queued ...
 	int prefetched_sb = -1, prefetched_fmt = 0;      // ... into this staging buffer, from this sample format
-	int last_buf = 0;
 	int32_t sample_rate = 0, centerfreq = 0, decimation = 0;
 	float tbw = 0;
 	Plan plan{};                       // shift = 0 geometry (src/fft.c:70-86)
@@ -136,8 +135,16 @@ struct hfdl_gpu_frontend {
 	std::vector<int32_t> freqs;
 	std::vector<ChanConst> cc;
 	float2 *d_hist[2] = { nullptr, nullptr }, *d_work = nullptr, *d_spec = nullptr, *d_taps = nullptr, *d_partial = nullptr;
-	float2 *d_chan_out[2] = { nullptr, nullptr }, *d_tw_m = nullptr, *d_stage[2] = { nullptr, nullptr };
-	int *d_out_count[2] = { nullptr, nullptr };
+	float2 *d_tw_m = nullptr, *d_stage[2] = { nullptr, nullptr };
+	// Channelizer output, double-buffered between stream A and stream B in two HALVES of `batch` blocks each: [2][batch][nch][outs].
+	// A demodulator launch takes the blocks of one half (one block when batch == 1) while the channelizer fills the other.
+	float2 *d_chan_all = nullptr;
+	int *d_cnt_all = nullptr;           // [2][batch][nch] outputs per channel of each block
+	int batch = 1;                      // blocks per demodulator launch (see pick_demod_batch)
+	int cur_half = 0, batch_fill = 0;   // the half being filled and the blocks already in it
+	int last_slot = 0;                  // slot (half * batch + index) of the newest block: what HFDL_GPU_TAP_CHAN_OUT reads
+	float2 *chan_slot(int slot) const { return d_chan_all + (size_t)slot * (size_t)geo.nch * (size_t)geo.outs; }
+	int *cnt_slot(int slot) const { return d_cnt_all + (size_t)slot * (size_t)geo.nch; }
 	ChanConst *d_cc = nullptr;
 	NcoState *d_nco = nullptr;
 	float2 *d_ph = nullptr, *d_ph_cont = nullptr;      // the block's NCO phasor table [outs][nch] and the riders' segment hand-over [nch]
@@ -153,12 +160,12 @@ struct hfdl_gpu_frontend {
 	double span_ms = 0;                 // first timed fold start -> last timed fold start
 	uint64_t blocks = 0;
 	FftOutLayout tap_layout;
-	int pending_demod_buf = -1;         // block whose demodulator launch is held back until the next forward FFT is queued
+	int pending_demod_buf = -1;         // half whose demodulator launch is held back until the next forward FFT is queued ...
+	int pending_demod_nblk = 0;         // ... and the blocks in it
 	bool frames_wait_on_a = false;      // stream A has waited for the frame queue the next demodulator launch reuses
 	hipEvent_t ev_fft = nullptr;
-	uint64_t demod_blocks = 0;          // value of `blocks` after the last block that went through the demodulator
-	int demod_buf = -1;                 // ... and the buffer / snapshot slot it used
-	int prev_demod_buf = -1;            // the one before it
+	int demod_buf = -1;                 // half / snapshot slot of the newest demodulator launch
+	int prev_demod_buf = -1;            // ... and of the one before it
 };
 
 static void frontend_free(hfdl_gpu_frontend *fe)
@@ -178,8 +185,8 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	if (fe->ev_first_fold) (void)hipEventDestroy(fe->ev_first_fold);
 	fe->demod.release();
 	fe->fft.release();
-	void *ptrs[] = { fe->d_hist[0], fe->d_hist[1], fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_out[0], fe->d_chan_out[1], fe->d_tw_m,
-		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_ph, fe->d_ph_cont, fe->d_out_count[0], fe->d_out_count[1] };
+	void *ptrs[] = { fe->d_hist[0], fe->d_hist[1], fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_all, fe->d_tw_m,
+		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_ph, fe->d_ph_cont, fe->d_cnt_all };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (fe->stream) (void)hipStreamDestroy(fe->stream);
 	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamDestroy(fe->stream_d);
@@ -198,6 +205,30 @@ static int pick_slices(int nch, int rows)
 	int s = 1;
 	while (s * 2 <= rows / 8 && nch * s < 1024) s *= 2;
 	return s;
+}
+
+// Blocks per demodulator launch.  Where the demodulator bounds the block (few channels: a serial recurrence per channel on a handful of
+// SIMDs, ~0.35 us per 5400-sps sample whatever the channel count) every launch pays for itself a second time in fixed costs: the
+// barrier packet in front of it (~11 us), ~25 KiB of tables and state staged into LDS and written back, and two chunks of pipeline
+// fill and drain -- ~40 us against ~210 us of recurrence per cfg2 block.  When blocks arrive faster than they are demodulated (file
+// replay, catching up) consecutive blocks are therefore handed to ONE launch, which treats them as one longer stretch of samples --
+// the per-channel state is carried sample by sample, so the result is that of block-by-block processing.  A caller that waits
+// for its PDUs after every block (live input: poll / sync) still gets a launch per block: a partial batch is launched by any call
+// that needs the results.  Bounds: the LDS (Demod::init keeps what fits), and one second of signal -- less than half the shortest
+// frame (2.34 s), so that a channel finishes at most one frame per launch (frame queue: one entry per channel; two data slots).
+static int pick_demod_batch(const hfdl_gpu_frontend *fe)
+{
+	int want = 1;
+	if (fe->own_decode_stream) {
+		const double block_s = (double)fe->plan.input_size / (double)fe->sample_rate;
+		want = (int)std::floor(1.0 / block_s);
+		want = std::max(1, std::min(8, want));
+	}
+	if (const char *e = getenv("HFDL_GPU_DEMOD_BATCH")) {       // A/B measurements; 1 = a launch per block
+		const long v = strtol(e, nullptr, 10);
+		if (v >= 1 && v <= 8) want = (int)v;
+	}
+	return want;
 }
 
 static int build_taps(hfdl_gpu_frontend *fe)
@@ -332,11 +363,6 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n));
 	FE_TRY(hipMalloc(&fe->d_taps, sizeof(float2) * n * (size_t)nch));
 	FE_TRY(hipMalloc(&fe->d_partial, sizeof(float2) * (size_t)nch * g.slices * (size_t)g.m));
-	for (int i = 0; i < 2; i++) {
-		FE_TRY(hipMalloc(&fe->d_chan_out[i], sizeof(float2) * (size_t)nch * g.outs));
-		FE_TRY(hipMalloc(&fe->d_out_count[i], sizeof(int) * (size_t)nch));
-		FE_TRY(hipMemsetAsync(fe->d_out_count[i], 0, sizeof(int) * (size_t)nch, fe->stream));
-	}
 	FE_TRY(hipMalloc(&fe->d_nco, sizeof(NcoState) * (size_t)nch));
 	FE_TRY(hipMemsetAsync(fe->d_nco, 0, sizeof(NcoState) * (size_t)nch, fe->stream));
 	FE_TRY(hipMalloc(&fe->d_ph, sizeof(float2) * (size_t)nch * g.outs));
@@ -355,7 +381,11 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	if ((rc = build_taps(fe))) { frontend_free(fe); return rc; }
 	FE_TRY(hipMemcpy(fe->d_cc, fe->cc.data(), sizeof(ChanConst) * (size_t)nch, hipMemcpyHostToDevice));
 	float resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)fe->decimation);
-	if ((rc = fe->demod.init(nch, g.outs, resamp_rate, fe->freqs.data(), fe->stream))) { frontend_free(fe); return rc; }
+	if ((rc = fe->demod.init(nch, g.outs, resamp_rate, fe->freqs.data(), fe->stream, pick_demod_batch(fe)))) { frontend_free(fe); return rc; }
+	fe->batch = fe->demod.batch;        // what fits the demodulator's LDS
+	FE_TRY(hipMalloc(&fe->d_chan_all, sizeof(float2) * 2 * (size_t)fe->batch * (size_t)nch * g.outs));
+	FE_TRY(hipMalloc(&fe->d_cnt_all, sizeof(int) * 2 * (size_t)fe->batch * (size_t)nch));
+	FE_TRY(hipMemsetAsync(fe->d_cnt_all, 0, sizeof(int) * 2 * (size_t)fe->batch * (size_t)nch, fe->stream));
 	FE_TRY(hipStreamSynchronize(fe->stream));
 #undef FE_TRY
 	*out = fe;
@@ -374,6 +404,7 @@ extern "C" int hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_
 	g->outputs_per_block = p.post_input_size / p.post;
 	g->max_outputs_per_block = (p.post_input_size + p.post - 1) / p.post;
 	g->channels = fe->geo.nch; g->fold_slices = fe->geo.slices;
+	g->demod_batch = fe->batch;
 	g->transition_bw = fe->tbw;
 	g->resamp_rate = (float)(1800 * 3) / ((float)fe->sample_rate / (float)fe->decimation);
 	return 0;
@@ -493,7 +524,7 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 // 2.56 ms or 2.87 ms per launch (profiles/r01_experiments.md).  So the launch of demod(k) is held back until the forward
 // FFT of block k+1 has finished: the workgroups then arrive while only the LDS-free fold kernel is resident, spread
 // evenly, and the fold time is the good one every time.  A sync / poll launches a held-back demodulator at once.
-static int launch_demod(hfdl_gpu_frontend *fe, int buf, bool after_fft)
+static int launch_demod(hfdl_gpu_frontend *fe, int buf, int nblk, bool after_fft)
 {
 	// the forward FFT of the next block follows this block's inverse FFT on stream A, so its event covers ev_chan too
 	if (after_fft) HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_fft, 0));
@@ -507,9 +538,10 @@ static int launch_demod(hfdl_gpu_frontend *fe, int buf, bool after_fft)
 		fe->ev_pool.pop_back();
 		t_start = e.first; done = e.second;
 		fe->ev_dmt.push_back(e);
+		fe->demod_timed_blocks += nblk;
 	}
 	fe->ev_dm_cur[buf] = done;
-	int rc = fe->demod.enqueue_demod(fe->d_chan_out[buf], fe->d_out_count[buf], buf, fe->stream_b, done, fe->frames_wait_on_a, t_start);
+	int rc = fe->demod.enqueue_demod(fe->chan_slot(buf * fe->batch), fe->cnt_slot(buf * fe->batch), nblk, fe->stream_b, done, fe->frames_wait_on_a, t_start);
 	fe->frames_wait_on_a = false;
 	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 	if (fe->own_decode_stream) HIP_TRY(hipStreamWaitEvent(fe->stream_d, done, 0));
@@ -522,9 +554,24 @@ static int launch_demod(hfdl_gpu_frontend *fe, int buf, bool after_fft)
 static int flush_pending_demod(hfdl_gpu_frontend *fe, bool after_fft)
 {
 	if (fe->pending_demod_buf < 0) return 0;
-	const int buf = fe->pending_demod_buf;
+	const int buf = fe->pending_demod_buf, nblk = fe->pending_demod_nblk;
 	fe->pending_demod_buf = -1;
-	return launch_demod(fe, buf, after_fft);
+	return launch_demod(fe, buf, nblk, after_fft);
+}
+
+// the half being filled is handed to the demodulator as it is (a full batch, or what a sync / poll finds waiting)
+static int close_batch(hfdl_gpu_frontend *fe, bool launch_now)
+{
+	if (fe->batch_fill == 0) return 0;
+	const int half = fe->cur_half, nblk = fe->batch_fill;
+	fe->cur_half ^= 1;
+	fe->batch_fill = 0;
+	fe->prev_demod_buf = fe->demod_buf;      // what poll_pdus_ready(.., 1) waits for: the launch before the newest one
+	fe->demod_buf = half;
+	if (launch_now) return launch_demod(fe, half, nblk, false);
+	fe->pending_demod_buf = half;
+	fe->pending_demod_nblk = nblk;
+	return 0;
 }
 
 // Stream A runs the channelizer of block k into buffer k&1; stream B demodulates it.  A's inverse FFT may not overwrite
@@ -532,7 +579,7 @@ static int flush_pending_demod(hfdl_gpu_frontend *fe, bool after_fft)
 static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx, int *buf_out, bool with_demod)
 {
 	const Geometry &g = fe->geo;
-	const int buf = (int)(fe->blocks & 1);
+	const int buf = fe->cur_half, slot = fe->cur_half * fe->batch + fe->batch_fill;
 	// The events other streams (and the bench's fold timer) wait for ride on the kernel dispatches themselves
 	// (hipExtLaunchKernelGGL start / stop events): a separate hipEventRecord is one more barrier packet in the queue, ~5 us
 	// of idle machine each (profiles/r01_experiments.md).
@@ -564,18 +611,21 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 	} else {
 		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
 	}
-	if (fe->ev_dm_cur[buf]) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm_cur[buf], 0));          // chan_out[buf] is free once demod(k-2) has read it
-	if (with_demod && fe->own_decode_stream) {
+	// this half is free once the demodulator launch that read it last (two launches ago) is done; the first block of a batch waits
+	if (fe->batch_fill == 0 && fe->ev_dm_cur[buf]) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm_cur[buf], 0));
+	if (with_demod && fe->own_decode_stream && fe->batch_fill == 0) {
 		// this block's demodulator (launched right after this kernel, on stream B) reuses the frame queue the decoder of two
 		// launches ago read: wait for it HERE, where the stream has slack, instead of in front of the demodulator
 		hipEvent_t e = fe->demod.frames_free_event();
 		if (e) HIP_TRY(hipStreamWaitEvent(fe->stream, e, 0));
 		fe->frames_wait_on_a = true;
 	}
-	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_ph, fe->d_tw_m, fe->d_chan_out[buf], fe->d_out_count[buf], fe->stream, fe->ev_chan[buf]);
+	// ev_chan[half] is re-recorded by every block of the batch: when the demodulator is launched it stands for the last one
+	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_ph, fe->d_tw_m, fe->chan_slot(slot), fe->cnt_slot(slot), fe->stream, fe->ev_chan[buf]);
 	HIP_TRY(hipGetLastError());
 	fe->blocks++;
-	fe->last_buf = buf;
+	fe->last_slot = slot;
+	fe->batch_fill++;
 	if (buf_out) *buf_out = buf;
 	return 0;
 }
@@ -586,7 +636,11 @@ extern "C" int hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const f
 	int sidx = -1;
 	int rc = stage_input(fe, iq, nsamples, SFMT_CF32, on_device, &fresh, &sidx);
 	if (rc) return rc;
-	return enqueue_channelizer(fe, fresh, SFMT_CF32, sidx, nullptr, false);
+	if ((rc = close_batch(fe, true))) return rc;            // blocks pushed for the demodulator and not yet handed to it
+	if ((rc = enqueue_channelizer(fe, fresh, SFMT_CF32, sidx, nullptr, false))) return rc;
+	fe->cur_half ^= 1;                                      // this block is never demodulated: its half is simply left behind
+	fe->batch_fill = 0;
+	return 0;
 }
 
 static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int fmt, int on_device)
@@ -596,18 +650,11 @@ static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int
 	int rc = stage_input(fe, raw, nsamples, fmt, on_device, &fresh, &sidx);
 	if (rc) return rc;
 	if ((rc = enqueue_channelizer(fe, fresh, fmt, sidx, &buf, true))) return rc;
-	if (fe->own_decode_stream) {
-		// demodulator-bound geometry (few channels): the fold is short, there is nothing to place the demodulator under, and
-		// holding it back until the NEXT block's forward FFT would put that block's host -> device copy on the demodulator's
-		// critical path (cfg2 fed from host memory: 0.56 -> 0.33 ms per block)
-		if ((rc = launch_demod(fe, buf, false))) return rc;
-	} else {
-		fe->pending_demod_buf = buf;
-	}
-	fe->demod_blocks = fe->blocks;
-	fe->prev_demod_buf = fe->demod_buf;
-	fe->demod_buf = buf;
-	return 0;
+	if (fe->batch_fill < fe->batch) return 0;               // the batch is still filling (demodulator-bound geometries)
+	// demodulator-bound geometry (few channels): the fold is short, there is nothing to place the demodulator under, and
+	// holding it back until the NEXT block's forward FFT would put that block's host -> device copy on the demodulator's
+	// critical path (cfg2 fed from host memory: 0.56 -> 0.33 ms per block): launched at once.  Otherwise held back (launch_demod).
+	return close_batch(fe, fe->own_decode_stream);
 }
 
 extern "C" int hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
@@ -654,6 +701,7 @@ extern "C" int hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe)
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	HIP_TRY(hipSetDevice(fe->device));
 	{ int rc = flush_pending_demod(fe, false); if (rc) return rc; }
+	{ int rc = close_batch(fe, true); if (rc) return rc; }          // blocks waiting for their batch to fill: demodulated now
 	HIP_TRY(hipStreamSynchronize(fe->stream_c));
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipStreamSynchronize(fe->stream_b));
@@ -718,7 +766,7 @@ extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
 	fe->fold_ms = 0; fe->fold_launches = 0; fe->timing = enable != 0;
-	fe->demod_ms = 0; fe->demod_launches = 0;
+	fe->demod_ms = 0; fe->demod_launches = 0; fe->demod_timed_blocks = 0;
 	if (fe->ev_first_fold) { (void)hipEventDestroy(fe->ev_first_fold); fe->ev_first_fold = nullptr; }
 	fe->span_ms = 0;
 	// enough event pairs for the launches between two drains (a sync / poll recycles them): created here, not in the timed loop
@@ -773,13 +821,14 @@ extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *tot
 	return 0;
 }
 
-extern "C" int hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches)
+extern "C" int hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches, int64_t *blocks)
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
 	if (total_ms) *total_ms = fe->demod_ms;
 	if (launches) *launches = fe->demod_launches;
+	if (blocks) *blocks = fe->demod_timed_blocks;
 	return 0;
 }
 
@@ -885,11 +934,11 @@ extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32
 		return 0; }
 	case HFDL_GPU_TAP_CHAN_OUT: {
 		int cnt = 0;
-		HIP_TRY(hipMemcpy(&cnt, fe->d_out_count[fe->last_buf] + channel, sizeof(cnt), hipMemcpyDeviceToHost));
-		src = fe->d_chan_out[fe->last_buf] + (size_t)channel * g.outs; nf = 2 * (size_t)cnt; break; }
+		HIP_TRY(hipMemcpy(&cnt, fe->cnt_slot(fe->last_slot) + channel, sizeof(cnt), hipMemcpyDeviceToHost));
+		src = fe->chan_slot(fe->last_slot) + (size_t)channel * g.outs; nf = 2 * (size_t)cnt; break; }
 	case HFDL_GPU_TAP_NCO_PHASORS: {
 		int cnt = 0;
-		HIP_TRY(hipMemcpy(&cnt, fe->d_out_count[fe->last_buf] + channel, sizeof(cnt), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&cnt, fe->cnt_slot(fe->last_slot) + channel, sizeof(cnt), hipMemcpyDeviceToHost));
 		if (2 * (size_t)cnt > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", 2 * (size_t)cnt, cap);
 		// column `channel` of the [outs][nch] table
 		if (cnt) HIP_TRY(hipMemcpy2D(dst, sizeof(float2), fe->d_ph + channel, sizeof(float2) * (size_t)g.nch, sizeof(float2), (size_t)cnt, hipMemcpyDeviceToHost));

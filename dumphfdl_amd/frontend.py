@@ -23,7 +23,7 @@ class Geometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "sample_rate", "decimation", "pre_decimation", "post_decimation", "taps_length", "overlap_length",
         "fft_size", "fft_inv_size", "input_size", "post_input_size", "scrap", "outputs_per_block",
-        "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float), ("max_outputs_per_block", C.c_int32)]
+        "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float), ("max_outputs_per_block", C.c_int32), ("demod_batch", C.c_int32)]
 
 
 class Pdu(C.Structure):
@@ -105,7 +105,7 @@ def load():
     L.hfdl_gpu_frontend_enable_taps.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_frontend_channel_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ChannelStats)]
     L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    L.hfdl_gpu_frontend_demod_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.hfdl_gpu_frontend_demod_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_frontend_stream_read_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.hfdl_gpu_fft_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
@@ -258,7 +258,7 @@ class Frontend:
 
     def read_tap(self, what, channel=0):
         g = self.geometry
-        cap = 2 * g.fft_size if what in (TAP_SPECTRUM, TAP_FILTER) else 2 * (g.post_input_size + 64)
+        cap = 2 * g.fft_size if what in (TAP_SPECTRUM, TAP_FILTER) else 2 * (g.post_input_size + 64) * max(1, g.demod_batch)   # demodulator taps cover a launch
         buf = np.empty(cap, np.float32)
         n = C.c_size_t(0)
         _check(load().hfdl_gpu_frontend_read_tap(self._h, what, channel, _p(buf), cap, C.byref(n)))
@@ -285,8 +285,9 @@ class Frontend:
     def demod_time_ms(self):
         ms = C.c_double(0)
         n = C.c_int64(0)
-        _check(load().hfdl_gpu_frontend_demod_time_ms(self._h, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+        nb = C.c_int64(0)
+        _check(load().hfdl_gpu_frontend_demod_time_ms(self._h, C.byref(ms), C.byref(n), C.byref(nb)))
+        return ms.value, n.value, nb.value
 
     def step_period_ms(self):
         v = C.c_double(0)

@@ -228,6 +228,31 @@ def rrc_pulse(t, beta=0.2):
     return out
 
 
+# the receiver's 19-tap matched filter at 3 samples per symbol (protocol pulse-shape table, src/hfdl.c:147-154)
+_MF_TABLE = np.array([-0.0170974647427123, 0.01148231492068473, 0.03138375667422348, 0.009454398851680437, -0.04161644170893816,
+                      -0.06451564801420356, -0.005495792933327306, 0.1316404671361545, 0.2759693160697777, 0.3375901874933208])
+_MF_TABLE = np.concatenate([_MF_TABLE, _MF_TABLE[-2::-1]])
+
+# transmit pulse of every burst shaped from here on: ("rrc", beta) -- a textbook root-raised cosine, the default (0.2) -- or
+# ("mf_table",): the receiver's own table, band-limited interpolation between its 3-per-symbol points, peak-normalised.
+# A module-level switch (set_tx_pulse) so that the sensitivity study can vary the transmitter without threading it through every caller.
+_TX_PULSE = ("rrc", 0.2)
+
+
+def set_tx_pulse(kind="rrc", beta=0.2):
+    global _TX_PULSE
+    _TX_PULSE = (kind, beta)
+
+
+def tx_pulse(t):
+    """The transmit pulse at t (in symbols)."""
+    if _TX_PULSE[0] == "mf_table":
+        t = np.asarray(t, np.float64)
+        k = np.arange(19) - 9
+        return (np.sinc(3.0 * t[..., None] - k) * _MF_TABLE).sum(-1) / _MF_TABLE[9]
+    return rrc_pulse(t, _TX_PULSE[1])
+
+
 def shape_burst(symbols, rate, t0, nsamples, span=6):
     """Pulse-shape `symbols` (1800 baud) onto a grid of `nsamples` samples at `rate` Hz, first symbol at t0 seconds."""
     out = np.zeros(nsamples, np.complex128)
@@ -244,7 +269,7 @@ def shape_burst(symbols, rate, t0, nsamples, span=6):
         k = k0 + d
         ok = (k >= 0) & (k < len(symbols))
         a = np.where(ok, symbols[np.clip(k, 0, len(symbols) - 1)], 0)
-        acc += a * rrc_pulse(tt - k)
+        acc += a * tx_pulse(tt - k)
     out[lo:hi] = acc
     return out
 

@@ -70,6 +70,9 @@ typedef struct {
 	int32_t max_outputs_per_block;   /* ceil(post_input_size / post_decimation): what a block can emit when the carried
 	                                    decimation remainder is non-zero (post_input_size not a multiple of post_decimation);
 	                                    size HFDL_GPU_TAP_CHAN_OUT buffers from this */
+	int32_t demod_batch;             /* blocks one demodulator launch takes when they are pushed faster than they are collected (1 where the
+	                                    channelizer bounds the block; up to 8 on the small, demodulator-bound geometries).  Results do not
+	                                    depend on it; a poll / sync always demodulates what has been pushed.  0 from hfdl_gpu_plan_geometry() */
 } hfdl_gpu_geometry;
 
 /* one decoded PDU: what dispatch_pdu() hands to pdu_decoder_queue_push (src/hfdl.c:1058-1080,
@@ -214,8 +217,9 @@ int  hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel
 /* timing of the dominant kernel (fold) measured with HIP events on the front end's stream */
 int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
 int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
-/* the same for the demodulator kernel (the kernel that bounds the small geometries), from its dispatch's own start / stop events */
-int  hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
+/* the same for the demodulator kernel (the kernel that bounds the small geometries), from its dispatch's own start / stop events;
+ * *blocks = the blocks those launches covered (a launch takes up to geometry.demod_batch blocks) */
+int  hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches, int64_t *blocks);
 /* steady-state period of one block: (start of the last timed fold launch - start of the first) / (launches - 1), free of
  * the pipeline fill before the first block and the demodulator / burst-decoder drain after the last */
 int  hfdl_gpu_frontend_step_period_ms(hfdl_gpu_frontend *fe, double *period_ms);

@@ -14,6 +14,13 @@
 #include <pthread.h>
 #include "hfdl_oracle.h"
 
+/* ======================= variant switches (hfdl_oracle.h) ======================= */
+
+orc_variant orc_v = { .soft_dmin_init = 4.0f };
+void orc_variant_default(orc_variant *v) { memset(v, 0, sizeof(*v)); v->soft_dmin_init = 4.0f; }
+void orc_variant_set(const orc_variant *v) { orc_v = *v; }
+void orc_variant_get(orc_variant *v) { *v = orc_v; }
+
 /* ======================= liquid-dsp filter design ======================= */
 
 static double bessel_i0(double z)
@@ -43,16 +50,69 @@ static double sinc_pi(double x)
 	return sin(M_PI * x) / (M_PI * x);
 }
 
+/* variant design_float: the same design in single precision with liquid's own series -- liquid_besseli0f (32 terms through
+ * lngammaf), sincf (product of three cosines below |x| = 0.01), kaiser_beta_As in float */
+static float besseli0f_series(float z)
+{
+	if (z == 0.0f) return 1.0f;
+	float y = 0.0f;
+	for (int k = 0; k < 32; k++) {
+		float t = (float)k * logf(0.5f * z) - lgammaf((float)k + 1.0f);
+		y += expf(2 * t);
+	}
+	return y;
+}
+
+static float sincf_liquid(float x)
+{
+	if (fabsf(x) < 0.01f) return cosf((float)M_PI * x / 2.0f) * cosf((float)M_PI * x / 4.0f) * cosf((float)M_PI * x / 8.0f);
+	return sinf((float)M_PI * x) / ((float)M_PI * x);
+}
+
 /* liquid_firdes_kaiser(n, fc, As, mu=0): h[i] = sinc(2 fc t) * kaiser(i, n, beta) */
 static void firdes_kaiser(int n, double fc, double As, float *h)
 {
+	const double den = orc_v.kaiser_arg ? (double)(n - 1) : (double)n;
+	if (orc_v.design_float) {
+		float a = fabsf((float)As), beta;
+		if (a > 50.0f) beta = 0.1102f * (a - 8.7f);
+		else if (a > 21.0f) beta = 0.5842f * powf(a - 21.0f, 0.4f) + 0.07886f * (a - 21.0f);
+		else beta = 0.0f;
+		for (int i = 0; i < n; i++) {
+			float t = (float)i - (float)(n - 1) / 2;
+			float r = 2.0f * t / (float)den;
+			float w = besseli0f_series(beta * sqrtf(1 - r * r)) / besseli0f_series(beta);
+			h[i] = sincf_liquid(2.0f * (float)fc * t) * w;
+		}
+		return;
+	}
 	double beta = kaiser_beta_from_As(As), i0b = bessel_i0(beta);
 	for (int i = 0; i < n; i++) {
 		double t = (double)i - (double)(n - 1) / 2.0;
-		double r = 2.0 * t / (double)n;
+		double r = 2.0 * t / den;
 		double w = bessel_i0(beta * sqrt(1.0 - r * r)) / i0b;
 		h[i] = (float)(sinc_pi(2.0 * fc * t) * w);
 	}
+}
+
+/* sum_k h[k] * w[k] (real taps, complex window): sequential, or (variant dot_order) even / odd partial sums as a 4-lane SIMD
+ * dot product accumulates them */
+static inline orc_cf dot_rc(const float *h, const orc_cf *w, int n)
+{
+	orc_cf y;
+	if (!orc_v.dot_order) {
+		float ar = 0, ai = 0;
+		for (int k = 0; k < n; k++) { ar += h[k] * w[k].re; ai += h[k] * w[k].im; }
+		y.re = ar; y.im = ai;
+		return y;
+	}
+	float er = 0, ei = 0, or_ = 0, oi = 0;
+	int k = 0;
+	for (; k + 1 < n; k += 2) { er += h[k] * w[k].re; ei += h[k] * w[k].im; or_ += h[k + 1] * w[k + 1].re; oi += h[k + 1] * w[k + 1].im; }
+	float ar = er + or_, ai = ei + oi;
+	for (; k < n; k++) { ar += h[k] * w[k].re; ai += h[k] * w[k].im; }
+	y.re = ar; y.im = ai;
+	return y;
 }
 
 /* ======================= msresamp_crcf (a10) =======================
@@ -62,40 +122,92 @@ static void firdes_kaiser(int n, double fc, double As, float *h)
 #define RS_NPFB 256
 #define RS_TAPS 14
 
-void orc_resamp_filter(float rate, float *h, uint32_t *step)
+/* the prototype split into `npfb` branches of 14 taps; fc relative to the input rate */
+static void resamp_design(int npfb, double fc, float *h)
 {
-	const int n = 2 * 7 * RS_NPFB + 1;
+	const int n = 2 * 7 * npfb + 1;
 	float *hf = malloc(sizeof(float) * (size_t)n);
-	double fc = 0.515 * rate;
-	if (fc > 0.49) fc = 0.49;
-	firdes_kaiser(n, (float)fc / (float)RS_NPFB, 60.0, hf);
+	firdes_kaiser(n, (float)fc / (float)npfb, 60.0, hf);
 	float gain = 0.0f;
 	for (int i = 0; i < n; i++) gain += hf[i];
-	gain = (float)RS_NPFB / gain;
+	gain = (float)npfb / gain;
 	/* polyphase split: branch b, tap k  <-  prototype[b + k*npfb] (prototype[n-1] unused) */
-	for (int b = 0; b < RS_NPFB; b++)
+	for (int b = 0; b < npfb; b++)
 		for (int k = 0; k < RS_TAPS; k++)
-			h[b * RS_TAPS + k] = hf[b + k * RS_NPFB] * gain;
-	*step = (uint32_t)lround((double)(1u << 24) / (double)rate);
+			h[b * RS_TAPS + k] = hf[b + k * npfb] * gain;
 	free(hf);
+}
+
+void orc_resamp_filter(float rate, float *h, uint32_t *step)
+{
+	double fc = 0.515 * rate;
+	if (fc > 0.49) fc = 0.49;
+	resamp_design(RS_NPFB, fc, h);
+	*step = (uint32_t)lround((double)(1u << 24) / (double)rate);
 }
 
 typedef struct {
 	float h[RS_NPFB * RS_TAPS];
 	orc_cf win[RS_TAPS];       /* win[0] newest */
 	uint32_t step, phase;
+	/* variant resamp_kind != 0 */
+	int kind, npfb, bits;      /* bits: phase >> (24 - bits) = branch (fixed-phase kinds) */
+	float del, tau, bf, mu;    /* float-phase kinds (liquid <= 1.3.1 resamp_crcf): tau in samples, bf = tau * npfb = b + mu */
+	int b, boundary;
+	orc_cf y0, y1;
 } resamp_t;
+
+static void resamp_init(resamp_t *r, float rate)
+{
+	memset(r, 0, sizeof(*r));
+	r->kind = orc_v.resamp_kind;
+	r->npfb = (r->kind == 1 || r->kind == 3) ? 64 : RS_NPFB;
+	r->bits = r->npfb == 64 ? 6 : 8;
+	double fc = 0.515 * rate;
+	if (fc > 0.49) fc = 0.49;
+	if (r->kind == 1) fc = 0.4;
+	resamp_design(r->npfb, fc, r->h);
+	r->step = (uint32_t)lround((double)(1u << 24) / (double)rate);
+	r->del = 1.0f / rate;
+}
+
+/* liquid <= 1.3.1 resamp_crcf_execute: outputs interpolated linearly between the two branches around the float phase; the pair
+ * (last branch, branch 0 of the next input sample) is finished when that sample arrives (RESAMP_STATE_BOUNDARY) */
+static int32_t resamp_push_float(resamp_t *r, orc_cf x, orc_cf *y)
+{
+	int32_t n = 0;
+	while (r->b < r->npfb) {
+		if (r->boundary) {
+			r->y1 = dot_rc(r->h, r->win, RS_TAPS);
+			r->boundary = 0;
+		} else {
+			r->y0 = dot_rc(r->h + r->b * RS_TAPS, r->win, RS_TAPS);
+			if (r->b == r->npfb - 1) { r->boundary = 1; r->b = r->npfb; break; }
+			r->y1 = dot_rc(r->h + (r->b + 1) * RS_TAPS, r->win, RS_TAPS);
+		}
+		y[n].re = (1.0f - r->mu) * r->y0.re + r->mu * r->y1.re;
+		y[n].im = (1.0f - r->mu) * r->y0.im + r->mu * r->y1.im;
+		n++;
+		r->tau += r->del;
+		r->bf = r->tau * (float)r->npfb;
+		r->b = (int)floorf(r->bf);
+		r->mu = r->bf - (float)r->b;
+	}
+	r->tau -= 1.0f; r->bf -= (float)r->npfb; r->b -= r->npfb;
+	(void)x;
+	return n;
+}
 
 static int32_t resamp_push(resamp_t *r, orc_cf x, orc_cf *y)
 {
 	memmove(r->win + 1, r->win, sizeof(orc_cf) * (RS_TAPS - 1));
 	r->win[0] = x;
+	if (r->kind == 1 || r->kind == 2) return resamp_push_float(r, x, y);
 	int32_t n = 0;
 	while (r->phase < (1u << 24)) {
-		const float *hb = r->h + (r->phase >> 16) * RS_TAPS;
-		float ar = 0, ai = 0;
-		for (int k = 0; k < RS_TAPS; k++) { ar += hb[k] * r->win[k].re; ai += hb[k] * r->win[k].im; }
-		y[n].re = ar; y[n].im = ai; n++;
+		const float *hb = r->h + (r->phase >> (24 - r->bits)) * RS_TAPS;
+		y[n] = dot_rc(hb, r->win, RS_TAPS);
+		n++;
 		r->phase += r->step;
 	}
 	r->phase -= (1u << 24);
@@ -105,7 +217,7 @@ static int32_t resamp_push(resamp_t *r, orc_cf x, orc_cf *y)
 int32_t orc_resamp_run(float rate, const orc_cf *x, int32_t n, orc_cf *y, uint32_t *phase_io, orc_cf *hist14)
 {
 	resamp_t *r = malloc(sizeof(*r));
-	orc_resamp_filter(rate, r->h, &r->step);
+	resamp_init(r, rate);
 	r->phase = *phase_io;
 	memcpy(r->win, hist14, sizeof(r->win));
 	int32_t total = 0;
@@ -124,7 +236,8 @@ static orc_cf agc_step(agc_t *a, orc_cf x)
 {
 	orc_cf y = { x.re * a->g, x.im * a->g };
 	float e = y.re * y.re + y.im * y.im;
-	a->y2 = (1.0f - a->alpha) * a->y2 + a->alpha * e;
+	if (orc_v.agc_double) a->y2 = (float)((1.0 - a->alpha) * a->y2 + a->alpha * e);      /* liquid writes (1.0 - alpha): a double expression */
+	else a->y2 = (1.0f - a->alpha) * a->y2 + a->alpha * e;
 	if (a->y2 > 1e-6f) a->g *= expf(-0.5f * a->alpha * logf(a->y2));
 	if (a->g > 1e6f) a->g = 1e6f;
 	return y;
@@ -177,6 +290,7 @@ typedef struct {
 static void symsync_reset(symsync_t *s)
 {
 	memset(s->win_mf, 0, sizeof(s->win_mf));
+	if (orc_v.symsync_reset_both) memset(s->win_dmf, 0, sizeof(s->win_dmf));
 	s->rate = (float)SS_K / (float)SS_KOUT;
 	s->del = s->rate;
 	s->b = 0; s->bf = 0.0f; s->tau = 0.0f; s->q = 0.0f; s->q_hat = 0.0f;
@@ -198,10 +312,7 @@ static void symsync_init(symsync_t *s, float lf_bw)
 
 static orc_cf bank_dot(const float *h, const orc_cf *w)
 {
-	float ar = 0, ai = 0;
-	for (int k = 0; k < SS_TAPS; k++) { ar += h[k] * w[k].re; ai += h[k] * w[k].im; }
-	orc_cf y = { ar, ai };
-	return y;
+	return dot_rc(h, w, SS_TAPS);
 }
 
 /* one input sample -> 0..2 outputs */
@@ -232,7 +343,7 @@ static int32_t symsync_step(symsync_t *s, orc_cf x, orc_cf *y)
 		s->decim_counter++;
 		s->tau += s->del;
 		s->bf = s->tau * (float)SS_NPFB;
-		s->b = (int)roundf(s->bf);
+		s->b = orc_v.symsync_bank_floor ? (int)floorf(s->bf) : (int)roundf(s->bf);
 		n++;
 	}
 	s->tau -= 1.0f;
@@ -309,11 +420,14 @@ static void eqlms_step(eqlms_t *e, orc_cf d, orc_cf d_hat)
 	}
 	/* w += mu * conj(d - d_hat) * x / sum|x|^2 */
 	float er = d.re - d_hat.re, ei = -(d.im - d_hat.im);
+	float norm = e->x2_sum;
+	if (orc_v.eqlms_norm == 1) { norm = 0.f; for (int i = 0; i < EQ_LEN; i++) norm += e->x2[i]; }
+	else if (orc_v.eqlms_norm == 2) norm = 1.0f;
 	for (int i = 0; i < EQ_LEN; i++) {
 		float pr = er * e->buf[i].re - ei * e->buf[i].im;
 		float pi = er * e->buf[i].im + ei * e->buf[i].re;
-		e->w[i].re = e->w[i].re + e->mu * pr / e->x2_sum;
-		e->w[i].im = e->w[i].im + e->mu * pi / e->x2_sum;
+		e->w[i].re = e->w[i].re + e->mu * pr / norm;
+		e->w[i].im = e->w[i].im + e->mu * pi / norm;
 	}
 }
 
@@ -401,6 +515,8 @@ struct orc_channel {
 	uint64_t pdu_sample_index;
 	float freq_err_hz, signal_level, noise_floor;
 	uint32_t cnt_a2_found, cnt_m1_found, cnt_m1_not_found, cnt_frames;   /* statsd increments, src/hfdl.c:818,828,840 */
+	uint32_t cnt_a1_found, cum_train_bad, cum_train_total;               /* S.A1_found, S.train_bits_*, :786, :962-963 */
+	float corr_total[3];                                                  /* S.A1_corr_total, S.A2_corr_total, S.M1_corr_total */
 	/* stage taps */
 	orc_cf *resampled; int32_t resampled_cap, resampled_n;
 	orc_cf *mf_out; float *agc_level;
@@ -437,7 +553,7 @@ orc_channel *orc_channel_create(int32_t sample_rate, int32_t decimation, float t
 	orc_channel *c = calloc(1, sizeof(*c));
 	c->chan_freq = frequency;
 	c->resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)decimation);
-	orc_resamp_filter(c->resamp_rate, c->rs.h, &c->rs.step);
+	resamp_init(&c->rs, c->resamp_rate);
 	float freq_shift = (float)(centerfreq - (frequency + 1440)) / (float)sample_rate;
 	if (orc_fastddc_init(&c->ddc, transition_bw, decimation, freq_shift)) { free(c); return NULL; }
 	c->has_channelizer = want_channelizer;
@@ -481,6 +597,13 @@ void orc_channel_counters(const orc_channel *c, uint32_t out[4], float *noise_fl
 }
 const orc_cf *orc_channel_taps(const orc_channel *c) { return c->taps_fft; }
 
+void orc_channel_summary(const orc_channel *c, uint32_t out[6], float corr[3])
+{
+	out[0] = c->cnt_a1_found; out[1] = c->cnt_a2_found; out[2] = c->cnt_m1_found; out[3] = c->cnt_m1_not_found;
+	out[4] = c->cum_train_bad; out[5] = c->cum_train_total;
+	for (int i = 0; i < 3; i++) corr[i] = c->corr_total[i];
+}
+
 void orc_channel_taps_view(const orc_channel *c, orc_taps_view *v)
 {
 	v->chan_out = c->chan_out; v->chan_out_n = c->chan_out_n;
@@ -521,6 +644,8 @@ static void count_train_errors(orc_channel *c)
 	int err = __builtin_popcount(0x9AFu ^ seq);
 	c->train_bits_total += T_LEN;
 	c->train_bits_bad += err;
+	c->cum_train_total += T_LEN;
+	c->cum_train_bad += (uint32_t)err;
 }
 
 /* everything after the equaliser for one on-time symbol: src/hfdl.c:737-891 */
@@ -560,6 +685,8 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 	case FR_A1: {
 		float corr = 2.0f * (float)bits_correlate(&seq_A, &c->bits) / (float)A_LEN - 1.0f;
 		if (fabsf(corr) > 0.36f) {
+			c->cnt_a1_found++;
+			c->corr_total[0] += fabsf(corr);
 			c->bitmask = corr > 0.f ? 0 : ~0u;
 			c->signal_level = 1.0f / c->agc.g;
 			c->frame_symbol_cnt = 1.0f;
@@ -572,6 +699,7 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 		float corr = 2.0f * (float)bits_correlate(&seq_A, &c->bits) / (float)A_LEN - 1.0f;
 		if (fabsf(corr) > 0.3f) {
 			c->cnt_a2_found++;
+			c->corr_total[1] += fabsf(corr);
 			c->pdu_sample_index = c->sample_cnt;   /* reference: wall clock, :808-809 */
 			c->freq_err_hz = (float)(c->loop.dphi * 1800 / (2.0 * M_PI));
 			c->symbols_wanted = M1_LEN;
@@ -589,6 +717,7 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 		}
 		if (fabsf(best) > 0.3f) {
 			c->cnt_m1_found++;
+			c->corr_total[2] += fabsf(best);
 			c->data_segment_cnt = orc_modes[best_idx].segments;
 			c->data_arity = orc_modes[best_idx].arity;
 			c->M1 = best_idx;
@@ -654,8 +783,7 @@ static void process_resampled(orc_channel *c, orc_pdu_sink sink, void *ctx)
 		c->agc_level[k] = 1.0f / c->agc.g;
 		memmove(c->mf_win + 1, c->mf_win, sizeof(orc_cf) * 18);
 		c->mf_win[0] = r;
-		orc_cf s = { 0, 0 };
-		for (int t = 0; t < 19; t++) { s.re += MF_TAPS[t] * c->mf_win[t].re; s.im += MF_TAPS[t] * c->mf_win[t].im; }
+		orc_cf s = dot_rc(MF_TAPS, c->mf_win, 19);
 		c->mf_out[k] = s;
 		if (c->fr_state == FR_A1 && (++c->nf_clk & 0xFFu) == 0xFFu) {
 			float lvl = 1.0f / c->agc.g;

@@ -11,6 +11,8 @@
 #include <string.h>
 #include "hfdl_oracle.h"
 
+extern orc_variant orc_v;       /* channel_restated.c */
+
 static inline int parity32(uint32_t x)
 {
 	x ^= x >> 16; x ^= x >> 8; x ^= x >> 4; x ^= x >> 2; x ^= x >> 1;
@@ -220,6 +222,32 @@ void orc_training_T(uint8_t bits[15])
  * (src/hfdl.c:300-347): state 0x4d4b, taps 0x4001, b = parity(state & taps), state = (state<<1 | b) */
 void orc_scrambler_bits(uint8_t *bits, int32_t n)
 {
+	if (orc_v.lfsr_kind == 1) {
+		/* the pre-1.6 msequence API as src/hfdl.c:331-333 feeds it (genpoly 0x8002, init 0x6959), restated literally:
+		 * msequence_create keeps g = genpoly >> 1 and a = the m-bit reversal of init; advance: b = parity(v & g), v = (v << 1 | b) & (2^m - 1) */
+		const uint32_t m = 15, g = 0x8002u >> 1;
+		uint32_t a = 0, init = 0x6959u;
+		for (uint32_t i = 0; i < m; i++) { a = (a << 1) | (init & 1u); init >>= 1; }
+		uint32_t v = a;
+		for (int32_t i = 0; i < n; i++) {
+			if (i % 120 == 0) v = a;
+			uint32_t b = (uint32_t)parity32(v & g);
+			v = ((v << 1) | b) & ((1u << m) - 1);
+			bits[i] = (uint8_t)b;
+		}
+		return;
+	}
+	if (orc_v.lfsr_kind == 2) {
+		/* the other way to read "msequence_create(15, 0x4001, 0x4d4b)": a register shifting RIGHT, feedback into the top bit */
+		uint32_t v = 0x4d4b;
+		for (int32_t i = 0; i < n; i++) {
+			if (i % 120 == 0) v = 0x4d4b;
+			uint32_t b = (uint32_t)parity32(v & 0x4001);
+			v = (v >> 1) | (b << 14);
+			bits[i] = (uint8_t)b;
+		}
+		return;
+	}
 	uint32_t v = 0x4d4b;
 	for (int32_t i = 0; i < n; i++) {
 		if (i % 120 == 0) v = 0x4d4b;
@@ -290,7 +318,10 @@ uint32_t orc_modem_demod_hard(int arity, orc_cf x, float *phase_error)
 		sym = gray_enc(s);
 		xh = orc_modem_modulate(arity, sym);
 	}
-	if (phase_error) *phase_error = x.im * xh.re - x.re * xh.im;
+	if (phase_error) {
+		*phase_error = x.im * xh.re - x.re * xh.im;
+		if (orc_v.perr_kind == 1) *phase_error = atan2f(x.im * xh.re - x.re * xh.im, x.re * xh.re + x.im * xh.im);
+	}
 	return sym;
 }
 
@@ -325,7 +356,8 @@ void orc_modem_demod_soft(int arity, orc_cf x, uint8_t *soft)
 	float er = x.re - xh.re, ei = x.im - xh.im;
 	float d = er * er + ei * ei;
 	for (int k = 0; k < arity; k++) {
-		if ((sym >> (arity - k - 1)) & 1) { d0[k] = 4.0f; d1[k] = d; } else { d0[k] = d; d1[k] = 4.0f; }
+		const float far = orc_v.soft_dmin_init;
+		if ((sym >> (arity - k - 1)) & 1) { d0[k] = far; d1[k] = d; } else { d0[k] = d; d1[k] = far; }
 	}
 	uint32_t lin = gray_dec(sym);
 	for (int nb = 0; nb < 2; nb++) {

@@ -110,6 +110,33 @@ uint32_t orc_modem_demod_hard(int arity, orc_cf x, float *phase_error);
 uint32_t orc_modem_demod_hard(int arity, orc_cf x, float *phase_error);
 orc_cf  orc_modem_modulate(int arity, uint32_t sym);
 
+/* ---------------- variant switches: sensitivity of the result to the UNPINNED readings ----------------
+ * liquid-dsp is absent here, so every choice below is a recollection or differs between liquid releases.  The defaults (all zero,
+ * dmin 4.0) are the restatement every parity test uses and the GPU implements; profiles/variant_study.py decodes the same traffic
+ * under each alternative and tabulates which ones change a decoded octet (profiles/r03_variant_sensitivity.md).  A variant is
+ * process-global: set it, THEN create channels (filter tables are designed at create time). */
+typedef struct {
+	int32_t symsync_reset_both;  /* symsync_crcf_reset: 0 = clears the matched-filter bank only (default), 1 = both banks */
+	int32_t resamp_kind;         /* arbitrary resampler of msresamp_crcf: 0 = 24-bit fixed-point phase, 256 branches, fc = min(0.515 r, 0.49)
+	                                (liquid >= 1.3.2); 1 = float phase + linear interpolation between adjacent branches, 64 branches,
+	                                fc = 0.4 (liquid <= 1.3.1 as recollected); 2 = float phase + interpolation, 256 branches, fc as 0;
+	                                3 = fixed phase, 64 branches, fc as 0 */
+	int32_t kaiser_arg;          /* Kaiser window argument: 0 = 2t/N (default), 1 = 2t/(N-1) */
+	float   soft_dmin_init;      /* 8-PSK soft de-mapper: initial "nearest 0 / 1" distance (default 4.0) */
+	int32_t lfsr_kind;           /* scrambler: 0 = v = (v<<1 | b), taps 0x4001, fill 0x4d4b (default = msequence API of liquid >= 1.6);
+	                                1 = the pre-1.6 API restated literally: genpoly 0x8002 >> 1, fill = bit-reversed 0x6959 (must equal 0);
+	                                2 = a right-shifting register with the same numbers (the other way to read the new API) */
+	int32_t eqlms_norm;          /* eqlms step normalisation: 0 = running sum of |x|^2 (default), 1 = sum recomputed every step, 2 = none */
+	int32_t agc_double;          /* agc y2 recursion: 0 = fp32 (default), 1 = evaluated in double as liquid's (1.0 - alpha) literal implies */
+	int32_t design_float;        /* filter design: 0 = double precision (default), 1 = single precision with liquid's series (besseli0f, sincf) */
+	int32_t perr_kind;           /* demodulator phase error: 0 = Im(r conj(x_hat)) (default), 1 = angle of r conj(x_hat) */
+	int32_t dot_order;           /* dot products: 0 = sequential (default), 1 = even / odd partial sums (a 4-lane SIMD dotprod) */
+	int32_t symsync_bank_floor;  /* filter-bank index: 0 = roundf(bf) (default), 1 = floorf(bf) */
+} orc_variant;
+void orc_variant_default(orc_variant *v);
+void orc_variant_set(const orc_variant *v);
+void orc_variant_get(orc_variant *v);
+
 /* ---------------- per-channel demodulator (src/hfdl.c:593-935) ---------------- */
 typedef struct {
 	int32_t freq;           /* channel frequency Hz */
@@ -133,6 +160,9 @@ const orc_ddc *orc_channel_ddc(const orc_channel *c);
 const orc_cf *orc_channel_taps(const orc_channel *c);
 /* StatsD counters of the hot path (src/hfdl.c:818,828,840) + noise floor (linear) + framer state */
 void orc_channel_counters(const orc_channel *c, uint32_t out[4], float *noise_floor, int *framer_state);
+/* the debug summary of src/hfdl.c:563-573 for one channel: out[0..5] = A1_found, A2_found, M1_found, M1_not_found, train_bits_bad,
+ * train_bits_total (all frames); corr[0..2] = sums of |corr| at the A1 / A2 / M1 detections */
+void orc_channel_summary(const orc_channel *c, uint32_t out[6], float corr[3]);
 /* one block of the shared spectrum -> PDUs (src/hfdl.c:662-891) */
 void orc_channel_process_spectrum(orc_channel *c, const orc_cf *spectrum, orc_pdu_sink sink, void *ctx);
 /* enter after the channelizer: n samples at fs/decimation */

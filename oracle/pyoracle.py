@@ -41,6 +41,13 @@ class TapsView(C.Structure):
                 ("agc_level", C.c_void_p)]
 
 
+class Variant(C.Structure):
+    """orc_variant (hfdl_oracle.h): switches for the unpinned readings; all zero / dmin 4.0 = the restatement the parity tests use."""
+    _fields_ = [("symsync_reset_both", C.c_int32), ("resamp_kind", C.c_int32), ("kaiser_arg", C.c_int32), ("soft_dmin_init", C.c_float),
+                ("lfsr_kind", C.c_int32), ("eqlms_norm", C.c_int32), ("agc_double", C.c_int32), ("design_float", C.c_int32),
+                ("perr_kind", C.c_int32), ("dot_order", C.c_int32), ("symsync_bank_floor", C.c_int32)]
+
+
 SINK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Pdu))
 
 
@@ -115,6 +122,10 @@ def lib():
         L.orc_channel_ddc.restype = C.POINTER(Ddc)
         L.orc_channel_ddc.argtypes = [C.c_void_p]
         L.orc_channel_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.orc_channel_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_variant_default.argtypes = [C.POINTER(Variant)]
+        L.orc_variant_set.argtypes = [C.POINTER(Variant)]
+        L.orc_variant_get.argtypes = [C.POINTER(Variant)]
         L.orc_channel_taps.restype = C.c_void_p
         L.orc_channel_taps.argtypes = [C.c_void_p]
         L.orc_channel_process_baseband.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, SINK, C.c_void_p]
@@ -163,6 +174,29 @@ def ref():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def set_variant(**kw):
+    """Process-global: applies to channels created afterwards (and to decode_user_data / the scrambler at call time).
+    set_variant() with no arguments restores the default restatement."""
+    v = Variant()
+    lib().orc_variant_default(C.byref(v))
+    for k, val in kw.items():
+        assert hasattr(v, k), k
+        setattr(v, k, val)
+    lib().orc_variant_set(C.byref(v))
+
+
+def get_variant():
+    v = Variant()
+    lib().orc_variant_get(C.byref(v))
+    return {n: getattr(v, n) for n, _ in Variant._fields_}
+
+
+def scrambler_bits(n):
+    out = np.zeros(n, np.uint8)
+    lib().orc_scrambler_bits(_p(out), n)
+    return out
 
 
 def cf(a):
@@ -312,6 +346,14 @@ class Channel:
                     mf_out=arr(v.mf_out, v.mf_out_n), symbols=arr(v.symbols, v.symbols_n),
                     agc_level=arr(v.agc_level, v.resampled_n, np.float32))
 
+    def summary(self):
+        """hfdl_print_summary's figures for this channel (src/hfdl.c:563-573)."""
+        cnt = (C.c_uint32 * 6)()
+        corr = (C.c_float * 3)()
+        lib().orc_channel_summary(self.h, cnt, corr)
+        return dict(a1_found=cnt[0], a2_found=cnt[1], m1_found=cnt[2], m1_not_found=cnt[3], train_bits_bad=cnt[4], train_bits_total=cnt[5],
+                    a1_corr_total=corr[0], a2_corr_total=corr[1], m1_corr_total=corr[2])
+
     def close(self):
         if self.h:
             lib().orc_channel_destroy(self.h)
@@ -347,6 +389,13 @@ class Frontend:
         nf, st = C.c_float(0), C.c_int(0)
         lib().orc_channel_counters(lib().orc_frontend_channel(self.h, i), cnt, C.byref(nf), C.byref(st))
         return dict(a2_found=cnt[0], m1_found=cnt[1], m1_not_found=cnt[2], frames=cnt[3], noise_floor=nf.value, framer_state=st.value)
+
+    def channel_summary(self, i):
+        ch = Channel.__new__(Channel)
+        ch.h = lib().orc_frontend_channel(self.h, i)
+        out = Channel.summary(ch)
+        ch.h = None
+        return out
 
     def channel_view(self, i):
         ch = Channel.__new__(Channel)

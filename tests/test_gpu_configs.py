@@ -114,7 +114,7 @@ def test_two_rank_bench_on_one_gpu():
     pr = r["per_rank"]
     assert [p["rank"] for p in pr] == [0, 1] and [p["stream_seed"] for p in pr] == [5, 6] and all(p["channels"] == 256 for p in pr)
     assert max(p["ms_per_step"] for p in pr) == pytest.approx(r["ms_per_step"], rel=1e-3)
-    assert sum(p["pdus"] for p in pr) == r["pdus_in_timed_region"] and all(p["fold_avg_ms"] > 0 and p["demod_avg_ms"] > 0 for p in pr)
+    assert sum(p["pdus"] for p in pr) == r["pdus_in_timed_region"] and all(p["fold_avg_ms"] > 0 and p["demod_ms_per_block"] > 0 for p in pr)
     assert r["distributed"]["backend"] == "gloo" and r["distributed"]["world_size"] == 2 and r["distributed"]["fallback"] is None
 
 
@@ -124,8 +124,8 @@ def test_rccl_path_at_world_size_one():
     gather of the run all go through RCCL on CUDA tensors -- at world size 1, but through the same calls."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "cfg2", "--steps", "16", "--warmup", "2",
-           "--backend", "nccl", "--no-cpu-baseline", "--no-extra-legs"]
+           "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "cfg2", "--steps", "26", "--warmup", "0",
+           "--backend", "nccl", "--no-cpu-baseline", "--no-extra-legs"]            # 26 steps = once around the resident stretch: every burst ends in it
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -133,7 +133,7 @@ def test_rccl_path_at_world_size_one():
     r = json.loads(lines[0])
     d = r["distributed"]
     assert d == dict(backend="nccl", requested="nccl", world_size=1, fallback=None), d      # RCCL came up: no gloo fall-back
-    assert r["n_gpus"] == 1 and r["steps"] == 16 and r["config"]["stream_seeds"] == [2]
+    assert r["n_gpus"] == 1 and r["steps"] == 26 and r["config"]["stream_seeds"] == [2]
     assert len(r["per_rank"]) == 1 and r["per_rank"][0]["rank"] == 0 and r["per_rank"][0]["pdus"] == r["pdus_in_timed_region"]
     assert r["per_rank"][0]["ms_per_step"] == pytest.approx(r["ms_per_step"], rel=1e-3)
     assert r["pdus_in_timed_region"] > 0 and r["pdus_matching_sent_payload"] == r["pdus_in_timed_region"]

@@ -613,17 +613,24 @@ def test_prefetched_uploads_same_pdus(gpu, oracle):
         fe.prefetch_host_ptr(ptr(1), F.SFMT_CS16)                       # one at a time
     with pytest.raises(gpu.GpuError):
         fe.push_host_ptr(ptr(1), F.SFMT_CS16)                           # not the prefetched block
+    dev_blk = np.zeros(n, np.complex64)
+    with pytest.raises(gpu.GpuError):
+        fe.push_block(dev_blk)                                          # nor anything else while the prefetch is pending ...
+    fe.prefetch_cancel()                                                # ... until it is cancelled: the front end takes any block again
+    fe.prefetch_cancel()                                                # (no-op without a prefetch)
+    fe.input_done_upto(0)                                               # the cancelled block kept its number: answers at once
+    fe.prefetch_host_ptr(ptr(0), F.SFMT_CS16)                           # host block 1 from here on
     for b in range(nb):
         fe.push_host_ptr(ptr(b), F.SFMT_CS16)
         if b + 1 < nb:
             fe.prefetch_host_ptr(ptr(b + 1), F.SFMT_CS16)
         if b >= 1:
-            fe.input_done_upto(b - 1)                                   # three host blocks outstanding: b-1, b, b+1
+            fe.input_done_upto(b)                                       # (host block b = stream block b-1, after the cancelled one) three outstanding
         got += fe.poll_pdus(max_in_flight=1)
         ora.push_block(xq[b * n:(b + 1) * n])
     got += fe.poll_pdus()
     with pytest.raises(gpu.GpuError):
-        fe.input_done_upto(nb)                                          # never uploaded
+        fe.input_done_upto(nb + 1)                                      # never uploaded
     fe.input_done_upto(0)                                               # long overwritten events: still answers
     pageable = np.zeros(2 * n, np.int16)
     with pytest.raises(gpu.GpuError):
@@ -632,6 +639,60 @@ def test_prefetched_uploads_same_pdus(gpu, oracle):
     assert sorted(map(key, got)) == sorted(map(key, ora.pdus)) and len(got) >= len(bursts) - 1
     fe.close()
     gpu.host_free(hbuf)
+
+
+def test_demodulator_batching_changes_nothing(gpu, oracle, monkeypatch):
+    """On the demodulator-bound geometries one demodulator launch takes several consecutive blocks when they are pushed faster than
+    they are collected (hfdl_gpu_geometry.demod_batch).  The per-channel state is carried sample by sample, so every PDU -- octets,
+    detection sample, frequency error, levels, training-bit counts -- and every channel's counters equal those of a launch per block
+    (HFDL_GPU_DEMOD_BATCH=1), whatever mix of pushes, lagging collections and draining polls cuts the batches."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000, 10_101_000]
+    dur = 16.0
+    bursts = synth.plan_traffic(freqs, dur, seed=77, dense=True, gap_s=0.12, amp=(0.02, 0.1))
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.012, seed=77)
+
+    def run(batch_env, pattern):
+        if batch_env is None:
+            monkeypatch.delenv("HFDL_GPU_DEMOD_BATCH", raising=False)
+        else:
+            monkeypatch.setenv("HFDL_GPU_DEMOD_BATCH", str(batch_env))
+        fe = gpu.Frontend(fs, cf, freqs)
+        n, got = fe.input_size, []
+        for b in range(len(x) // n):
+            fe.push_block(x[b * n:(b + 1) * n])
+            if pattern == "lagging":
+                got += fe.poll_pdus(max_in_flight=1)
+            elif pattern == "ragged" and b % 7 in (2, 3):           # a draining poll every few blocks: batches of 3, 1 and 4 blocks
+                got += fe.poll_pdus()
+        got += fe.poll_pdus()
+        stats = fe.all_channel_stats()
+        batch = fe.geometry.demod_batch
+        fe.close()
+        return sorted(got, key=lambda p: (p["freq"], p["sample_index"])), stats, batch
+
+    ref, ref_stats, b1 = run(1, "end")
+    assert b1 == 1 and len(ref) >= len(bursts) - 2
+    for pattern in ("end", "lagging", "ragged"):
+        got, stats, bn = run(None, pattern)
+        assert bn >= 2, "this geometry (0.115 s blocks, 5 channels) batches"
+        assert got == ref, pattern                                    # every field of every PDU
+        assert stats == ref_stats, pattern
+    # and what a launch per block gives is what the oracle gives
+    ora = oracle.Frontend(fs, cf, freqs)
+    n = ora.ddc.input_size
+    for b in range(len(x) // n):
+        ora.push_block(x[b * n:(b + 1) * n])
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, ref)) == sorted(map(key, ora.pdus))
+    # the reference's debug summary (hfdl_print_summary, src/hfdl.c:563-573) per channel, from the device state
+    for c in range(len(freqs)):
+        want, have = ora.channel_summary(c), ref_stats[c]
+        assert (have["a1_found"], have["a2_found"], have["m1_found"], have["m1_not_found"]) == (want["a1_found"], want["a2_found"], want["m1_found"], want["m1_not_found"])
+        assert (have["train_bits_bad"], have["train_bits_total"]) == (want["train_bits_bad"], want["train_bits_total"])
+        for k, cnt in (("a1", "a1_found"), ("a2", "a2_found"), ("m1", "m1_found")):
+            if want[cnt]:
+                assert have[k + "_corr_avg"] == pytest.approx(want[k + "_corr_total"] / want[cnt], rel=1e-5)
 
 
 def test_full_pdu_ring_drops_and_counts(gpu, oracle, monkeypatch):
