@@ -64,10 +64,13 @@ def make_input(w, geom_input_size, rank, world, shard_mode="streams"):
     from dumphfdl_amd import shard
     seed = shard.stream_seed(w["seed"], rank, world) if shard_mode == "streams" else w["seed"]
     nsamp = w["blocks"] * geom_input_size
-    cache = "/tmp/hfdl_bench_%s_seed%d_%d%s.npy" % (w["fs"], seed, nsamp, "_dense" if w.get("dense") else "")
     freqs = channel_plan(w)
     dur = nsamp / w["fs"]
     bursts = plan_bursts(w, freqs, dur, seed)
+    # the cached stream belongs to THIS traffic plan: a file left by another version of the plan (other payloads) is not reused
+    import zlib
+    tag = zlib.crc32(b"".join(b["octets"] + bytes([b["mode"]]) + np.float64([b["t0"], b["amp"], b["cfo"]]).tobytes() for b in bursts))
+    cache = "/tmp/hfdl_bench_%s_seed%d_%d%s_%08x.npy" % (w["fs"], seed, nsamp, "_dense" if w.get("dense") else "", tag)
     def cached():
         if os.path.exists(cache):
             x = np.load(cache, mmap_mode="r")

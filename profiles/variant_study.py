@@ -273,6 +273,34 @@ def write_markdown(rep, path):
     L.append("|---|---|")
     for n, d in list(rep["rx_variants"].items()) + list(rep["tx_variants"].items()):
         L.append("| `%s` | %s |" % (n, d))
+    names = list(rep["sets"].keys())
+    L.append("")
+    L.append("## Summary 1 -- frames whose OCTETS change against the default reading (same place +-3 samples, other octets); `=`: the PDU set is identical, `p`: same octets, only the detection sample moves")
+    L.append("")
+    L.append("| variant | " + " | ".join(names) + " |")
+    L.append("|---|" + "---|" * len(names))
+    for n in rep["rx_variants"]:
+        if n == "default":
+            continue
+        cells = []
+        for sn in names:
+            v = rep["sets"][sn]["rows"].get(n, {}).get("vs_default")
+            cells.append("-" if v is None else ("=" if v["identical"] else (str(v["octets_changed"]) if v["octets_changed"] else "p")))
+        L.append("| `%s` | %s |" % (n, " | ".join(cells)))
+    L.append("")
+    L.append("## Summary 2 -- sent payloads recovered (of the bursts in the set)")
+    L.append("")
+    L.append("| variant | " + " | ".join("%s (%d)" % (sn, rep["sets"][sn]["bursts"]) for sn in names) + " |")
+    L.append("|---|" + "---|" * len(names))
+    for n in list(rep["rx_variants"]) + list(rep["tx_variants"])[1:]:
+        L.append("| `%s` | %s |" % (n, " | ".join(str(rep["sets"][sn]["rows"][n]["recovered"]) if n in rep["sets"][sn]["rows"] else "-" for sn in names)))
+    L.append("")
+    L.append("## Summary 3 -- `M1_not_found` (A2 found, M1 search failed: the burst is lost) per set")
+    L.append("")
+    L.append("| variant | " + " | ".join(names) + " |")
+    L.append("|---|" + "---|" * len(names))
+    for n in list(rep["rx_variants"]) + list(rep["tx_variants"])[1:]:
+        L.append("| `%s` | %s |" % (n, " | ".join(str(rep["sets"][sn]["rows"][n]["m1_not_found"]) if n in rep["sets"][sn]["rows"] else "-" for sn in names)))
     for sname, s in rep["sets"].items():
         L.append("")
         L.append("## %s -- %d bursts" % (sname, s["bursts"]))
@@ -293,4 +321,13 @@ def write_markdown(rep, path):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--merge":          # --merge OUT.json PART.json ...: sets of the parts replace those of OUT, the table is re-rendered
+        rep = json.load(open(sys.argv[2]))
+        for part in sys.argv[3:]:
+            rep["sets"].update(json.load(open(part))["sets"])
+        order = ["cfg3", "cfg4", "bb20"] + ["snr%+d" % k for k in range(-6, 11, 2)]
+        rep["sets"] = {k: rep["sets"][k] for k in order if k in rep["sets"]}
+        json.dump(rep, open(sys.argv[2], "w"), indent=1)
+        write_markdown(rep, sys.argv[2][:-5] + ".md")
+    else:
+        main()
