@@ -234,7 +234,19 @@ def parity_gate(w, x, input_size, hf, dev_index, cores, max_seconds=25.0):
     want = sorted(pdu_key(p) for p in ora.pdus)
     fe.close()
     ora.close()
+    # ... and where "identical" stops: the same comparison on traffic binned by in-channel SNR (64 channels at 1 Msps, 128 bursts per
+    # bin, all eight modes; the full sweep -8 .. +10 dB is tests/test_gpu_low_snr.py)
+    low = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import low_snr_parity
+        low = [{k: r[k] for k in ("snr_db", "bursts", "gpu_pdus", "oracle_pdus", "common", "gpu_only", "oracle_only", "identical",
+                                   "gpu_recovered", "oracle_recovered")}
+               for r in low_snr_parity.sweep(hf, pyoracle, [-6, -2, 2, 6], bursts_per_channel=2, device=dev_index)]
+    except Exception as e:                  # noqa: BLE001 -- an extra, never fatal to the line
+        low = dict(error="%s: %s" % (type(e).__name__, e))
     return dict(channels=cs, blocks=nblk, oracle_build="strict (-O3 -ffp-contract=off, no fast-math; bit-pinned parts see tests/golden)",
+                low_snr_bins=low,
                 chan_out_rel_rms=worst, chan_out_rel_rms_limit=1e-4, chan_out_within_limit=bool(worst <= 1e-4),
                 gpu_pdus=len(got), cpu_pdus=len(want), pdu_multisets_identical=bool(got == want),
                 compared="(freq, sample_index, mode, octets) of every PDU both sides dispatched on these channels and blocks")

@@ -339,8 +339,13 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				s.phi = ph > (float)M_PI ? dn : (ph < -(float)M_PI ? up : ph);
 			}
 			// |phi| <= pi: the hardware sin/cos (argument in revolutions) needs no range reduction
+#ifdef HFDL_DM_LIBM_TRIG              // experiment (profiles/r03_experiments.md): the library's accurate sincosf instead of v_sin / v_cos
+			float sp, cp;
+			sincosf(s.phi, &sp, &cp);
+#else
 			const float rev = s.phi * 0.15915494309189535f;
 			const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
+#endif
 			cf r;
 			r.x = oi.x * cp + oi.y * sp;
 			r.y = oi.y * cp - oi.x * sp;
