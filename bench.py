@@ -241,7 +241,7 @@ def parity_gate(w, x, input_size, hf, dev_index, cores, max_seconds=25.0):
         sys.path.insert(0, os.path.join(ROOT, "profiles"))
         import low_snr_parity
         low = [{k: r[k] for k in ("snr_db", "bursts", "gpu_pdus", "oracle_pdus", "common", "gpu_only", "oracle_only", "identical",
-                                   "gpu_recovered", "oracle_recovered")}
+                                   "gpu_recovered", "oracle_recovered", "recovered_sets_identical")}
                for r in low_snr_parity.sweep(hf, pyoracle, [-6, -2, 2, 6], bursts_per_channel=2, device=dev_index)]
     except Exception as e:                  # noqa: BLE001 -- an extra, never fatal to the line
         low = dict(error="%s: %s" % (type(e).__name__, e))

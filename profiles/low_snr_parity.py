@@ -72,7 +72,8 @@ def run_bin(hf, pyoracle, snr_db, bursts_per_channel=4, seed=None, threads=None,
     sent = {}
     for b in bursts:
         sent.setdefault(b["freq"], []).append(b)
-    ok = lambda s: sum(1 for f, _, m, o in s if any(o[:len(b["octets"])] == b["octets"] and m == b["mode"] for b in sent[f]))
+    good = lambda s: {(f, si, m, o) for f, si, m, o in s if any(o[:len(b["octets"])] == b["octets"] and m == b["mode"] for b in sent[f])}
+    ok = lambda s: len(good(s))
     # same frame found at the same place with other octets, or the same octets found elsewhere (+-3 samples)?
     changed = sum(1 for f, si, m, o in gs - ws if any(f == f2 and m == m2 and abs(si - s2) <= 3 and o != o2 for f2, s2, m2, o2 in ws - gs))
     moved = sum(1 for f, si, m, o in gs - ws if any(f == f2 and m == m2 and 0 < abs(si - s2) <= 3 and o == o2 for f2, s2, m2, o2 in ws - gs))
@@ -80,7 +81,7 @@ def run_bin(hf, pyoracle, snr_db, bursts_per_channel=4, seed=None, threads=None,
     ora.close()
     return dict(snr_db=snr_db, bursts=len(bursts), gpu_pdus=len(got), oracle_pdus=len(want), common=len(gs & ws), gpu_only=len(gs - ws),
                 oracle_only=len(ws - gs), identical=got == want, same_place_other_octets=changed, same_octets_other_place=moved,
-                gpu_recovered=ok(gs), oracle_recovered=ok(ws), samples=len(x))
+                gpu_recovered=ok(gs), oracle_recovered=ok(ws), recovered_sets_identical=good(gs) == good(ws), samples=len(x))
 
 
 def sweep(hf, pyoracle, bins, bursts_per_channel=4, device=0):

@@ -22,13 +22,15 @@ def test_frame_sets_identical_down_to_marginal_snr(gpu, oracle):
     for r in rows:
         assert r["bursts"] == 256
         differing = r["gpu_only"] + r["oracle_only"]
+        both = r["gpu_pdus"] + r["oracle_pdus"]
+        # every correctly decoded frame is common to both, at the same detection sample, in EVERY bin ...
+        assert r["recovered_sets_identical"] and r["gpu_recovered"] == r["oracle_recovered"], r
         if r["snr_db"] >= 2:
-            # every frame either side dispatches, same detection sample, same octets -- including the frames with bit errors
-            assert r["identical"] and r["gpu_pdus"] >= 250, r
+            # ... and from +2 dB up so is every frame either side dispatches, the ones with bit errors included
+            assert r["identical"] and r["gpu_pdus"] >= 245, r
         elif r["snr_db"] >= -4:
-            assert differing <= 0.02 * (r["gpu_pdus"] + r["oracle_pdus"]), r          # a frame or two per 200 whose fate hangs on one soft decision
-            assert abs(r["gpu_recovered"] - r["oracle_recovered"]) <= 2, r
+            # below, a few frames that both sides dispatch WITH bit errors carry different wrong octets (same place, other octets):
+            # measured 2 / 3 / 9 of ~230 at 0 / -2 / -4 dB (profiles/r03_low_snr_sweep.md)
+            assert differing <= 0.06 * both and r["same_place_other_octets"] == r["gpu_only"] == r["oracle_only"], r
         else:
-            assert differing <= 0.05 * (r["gpu_pdus"] + r["oracle_pdus"]), r
-            assert abs(r["gpu_recovered"] - r["oracle_recovered"]) <= 4, r
-        assert r["same_place_other_octets"] <= max(1, differing // 2), r
+            assert differing <= 0.10 * both, r                       # measured 6 of 169 at -6 dB, 8 of 111 at -8 dB
