@@ -121,11 +121,7 @@ struct hfdl_gpu_frontend {
 	double demod_ms = 0;
 	int64_t demod_launches = 0, demod_timed_blocks = 0;
 	hipStream_t stream_c = nullptr;     // C: host -> device copies of block k+1 into the other staging buffer
-	// one copy engine moves a 7 MB block at 13-30 GB/s; a block cut in `copy_ways` pieces on as many streams uses that many engines
-	// (HFDL_GPU_COPY_STREAMS, measured in profiles/r03_experiments.md).  Pieces join on stream C, which carries every event.
-	int copy_ways = 1;
-	hipStream_t stream_cx[3] = { nullptr, nullptr, nullptr };
-	hipEvent_t ev_cx[3] = { nullptr, nullptr, nullptr };
+
 	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
 	hipEvent_t ev_stage_ready[2] = { nullptr, nullptr }, ev_stage_free[2] = { nullptr, nullptr };
 	uint64_t host_blocks = 0;
@@ -181,10 +177,6 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	if (fe->stream_b) (void)hipStreamSynchronize(fe->stream_b);
 	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamSynchronize(fe->stream_d);
 	if (fe->stream_c) (void)hipStreamSynchronize(fe->stream_c);
-	for (int i = 0; i < 3; i++) {
-		if (fe->stream_cx[i]) { (void)hipStreamSynchronize(fe->stream_cx[i]); (void)hipStreamDestroy(fe->stream_cx[i]); }
-		if (fe->ev_cx[i]) (void)hipEventDestroy(fe->ev_cx[i]);
-	}
 	for (int i = 0; i < 2; i++)
 		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_dm[i], fe->ev_stage_ready[i], fe->ev_stage_free[i], fe->ev_copy[i], fe->ev_copy[i + 2] }) if (e) (void)hipEventDestroy(e);
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -341,14 +333,6 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 		FE_TRY(hipStreamCreateWithFlags(&fe->stream_b, hipStreamNonBlocking));
 	}
 	FE_TRY(hipStreamCreateWithFlags(&fe->stream_c, hipStreamNonBlocking));
-	if (const char *e = getenv("HFDL_GPU_COPY_STREAMS")) {
-		const long v = strtol(e, nullptr, 10);
-		if (v >= 1 && v <= 4) fe->copy_ways = (int)v;
-	}
-	for (int i = 0; i + 1 < fe->copy_ways; i++) {
-		FE_TRY(hipStreamCreateWithFlags(&fe->stream_cx[i], hipStreamNonBlocking));
-		FE_TRY(hipEventCreateWithFlags(&fe->ev_cx[i], hipEventDisableTiming));
-	}
 	{
 		// The burst decoder of block k only hands PDUs to the host; the demodulator of block k+1 does not need it.  With few
 		// channels the demodulator (a serial recurrence per channel, ~0.3 ms per block whatever the channel count) bounds the
@@ -493,18 +477,8 @@ static int queue_input_copy(hfdl_gpu_frontend *fe, const void *iq, size_t nsampl
 		fe->stage_cap[sb] = nsamples;
 	}
 	HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_stage_free[sb], 0));     // stream A finished reading this buffer two blocks ago
-	const size_t total = sample_bytes(fmt) * nsamples;
-	const int ways = total >= ((size_t)1 << 20) ? fe->copy_ways : 1;
-	const size_t piece = ((total / (size_t)ways) + 255) & ~(size_t)255;
-	for (int w = 1; w < ways; w++) {                         // pieces 1.. on their own streams (their own copy engines)
-		const size_t at = piece * (size_t)w, len = at >= total ? 0 : std::min(piece, total - at);
-		if (!len) continue;
-		HIP_TRY(hipStreamWaitEvent(fe->stream_cx[w - 1], fe->ev_stage_free[sb], 0));
-		HIP_TRY(hipMemcpyAsync((char *)fe->d_stage[sb] + at, (const char *)iq + at, len, hipMemcpyHostToDevice, fe->stream_cx[w - 1]));
-		HIP_TRY(hipEventRecord(fe->ev_cx[w - 1], fe->stream_cx[w - 1]));
-	}
-	HIP_TRY(hipMemcpyAsync(fe->d_stage[sb], iq, ways > 1 ? std::min(piece, total) : total, hipMemcpyHostToDevice, fe->stream_c));
-	for (int w = 1; w < ways; w++) HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_cx[w - 1], 0));   // stream C's events stand for the whole block
+	// (one hipMemcpyAsync per block: cutting a block in 2 or 4 pieces on as many streams was measured and is slower, profiles/r03_experiments.md)
+	HIP_TRY(hipMemcpyAsync(fe->d_stage[sb], iq, sample_bytes(fmt) * nsamples, hipMemcpyHostToDevice, fe->stream_c));
 	HIP_TRY(hipEventRecord(fe->ev_stage_ready[sb], fe->stream_c));
 	HIP_TRY(hipEventRecord(fe->ev_copy[j & 3], fe->stream_c));
 	// a buffer this library did not allocate may be reused by the caller as soon as we return (include/hfdl_gpu.h): do not

@@ -340,11 +340,29 @@ static void *frontend_thread(void *ctx)
 		const double tw2 = now_s();
 		s_push += tw2 - tw1;
 		/* Keeping up with the source (live radio): wait for this block and deliver its PDUs at once.  Behind (file
-		 * replay, catching up): leave it running and collect the previous block, so the producer's reads and the copy of
-		 * this block overlap it. */
+		 * replay, catching up): leave it running and collect the previous block (or batch of blocks), so the producer's reads
+		 * and the copy of this block overlap it. */
+		/* "Keeping up" is only believed after a moment's grace: a source that delivers the next block a few hundred microseconds
+		 * late (a file reader that is about as fast as the GPU) is not a live radio, and draining the pipeline for it would idle
+		 * the GPU for a whole block (or batch of blocks) every time.  A live source sends a block every ~0.1 s: the grace costs it
+		 * half a millisecond of latency. */
+		bool behind = backlog;
+		if (!behind && blk != NULL) {
+			const size_t held = leased - (prefetched ? 1 : 0);          /* pushed blocks still in the ring, this one included */
+			struct timespec until;
+			clock_gettime(CLOCK_REALTIME, &until);
+			until.tv_nsec += 500000;
+			if (until.tv_nsec >= 1000000000) { until.tv_sec++; until.tv_nsec -= 1000000000; }
+			pthread_mutex_lock(ring->mutex);
+			while (hfdl_ring_size(ring->buf) < (held + 1) * need && !block_connection_is_shutdown_signaled(block->consumer.in)) {
+				if (pthread_cond_timedwait(ring->cond, ring->mutex, &until) != 0) break;
+			}
+			behind = hfdl_ring_size(ring->buf) >= (held + 1) * need;
+			pthread_mutex_unlock(ring->mutex);
+		}
 		int32_t n = 0;
 		do {
-			if (hfdl_gpu_frontend_poll_pdus_ready(fe, pdus, max_pdus, &n, backlog ? 1 : 0) != 0) break;
+			if (hfdl_gpu_frontend_poll_pdus_ready(fe, pdus, max_pdus, &n, behind ? 1 : 0) != 0) break;
 			for (int32_t i = 0; i < n; i++) push_pdu(&pdus[i], &t0);
 			npdus += (uint64_t)n;
 		} while (n == max_pdus);
@@ -353,7 +371,7 @@ static void *frontend_thread(void *ctx)
 		/* Ring slots go back to the producer when the DMA engine has read them.  With a backlog the copies of the block just
 		 * pushed and of the prefetched one are NOT waited for -- only older ones (done long ago), so the copy engine never
 		 * idles on this thread; without a backlog the pipeline was drained above and everything is free. */
-		const size_t keep = backlog ? (prefetched ? 2u : 1u) : 0u;
+		const size_t keep = behind ? (prefetched ? 2u : 1u) : 0u;
 		while (leased > keep) {
 			/* the oldest leased block, as the GPU library numbers host blocks; on failure fall back to waiting for every copy, and
 			 * stop (slot kept) if even that fails: the producer must never overwrite memory the DMA engine may still read */
