@@ -132,6 +132,7 @@ static size_t read_fully(int fd, void *buf, size_t want)        /* what fread() 
  * One thread moves ~5-8 GB/s from the page cache; the front end takes cf32 at > 20 GB/s (2.7 Gsamples/s). */
 #define FILE_READERS_MAX 8
 #define FILE_PIECE (1u << 20)
+#define FILE_JOB_MAX ((size_t)64 << 20)
 struct read_pool {
 	pthread_t th[FILE_READERS_MAX];
 	int nthreads;
@@ -140,7 +141,9 @@ struct read_pool {
 	int fd;
 	char *dst;
 	off_t off;
-	size_t len, next, got;       /* one job at a time: bytes [next, len) are not yet claimed by a worker */
+	size_t len, next;            /* one job at a time: bytes [next, len) are not yet claimed by a worker */
+	size_t piece_got[FILE_JOB_MAX / FILE_PIECE];        /* bytes read into piece i ... */
+	unsigned char piece_done[FILE_JOB_MAX / FILE_PIECE]; /* ... once its worker is back */
 	int busy;                    /* workers inside pread() */
 	bool quit;
 };
@@ -164,9 +167,10 @@ static void *read_worker(void *ctx)
 			got += (size_t)k;
 		}
 		pthread_mutex_lock(&p->lock);
-		p->got += got;
+		p->piece_got[at / FILE_PIECE] = got;
+		p->piece_done[at / FILE_PIECE] = 1;
 		p->busy--;
-		if (p->next >= p->len && p->busy == 0) pthread_cond_signal(&p->done);
+		pthread_cond_signal(&p->done);       /* every piece: the caller hands finished pieces on in order, as they come */
 	}
 	pthread_mutex_unlock(&p->lock);
 	return NULL;
@@ -184,8 +188,10 @@ static void pool_start(struct read_pool *p, int fd)
 	for (int i = 0; i < want; i++) if (pthread_create(&p->th[p->nthreads], NULL, read_worker, p) == 0) p->nthreads++;
 }
 
-/* read [off, off+len) of the file into dst with all workers; returns the bytes read (short at end of file) */
-static size_t pool_read(struct read_pool *p, void *dst, off_t off, size_t len)
+/* Read [off, off+len) of the file (len <= FILE_JOB_MAX) into dst with all workers; returns the bytes read (short at end of file).
+ * progress(ctx, n) is called for every n further bytes that are in place IN ORDER from dst, as the pieces come in: the consumer
+ * sees the first megabytes of a 60 MB job while the rest is still being read, instead of nothing and then all of it. */
+static size_t pool_read(struct read_pool *p, void *dst, off_t off, size_t len, void (*progress)(void *ctx, size_t n), void *ctx)
 {
 	if (p->nthreads == 0 || len < 2 * FILE_PIECE) {
 		size_t got = 0;
@@ -195,13 +201,28 @@ static size_t pool_read(struct read_pool *p, void *dst, off_t off, size_t len)
 			if (k <= 0) break;
 			got += (size_t)k;
 		}
+		if (got) progress(ctx, got);
 		return got;
 	}
+	const size_t npieces = (len + FILE_PIECE - 1) / FILE_PIECE;
 	pthread_mutex_lock(&p->lock);
-	p->dst = dst; p->off = off; p->got = 0; p->next = 0; p->len = len;
+	memset(p->piece_done, 0, npieces);
+	p->dst = dst; p->off = off; p->next = 0; p->len = len;
 	pthread_cond_broadcast(&p->go);
-	while (p->next < p->len || p->busy > 0) pthread_cond_wait(&p->done, &p->lock);
-	size_t got = p->got;
+	size_t got = 0;
+	bool short_piece = false;               /* end of file met: what lies behind it in this job is not data */
+	for (size_t i = 0; i < npieces; i++) {
+		while (!p->piece_done[i]) pthread_cond_wait(&p->done, &p->lock);
+		const size_t want = len - i * FILE_PIECE < FILE_PIECE ? len - i * FILE_PIECE : FILE_PIECE, have = short_piece ? 0 : p->piece_got[i];
+		if (have) {
+			pthread_mutex_unlock(&p->lock);
+			progress(ctx, have);
+			pthread_mutex_lock(&p->lock);
+			got += have;
+		}
+		if (have < want) short_piece = true;
+	}
+	while (p->busy > 0) pthread_cond_wait(&p->done, &p->lock);
 	p->len = p->next = 0;
 	pthread_mutex_unlock(&p->lock);
 	return got;
@@ -219,6 +240,16 @@ static void pool_stop(struct read_pool *p)
 	pthread_cond_destroy(&p->done);
 }
 
+/* `n` more bytes are in place behind the pointer hfdl_ring_write_acquire() gave: make the whole samples readable, wake the consumer */
+static void commit_bytes(void *ctx, size_t n)
+{
+	struct circ_buffer *cb = ctx;
+	pthread_mutex_lock(cb->mutex);
+	hfdl_ring_write_commit(cb->buf, n);
+	pthread_mutex_unlock(cb->mutex);
+	pthread_cond_signal(cb->cond);
+}
+
 /* The ring's element is this file's sample (raw ring in front of the GPU front end, or a cf32 file into any cf32 ring,
  * where convert_cf32 is the identity: x / 1.0f): the file is read STRAIGHT into the ring's free space -- no conversion pass,
  * no bounce buffers.  Regular files are read a front-end block at a time by the reader pool; a pipe delivers what it has. */
@@ -228,7 +259,7 @@ static void file_loop_direct(struct input *in, struct file_input *fi, struct cir
 	if (fi->seekable) pool_start(&pool, fi->fd);
 	off_t off = 0;
 	int loops_left = g_file_loops;
-	const size_t chunk_max = fi->seekable ? (size_t)64 << 20 : (size_t)in->config->read_buffer_size;
+	const size_t chunk_max = fi->seekable ? FILE_JOB_MAX : (size_t)in->config->read_buffer_size;
 	for (;;) {
 		void *dst = NULL;
 		size_t room;
@@ -249,21 +280,22 @@ static void file_loop_direct(struct input *in, struct file_input *fi, struct cir
 		size_t want = room < chunk_max ? room : chunk_max;
 		size_t got;
 		if (fi->seekable) {
-			got = pool_read(&pool, dst, off, want);
+			got = pool_read(&pool, dst, off, want, commit_bytes, cb);       /* commits piece by piece */
 			off += (off_t)got;
 			if (got < want && --loops_left > 0) off = 0;            /* --loop: replay the file from the start */
 			else if (got < want) loops_left = 0;
+			if (got < want) {
+				pthread_mutex_lock(cb->mutex);
+				hfdl_ring_discard_partial(cb->buf);                   /* end of file: an incomplete last sample is dropped (whole_samples()) */
+				pthread_mutex_unlock(cb->mutex);
+			}
 		} else {
 			ssize_t n;
 			do n = read(fi->fd, dst, want); while (n < 0 && errno == EINTR);
 			got = n > 0 ? (size_t)n : 0;
 			if (got == 0) loops_left = 0;
+			commit_bytes(cb, got);
 		}
-		pthread_mutex_lock(cb->mutex);
-		hfdl_ring_write_commit(cb->buf, got);
-		if (got < want && fi->seekable) hfdl_ring_discard_partial(cb->buf);   /* end of file: an incomplete last sample is dropped (whole_samples()) */
-		pthread_mutex_unlock(cb->mutex);
-		pthread_cond_signal(cb->cond);
 		if (loops_left <= 0) break;
 	}
 	if (fi->seekable) pool_stop(&pool);
