@@ -275,7 +275,8 @@ static void *frontend_thread(void *ctx)
 	const int gfmt = gpu_format_of(hfdl_ring_format(ring->buf));
 	uint64_t k = 0, npdus = 0;
 	double t_first = 0, t_last = 0, t_published = 0;
-	double s_wait = 0, s_push = 0, s_poll = 0, s_release = 0;      /* where this thread's time went (seconds) */
+	double s_wait = 0, s_push = 0, s_poll = 0, s_release = 0, s_grace = 0;      /* where this thread's time went (seconds) */
+	uint64_t drains = 0;
 	size_t leased = 0;                       /* ring slots the GPU may still read (0..3), oldest first: pushed blocks, then a prefetched one */
 	bool prefetched = false;                 /* the newest leased slot has been uploaded ahead (prefetch) but not pushed yet */
 	uint64_t uploads = 0;                    /* host blocks whose copy has been queued, as the GPU library numbers them */
@@ -359,7 +360,9 @@ static void *frontend_thread(void *ctx)
 			}
 			behind = hfdl_ring_size(ring->buf) >= (held + 1) * need;
 			pthread_mutex_unlock(ring->mutex);
+			s_grace += now_s() - tw2;
 		}
+		if (!behind) drains++;
 		int32_t n = 0;
 		do {
 			if (hfdl_gpu_frontend_poll_pdus_ready(fe, pdus, max_pdus, &n, behind ? 1 : 0) != 0) break;
@@ -409,6 +412,7 @@ shutdown:
 		g_run.bytes_per_sample = (int32_t)elem; g_run.channels = (int32_t)nch; g_run.block_samples = (int32_t)need;
 		g_run.zero_copy = hfdl_ring_is_pinned(ring->buf);
 		g_run.wait_input_s = s_wait; g_run.push_s = s_push; g_run.collect_s = s_poll; g_run.release_s = s_release;
+		g_run.drains = drains; g_run.grace_s = s_grace;
 		g_run.mpdus_walked = g_lpdu_tally[0]; g_run.lpdus_processed = g_lpdu_tally[1]; g_run.lpdus_good = g_lpdu_tally[2]; g_run.lpdus_bad_fcs = g_lpdu_tally[3];
 		pthread_mutex_unlock(&g_run_lock);
 	}

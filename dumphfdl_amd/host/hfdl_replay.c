@@ -143,10 +143,10 @@ int main(int argc, char **argv)
 		struct hfdl_run_stats rs;
 		hfdl_frontend_run_stats(&rs);
 		printf("{\"tool\": \"hfdl_replay --bench\", \"value\": %.3f, \"unit\": \"Msamples/s\", \"samples\": %llu, \"blocks\": %llu, \"seconds\": %.6f, "
-				"\"pdus\": %llu, \"pdu_octets\": %llu, \"channels\": %d, \"block_samples\": %d, \"bytes_per_sample_over_pcie\": %d, \"zero_copy_ring\": %s, \"thread_s\": {\"wait_input\": %.4f, \"enqueue\": %.4f, \"collect\": %.4f, \"release\": %.4f}, "
+				"\"pdus\": %llu, \"pdu_octets\": %llu, \"channels\": %d, \"block_samples\": %d, \"bytes_per_sample_over_pcie\": %d, \"zero_copy_ring\": %s, \"thread_s\": {\"wait_input\": %.4f, \"enqueue\": %.4f, \"collect\": %.4f, \"release\": %.4f, \"grace\": %.4f}, \"pipeline_drains\": %llu, "
 				"\"lpdu_walk_on_device\": {\"mpdus\": %llu, \"lpdus\": %llu, \"good_fcs\": %llu, \"bad_fcs\": %llu}, \"shard\": \"%d/%d\", \"path\": \"file (page cache) -> file input (parallel pread into the page-locked ring) -> GPU front-end block -> pdu_decoder_queue_push\"}\n",
 				rs.seconds > 0 ? (double)rs.samples / rs.seconds / 1e6 : 0.0, (unsigned long long)rs.samples, (unsigned long long)rs.blocks, rs.seconds,
-				bench_pdus, bench_octets, rs.channels, rs.block_samples, rs.bytes_per_sample, rs.zero_copy ? "true" : "false", rs.wait_input_s, rs.push_s, rs.collect_s, rs.release_s,
+				bench_pdus, bench_octets, rs.channels, rs.block_samples, rs.bytes_per_sample, rs.zero_copy ? "true" : "false", rs.wait_input_s, rs.push_s, rs.collect_s, rs.release_s, rs.grace_s, (unsigned long long)rs.drains,
 				(unsigned long long)rs.mpdus_walked, (unsigned long long)rs.lpdus_processed, (unsigned long long)rs.lpdus_good, (unsigned long long)rs.lpdus_bad_fcs, shard_rank, shard_world);
 		fflush(stdout);
 	}

@@ -195,6 +195,10 @@ struct hfdl_run_stats {
 	/* what the device found when it walked the LPDU lists of the MPDUs with a good header FCS (hfdl_gpu_pdu.lpdus_*): informational --
 	 * dumphfdl's own lpdu_parse emits the StatsD events for these downstream */
 	uint64_t mpdus_walked, lpdus_processed, lpdus_good, lpdus_bad_fcs;
+	/* how often the thread took the source for live (next block not there after the grace period) and drained the pipeline, and
+	 * the time spent in that grace period */
+	uint64_t drains;
+	double grace_s;
 };
 void          hfdl_frontend_run_stats(struct hfdl_run_stats *out);
 /* replay a regular input file this many times back to back (default 1); not in the reference */
