@@ -25,6 +25,13 @@ struct Demod {
 	bool separate_decode = false;           // the burst decoder runs on another stream than the demodulator
 	hipEvent_t ev_dec[2] = { nullptr, nullptr };   // decoder of an even / odd launch done: its frame queue and counter may be reused
 	hfdl_gpu_pdu *d_pdus = nullptr;
+	// Collection runs beside the kernels: device -> host copies go through page-locked bounce buffers on a stream of their own.
+	// (A synchronous hipMemcpy waits for the kernels in flight -- up to a whole demodulator launch, ~1 ms on the small geometries,
+	// every time a PDU is collected: profiles/r03_experiments.md.)
+	hipStream_t st_collect = nullptr;
+	hfdl_gpu_pdu *h_pdu_bounce = nullptr;   // pinned [bounce_cap]
+	int bounce_cap = 0;
+	void *h_stats_bounce = nullptr;         // pinned [nch] ChanScalars
 	int32_t *d_freqs = nullptr;
 	int pdu_cap = 0;
 	// stage taps

@@ -592,6 +592,10 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 		if (v >= 1 && v <= (1 << 20)) pdu_cap = (int)v;
 	}
 	D_TRY(hipMalloc(&d_pdus, sizeof(hfdl_gpu_pdu) * (size_t)pdu_cap));
+	D_TRY(hipStreamCreateWithFlags(&st_collect, hipStreamNonBlocking));
+	bounce_cap = pdu_cap < 512 ? pdu_cap : 512;
+	D_TRY(hipHostMalloc((void **)&h_pdu_bounce, sizeof(hfdl_gpu_pdu) * (size_t)bounce_cap, hipHostMallocDefault));
+	D_TRY(hipHostMalloc(&h_stats_bounce, sizeof(ChanScalars) * (size_t)nch, hipHostMallocDefault));
 	D_TRY(hipMalloc(&d_freqs, sizeof(int32_t) * (size_t)nch));
 	D_TRY(hipMemcpyAsync(d_freqs, freqs, sizeof(int32_t) * (size_t)nch, hipMemcpyHostToDevice, st));
 	if (taps_on) {
@@ -666,10 +670,18 @@ int Demod::take(unsigned produced, hfdl_gpu_pdu *out, int32_t max, int32_t *n, h
 	unsigned have = (unsigned)avail;
 	if (have > (unsigned)pdu_cap) have = (unsigned)pdu_cap;
 	const unsigned cnt = have < (unsigned)max ? have : (unsigned)max;
-	const unsigned first = taken % (unsigned)pdu_cap;
-	const unsigned run = cnt < (unsigned)pdu_cap - first ? cnt : (unsigned)pdu_cap - first;
-	D_TRY(hipMemcpy(out, d_pdus + first, sizeof(hfdl_gpu_pdu) * run, hipMemcpyDeviceToHost));
-	if (cnt > run) D_TRY(hipMemcpy(out + run, d_pdus, sizeof(hfdl_gpu_pdu) * (cnt - run), hipMemcpyDeviceToHost));
+	// ring entries [taken, taken + cnt) in pieces that neither wrap nor exceed the bounce buffer; each piece is copied on the
+	// collection stream (beside whatever kernels are running) and waited for on that stream alone
+	for (unsigned done = 0; done < cnt;) {
+		const unsigned first = (taken + done) % (unsigned)pdu_cap;
+		unsigned n1 = cnt - done;
+		if (n1 > (unsigned)pdu_cap - first) n1 = (unsigned)pdu_cap - first;
+		if (n1 > (unsigned)bounce_cap) n1 = (unsigned)bounce_cap;
+		D_TRY(hipMemcpyAsync(h_pdu_bounce, d_pdus + first, sizeof(hfdl_gpu_pdu) * n1, hipMemcpyDeviceToHost, st_collect));
+		D_TRY(hipStreamSynchronize(st_collect));
+		std::memcpy(out + done, h_pdu_bounce, sizeof(hfdl_gpu_pdu) * n1);
+		done += n1;
+	}
 	taken += cnt;
 	D_TRY(hipMemsetD32Async((hipDeviceptr_t)(d_counts + 3), (int)taken, 1, st));    // ordered after the blocks already queued
 	*n = (int32_t)cnt;
@@ -732,9 +744,11 @@ int Demod::stats(int channel, hfdl_gpu_channel_stats *out)
 // all channels in one strided copy; does not wait for blocks in flight (each field is read whole, the set may straddle a block)
 int Demod::stats_all(hfdl_gpu_channel_stats *out, int n)
 {
-	std::vector<ChanScalars> sc((size_t)n);
-	D_TRY(hipMemcpy2D(sc.data(), sizeof(ChanScalars), &d_states[0].s, sizeof(ChanState), sizeof(ChanScalars), (size_t)n, hipMemcpyDeviceToHost));
-	for (int i = 0; i < n; i++) fill_stats(sc[(size_t)i], out + i);
+	if (n > nch) return HFDL_GPU_EINVAL;
+	ChanScalars *sc = (ChanScalars *)h_stats_bounce;
+	D_TRY(hipMemcpy2DAsync(sc, sizeof(ChanScalars), &d_states[0].s, sizeof(ChanState), sizeof(ChanScalars), (size_t)n, hipMemcpyDeviceToHost, st_collect));
+	D_TRY(hipStreamSynchronize(st_collect));
+	for (int i = 0; i < n; i++) fill_stats(sc[i], out + i);
 	return 0;
 }
 
@@ -744,6 +758,10 @@ void Demod::release()
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (h_snap) (void)hipHostFree(h_snap);
 	h_snap = nullptr;
+	if (st_collect) { (void)hipStreamSynchronize(st_collect); (void)hipStreamDestroy(st_collect); st_collect = nullptr; }
+	if (h_pdu_bounce) (void)hipHostFree(h_pdu_bounce);
+	if (h_stats_bounce) (void)hipHostFree(h_stats_bounce);
+	h_pdu_bounce = nullptr; h_stats_bounce = nullptr;
 	for (auto &e : ev_dec) { if (e) (void)hipEventDestroy(e); e = nullptr; }
 	d_tables = nullptr; d_states = nullptr; d_data = nullptr; d_frames = nullptr; d_counts = nullptr; d_pdus = nullptr; d_freqs = nullptr;
 	d_tap_rs = d_tap_mf = d_tap_sym = nullptr; d_tap_lvl = nullptr; d_tap_counts = nullptr;
