@@ -467,11 +467,14 @@ def host_ram_leg(torch, hf, F, fe, x, g, nblocks, steps):
     queued while block k is pushed (hfdl_gpu_frontend_prefetch_block_raw) -- PCIe-inclusive."""
     hbuf, hpush, hprefetch = host_feed(hf, F, fe, x, g, nblocks, "cf32")
     k2 = min(steps, 96)
-    for i in range(4):
+    # one untimed pass over EVERY block first: the first DMA out of a freshly page-locked page costs more than the later ones
+    # (address translation for the device is set up as pages are first touched), and the stream is replayed several times below
+    warm = max(4, nblocks)
+    for i in range(warm):
         hpush(i % nblocks)
     fe.poll_pdus()
-    hprefetch(4 % nblocks)
-    el2, raw2, _ = timed_blocks(torch, fe, hpush, k2, 4, nblocks, prefetch_fn=hprefetch)
+    hprefetch(warm % nblocks)
+    el2, raw2, _ = timed_blocks(torch, fe, hpush, k2, warm, nblocks, prefetch_fn=hprefetch)
     return hbuf, dict(value=k2 * g.input_size / el2 / 1e6, unit="Msamples/s", steps=k2, ms_per_step=el2 / k2 * 1e3,
                       path="cf32 blocks in page-locked host RAM -> hfdl_gpu_frontend_prefetch_block_raw (copy stream, two HBM staging "
                            "buffers, one block ahead) -> hfdl_gpu_frontend_push_block_raw -> same kernels; PCIe-inclusive",

@@ -860,11 +860,15 @@ extern "C" int hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu
 	if (!out && max > 0) return fail(HFDL_GPU_EINVAL, "null PDU buffer with max = %d", max);
 	if (max_in_flight <= 0) return hfdl_gpu_frontend_poll_pdus(fe, out, max, n);
 	*n = 0;
-	// leave the newest block running: wait for the one before it and take what the ring held when that one finished
+	// Leave the newest launch running: wait for the DEMODULATOR of the one before it -- that is the flow control: the caller may
+	// queue the next blocks, the demodulator stream will not run dry -- and take what the PDU ring is known to hold: the snapshot
+	// written after that launch's burst decoder if it has finished too, else the one written two launches earlier (a stale snapshot
+	// yields nothing new; those PDUs come with the next call).  Waiting for the burst decoder here (0.3 ms when a long frame ended)
+	// left the demodulator idle for as long on the demodulator-bound geometries (profiles/r03_experiments.md).
 	const int buf = fe->prev_demod_buf;
-	if (buf < 0) return 0;                              // fewer than two blocks pushed: nothing is known to be done
+	if (buf < 0) return 0;                              // fewer than two launches: nothing is known to be done
 	HIP_TRY(hipSetDevice(fe->device));
-	HIP_TRY(hipEventSynchronize(fe->ev_demod[buf]));
+	HIP_TRY(hipEventSynchronize(fe->ev_dm_cur[buf] ? fe->ev_dm_cur[buf] : fe->ev_demod[buf]));
 	int rc = fe->demod.collect_snapshot(buf, out, max, n, fe->stream_d);
 	if (rc) return fail(rc, "pdu collection failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;

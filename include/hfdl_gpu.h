@@ -154,11 +154,12 @@ int  hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe);
 /* Collect PDUs produced by all blocks enqueued so far (implies a sync). Returns count in *n.  `out` must hold `max`
  * entries; out == NULL with max > 0 is HFDL_GPU_EINVAL (nothing is discarded), max == 0 just syncs. */
 int  hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n);
-/* Same without draining the pipeline: with max_in_flight = 1 the newest block keeps running; the call waits only for
- * the block before it and returns what had been decoded when that one finished (nothing until two blocks were pushed).
- * max_in_flight = 0 is hfdl_gpu_frontend_poll_pdus().  A file replay pushes block k+1, then collects block k this way,
- * so copies, channelizer and demodulator of consecutive blocks overlap; a live receiver that has no further input
- * queued uses 0 and gets its PDUs at once. */
+/* Same without draining the pipeline: with max_in_flight = 1 the newest demodulator launch (one block, or geometry.demod_batch
+ * blocks on the small geometries) keeps running; the call waits only for the demodulator of the launch before it and returns the PDUs
+ * known to be complete at that moment -- those of that launch if its burst decoder has finished too, otherwise they come with the next
+ * call (nothing until two launches were made).  max_in_flight = 0 is hfdl_gpu_frontend_poll_pdus().  A file replay pushes block k+1,
+ * then collects this way, so copies, channelizer, demodulator and burst decoder of consecutive blocks overlap; a live receiver that has
+ * no further input queued uses 0 and gets its PDUs at once. */
 int  hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n, int32_t max_in_flight);
 /* PDUs wait in a device ring of pdu_ring_capacity entries; one that finds the ring full is dropped and counted
  * (the reference's GAsyncQueue is unbounded, src/pdu.c:37-43: poll at least once per few seconds of signal).
