@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAI
 done
 DBS=$(find /tmp/pmc_${WL}_* -name "*.db" | sort)
 {
-	echo "# r02 $WL PMC passes (profiles/pmc_passes.sh $WL: rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-extra-legs, one pass per counter set; commit $COMMIT)"
+	echo "# r03 $WL PMC passes (profiles/pmc_passes.sh $WL: rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-extra-legs, one pass per counter set; commit $COMMIT)"
 	echo
 	echo "Per-dispatch averages. FETCH_SIZE / WRITE_SIZE in KB; on gfx950 reads = 2 x FETCH_SIZE for wide coalesced streaming reads (calibrated in the same run on stream_read_kernel, which reads a known byte count). SQ_* count quad-cycles summed over the dispatch's waves."
 	echo
