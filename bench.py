@@ -408,6 +408,22 @@ def alg_bytes_per_block(g):
     return 8 * g.input_size + g.channels * 8 * g.fft_size + g.channels * 8 * (g.post_input_size // g.post_decimation)
 
 
+class stdout_to_stderr:
+    """Anything the communication libraries print to file descriptor 1 while they come up (RCCL's version banner, gloo's connection
+    report) goes to stderr instead: rank 0's stdout carries ONE JSON line and nothing else."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def init_dist(torch, dist, backend, dev_index, world):
     """torch.distributed carries the timing barrier and the final reductions only (no data-path collective).  `nccl` = RCCL for
     CUDA tensors (with gloo beside it for CPU tensors); if RCCL cannot be brought up the run continues on gloo and says so."""
@@ -561,7 +577,8 @@ def main():
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     dist_info = None
     if world > 1 or launched:
-        used, red_device, note = init_dist(torch, dist, args.backend, dev_index, world)
+        with stdout_to_stderr():
+            used, red_device, note = init_dist(torch, dist, args.backend, dev_index, world)
         dist_info = dict(backend=used, requested=args.backend, world_size=world, fallback=note)
         # all ranks build their filter taps on the host at once: share the cores
         os.environ.setdefault("HFDL_GPU_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, world))))
@@ -715,8 +732,9 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     if use_dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        with stdout_to_stderr():
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

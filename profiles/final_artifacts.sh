@@ -15,7 +15,7 @@ python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/b
 python bench.py --host-input --sample-format cs16 --no-cpu-baseline --no-extra-legs > $OUT/bench_cfg3_host_cs16.json 2>> $OUT/bench.err
 HFDL_GPU_DEMOD_BATCH=1 python bench.py --workload cfg2 --no-cpu-baseline --no-extra-legs > $OUT/bench_cfg2_one_block_per_launch.json 2>> $OUT/bench.err
 # the N > 1 launch path through RCCL at world size 1, exactly as the driver starts it
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --steps 64 --warmup 4 --no-cpu-baseline --no-extra-legs > $OUT/bench_cfg3_rccl_world1.json 2>> $OUT/bench.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --steps 64 --warmup 4 --no-cpu-baseline --no-extra-legs 2>> $OUT/bench.err | grep "^{" > $OUT/bench_cfg3_rccl_world1.json
 # the C host path on cf32 and cs16 files (raw samples over PCIe, converted on the device)
 python - > $OUT/host_path.json 2>> $OUT/bench.err <<'PY'
 import json, sys

@@ -128,8 +128,8 @@ def test_rccl_path_at_world_size_one():
            "--backend", "nccl", "--no-cpu-baseline", "--no-extra-legs"]            # 26 steps = once around the resident stretch: every burst ends in it
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]      # stdout = ONE JSON line: no RCCL banner, no gloo chatter
     r = json.loads(lines[0])
     d = r["distributed"]
     assert d == dict(backend="nccl", requested="nccl", world_size=1, fallback=None), d      # RCCL came up: no gloo fall-back
