@@ -378,14 +378,8 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 						const float er = tv - y.x, ei = -(0.0f - y.y);
 						const float bx = row1 ? -c.ev : c.eu, by = row1 ? c.eu : c.ev;       // the window sample (x, y) in either row
 						const float pr = er * bx - ei * by, pi = er * by + ei * bx;
-#ifdef HFDL_DM_EXACT_DIV
 						c.ewx = c.ewx + 0.1f * pr / s.eq_x2sum;
 						c.ewy = c.ewy + 0.1f * pi / s.eq_x2sum;
-#else
-						const float step = HFDL_QUICK_DIV(0.1f, s.eq_x2sum);        // mu / sum |x|^2: one reciprocal for both parts of all 15 taps
-						c.ewx = c.ewx + pr * step;
-						c.ewy = c.ewy + pi * step;
-#endif
 					}
 					s.T_idx++;
 				}

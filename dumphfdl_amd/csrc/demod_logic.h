@@ -12,15 +12,6 @@
 
 #define HFDL_FN __device__ inline
 #define HFDL_HD __host__ __device__ inline
-// a / b on the carrier wave's per-symbol path where the quotient feeds metadata or an adaptation step, not a decision: the hardware
-// reciprocal (1 ulp) and one multiply instead of the 12-instruction IEEE division sequence -- a lone wave pays ~8 cycles per
-// instruction.  (The CPU harness defines it as a plain division before including this file.)
-#if defined(HFDL_DM_EXACT_DIV) && !defined(HFDL_QUICK_DIV)          // A/B builds (profiles/r03_experiments.md)
-#define HFDL_QUICK_DIV(a, b) ((a) / (b))
-#endif
-#ifndef HFDL_QUICK_DIV
-#define HFDL_QUICK_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
-#endif
 
 namespace hfdl {
 
@@ -417,7 +408,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 		}
 	}
 	if (s.fr_state > FR_A1) {
-		s.signal_level = HFDL_QUICK_DIV(s.signal_level * s.frame_symbol_cnt + level, s.frame_symbol_cnt + 1.0f);
+		s.signal_level = (s.signal_level * s.frame_symbol_cnt + level) / (s.frame_symbol_cnt + 1.0f);
 		s.frame_symbol_cnt += 1.0f;
 	}
 	if (s.symbols_wanted > 1) { s.symbols_wanted--; return; }

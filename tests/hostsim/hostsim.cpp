@@ -10,7 +10,6 @@
 // ---- shims for compiling device code on the host (one "lane")
 #define __device__
 #define __host__
-#define HFDL_QUICK_DIV(a, b) ((a) / (b))          // the oracle's division: the device form is the hardware reciprocal
 static const struct { unsigned x; } threadIdx = { 0 };
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
