@@ -444,6 +444,9 @@ def init_dist(torch, dist, backend, dev_index, world):
                     dist.destroy_process_group()
             except Exception:                       # noqa: BLE001
                 pass
+            # a second rendezvous: next port (rank 0's first store may still hold the old one); every rank computes the same number
+            if os.environ.get("MASTER_PORT", "").isdigit():
+                os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
     dist.init_process_group("gloo")
     return "gloo", "cpu", note
 
@@ -577,9 +580,16 @@ def main():
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     dist_info = None
     if world > 1 or launched:
+        backend, shared_note = args.backend, None
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if backend == "nccl" and local_world > torch.cuda.device_count():
+            # RCCL does not refuse two ranks on one device, it hangs in the first collective (measured: profiles/r03_experiments.md):
+            # ranks that share a GPU talk through gloo, and the line says so
+            backend = "gloo"
+            shared_note = "%d local ranks on %d visible GPU(s): RCCL cannot run ranks that share a device -- gloo used" % (local_world, torch.cuda.device_count())
         with stdout_to_stderr():
-            used, red_device, note = init_dist(torch, dist, args.backend, dev_index, world)
-        dist_info = dict(backend=used, requested=args.backend, world_size=world, fallback=note)
+            used, red_device, note = init_dist(torch, dist, backend, dev_index, world)
+        dist_info = dict(backend=used, requested=args.backend, world_size=world, fallback=note or shared_note)
         # all ranks build their filter taps on the host at once: share the cores
         os.environ.setdefault("HFDL_GPU_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, world))))
     import dumphfdl_amd as hf

@@ -94,7 +94,7 @@ def test_two_rank_bench_on_one_gpu():
     payload its own stream carried."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2", "--backend", "gloo"]
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2"]      # default backend nccl: two ranks on one GPU -> gloo, and the line says so
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -115,7 +115,8 @@ def test_two_rank_bench_on_one_gpu():
     assert [p["rank"] for p in pr] == [0, 1] and [p["stream_seed"] for p in pr] == [5, 6] and all(p["channels"] == 256 for p in pr)
     assert max(p["ms_per_step"] for p in pr) == pytest.approx(r["ms_per_step"], rel=1e-3)
     assert sum(p["pdus"] for p in pr) == r["pdus_in_timed_region"] and all(p["fold_avg_ms"] > 0 and p["demod_ms_per_block"] > 0 for p in pr)
-    assert r["distributed"]["backend"] == "gloo" and r["distributed"]["world_size"] == 2 and r["distributed"]["fallback"] is None
+    assert r["distributed"]["backend"] == "gloo" and r["distributed"]["requested"] == "nccl" and r["distributed"]["world_size"] == 2
+    assert "share a device" in r["distributed"]["fallback"]
 
 
 def test_rccl_path_at_world_size_one():
