@@ -576,8 +576,9 @@ static int close_batch(hfdl_gpu_frontend *fe, bool launch_now)
 	return 0;
 }
 
-// Stream A runs the channelizer of block k into buffer k&1; stream B demodulates it.  A's inverse FFT may not overwrite
-// a buffer before B has finished with it (two blocks ago); B may not start before A has filled it.
+// Stream A runs the channelizer of a block into the next slot of the half being filled; stream B demodulates a half (one block, or
+// `batch` blocks) at a time.  A's inverse FFT may not overwrite a half before the demodulator launch that read it last (two launches
+// ago) is done; B may not start before A has filled what it is given.
 static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx, int *buf_out, bool with_demod)
 {
 	const Geometry &g = fe->geo;

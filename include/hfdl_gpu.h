@@ -209,8 +209,10 @@ enum {
 	HFDL_GPU_TAP_PHASE_CYCLES = 8    /* f32[4]: shader cycles of the last demod launch: resampler phase, the whole three-wave pipelined phase (wall),
 	                                    busy cycles of the timing-recovery wave, busy cycles of the carrier / equaliser / framer wave */
 };
-/* Stage taps 4..8 make the demodulator write its intermediate samples to HBM every block; on by default (tests), a
- * production caller / the bench turns them off.  Taps 1..3 are always available (they are the kernels' own buffers). */
+/* Stage taps 4..8 make the demodulator write its intermediate samples to HBM every launch; on by default (tests), a
+ * production caller / the bench turns them off.  Taps 1..3 are always available (they are the kernels' own buffers).  Taps 4..8 hold
+ * the LAST demodulator launch: one block when the caller syncs / polls after every push, up to geometry.demod_batch blocks otherwise
+ * (size buffers for demod_batch * (post_input_size + 64) complex samples); tap 3 and tap 9 hold the last block. */
 int  hfdl_gpu_frontend_enable_taps(hfdl_gpu_frontend *fe, int enable);
 /* dst holds `cap` floats; *n_floats receives the number written */
 int  hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel, float *dst, size_t cap, size_t *n_floats);
