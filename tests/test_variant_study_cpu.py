@@ -99,3 +99,32 @@ def test_committed_table_reproduces(oracle, bb20):
             assert cells[:3] == [0, 0, 0]
         else:
             assert cells == [0] * 7, (n, cells)
+
+
+def test_kaiser_designs_against_numpy(oracle):
+    """The restated liquid_firdes_kaiser against an independent implementation: with the textbook window argument 2t/(N-1) (variant
+    kaiser_arg = 1) the equaliser's initial taps ARE numpy's Kaiser design (beta from scipy's kaiser_beta) to fp32 rounding; liquid's own
+    argument 2t/N (the default reading) moves the edge taps by 3.5e-3 -- the one liquid-specific choice in the design, and
+    profiles/r03_variant_sensitivity.md shows it changes no decoded frame from +2 dB up.  The symsync prototype bank equals the direct formula."""
+    import ctypes as C
+    import scipy.signal as ss
+    L = oracle.lib()
+    beta = ss.kaiser_beta(40.0)
+    assert beta == pytest.approx(0.5842 * 19 ** 0.4 + 0.07886 * 19, rel=1e-12)
+    t = np.arange(15) - 7.0
+    ref = 2 * 0.45 * np.sinc(2 * 0.45 * t) * np.kaiser(15, beta)
+    got = {}
+    for arg in (0, 1):
+        oracle.set_variant(kaiser_arg=arg)
+        w = np.zeros(15, np.float32)
+        L.orc_eq_initial_taps(w.ctypes.data_as(C.c_void_p))
+        got[arg] = np.abs(w - ref).max()
+    oracle.set_variant()
+    assert got[1] < 1e-7 and 1e-3 < got[0] < 1e-2
+    mf, dmf = np.zeros(16 * 18, np.float32), np.zeros(16 * 18, np.float32)
+    L.orc_symsync_filters(mf.ctypes.data_as(C.c_void_p), dmf.ctypes.data_as(C.c_void_p))
+    n, fc = 289, 0.75 / 48
+    tt = np.arange(n) - (n - 1) / 2
+    r = 2 * tt / n
+    H = (np.sinc(2 * fc * tt) * np.i0(beta * np.sqrt(1 - r * r)) / np.i0(beta) * 1.5).astype(np.float32)
+    assert np.abs(mf.reshape(16, 18) - np.array([[H[b + 16 * k] for k in range(18)] for b in range(16)])).max() < 5e-7
