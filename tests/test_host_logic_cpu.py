@@ -337,6 +337,36 @@ def test_bench_traffic_plans():
         assert modes == (set(range(8)) if w.get("dense") else set(range(4)))
 
 
+def _make_input_worker(q):
+    import bench
+    w = dict(fs=250_000, centerfreq=10_000_000, nch=2, grid=60_000, blocks=24, seed=77, noise=0.01, name="tiny")
+    x, bursts = bench.make_input(w, 28672, 0, 1)
+    q.put((float(np.abs(x).sum()), len(x), len(bursts)))
+
+
+def test_bench_input_is_made_once_per_seed(tmp_path):
+    """Ranks that share a stream (--shard channels) call make_input() at the same moment: the file lock lets one synthesise and the others
+    load its file; all get the same samples, and the cache file carries the traffic plan's tag (a file left by another plan is not reused)."""
+    import glob
+    import multiprocessing as mp
+    for f in glob.glob("/tmp/hfdl_bench_250000_seed77_*"):
+        os.remove(f)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_make_input_worker, args=(q,)) for _ in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert len(set(res)) == 1 and res[0][1] == 24 * 28672 and res[0][2] == 2
+    files = [f for f in glob.glob("/tmp/hfdl_bench_250000_seed77_*") if f.endswith(".npy")]
+    assert len(files) == 1 and len(os.path.basename(files[0]).split("_")[-1]) == 12          # <crc32 tag>.npy
+    for f in glob.glob("/tmp/hfdl_bench_250000_seed77_*"):
+        os.remove(f)
+
+
 def test_abi_argument_checks_need_no_device():
     """Every front-end entry point rejects a NULL handle / NULL outputs with HFDL_GPU_EINVAL before touching HIP (the
     reference ASSERTs its arguments: src/fft.c:31, src/hfdl.c:648); the error text is per calling thread."""
