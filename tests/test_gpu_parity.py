@@ -700,6 +700,58 @@ def test_demodulator_batching_changes_nothing(gpu, oracle, monkeypatch):
                 assert have[k + "_corr_avg"] == pytest.approx(want[k + "_corr_total"] / want[cnt], rel=1e-5)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_call_sequences_equal_a_launch_per_block(gpu, monkeypatch, seed):
+    """The batching state machine under random use: after every pushed block one of {nothing, lagging collection, draining poll, sync,
+    statistics read, stage-tap read} at random, and now and then a block that only goes through the channelizer (never demodulated, in
+    both runs).  Whatever the sequence cuts the batches into, PDUs (every field) and channel statistics equal those of the same sequence
+    with one block per launch."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000]
+    dur = 14.0
+    bursts = synth.plan_traffic(freqs, dur, seed=100 + seed, dense=True, gap_s=0.12, amp=(0.02, 0.1))
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.012, seed=100 + seed)
+    rng = np.random.default_rng(seed)
+    nblk = len(x) // 28672
+    script = [(str(rng.choice(["none", "none", "none", "lag", "lag", "drain", "sync", "stats", "tap"])), bool(rng.random() < 0.04)) for _ in range(nblk)]
+
+    def run(batch_env):
+        if batch_env is None:
+            monkeypatch.delenv("HFDL_GPU_DEMOD_BATCH", raising=False)
+        else:
+            monkeypatch.setenv("HFDL_GPU_DEMOD_BATCH", str(batch_env))
+        fe = gpu.Frontend(fs, cf, freqs)
+        n, got = fe.input_size, []
+        assert n == 28672
+        for b, (act, chan_only) in enumerate(script):
+            blk = x[b * n:(b + 1) * n]
+            if chan_only:
+                fe.channelize_block(blk)
+                continue
+            fe.push_block(blk)
+            if act == "lag":
+                got += fe.poll_pdus(max_in_flight=1)
+            elif act == "drain":
+                got += fe.poll_pdus()
+            elif act == "sync":
+                fe.sync()
+            elif act == "stats":
+                fe.all_channel_stats()
+            elif act == "tap":
+                fe.read_tap(F.TAP_CHAN_OUT, 1)
+        got += fe.poll_pdus()
+        stats = fe.all_channel_stats()
+        cnt = fe.counters()
+        fe.close()
+        assert cnt["pdus_dropped"] == 0 and cnt["pdus_taken"] == len(got)
+        return sorted(got, key=lambda p: (p["freq"], p["sample_index"])), stats
+
+    ref, ref_stats = run(1)
+    got, stats = run(None)
+    assert len(ref) >= 8
+    assert got == ref and stats == ref_stats
+
+
 def test_full_pdu_ring_drops_and_counts(gpu, oracle, monkeypatch):
     """More frames finishing in one block than the device ring holds: the surplus is dropped and counted, what is
     delivered is intact, and the ring keeps working afterwards."""
