@@ -752,6 +752,56 @@ def test_random_call_sequences_equal_a_launch_per_block(gpu, monkeypatch, seed):
     assert got == ref and stats == ref_stats
 
 
+def test_random_call_sequences_on_a_fold_bound_geometry(gpu):
+    """The same on a geometry with 128 channels, where a block's demodulator launch is held back until the next block's forward FFT
+    is queued: whatever is called between the pushes -- lagging collections, draining polls, syncs, statistics and tap reads,
+    channelizer-only blocks -- the PDUs and channel statistics are those of plain pushes with one poll at the end."""
+    fs, cf = 2_400_000, 10_000_000
+    freqs = [int(cf + (i - 64) * 15_000 + 4_000) for i in range(128)]
+    rng = np.random.default_rng(5)
+    bursts = [dict(freq=freqs[c], mode=int(rng.integers(0, 4)), octets=b"", t0=float(rng.uniform(0.2, 0.8)), amp=0.03, cfo=float(rng.uniform(-10, 10)))
+              for c in (3, 40, 77, 101, 126)]
+    for b in bursts:
+        b["octets"] = synth.make_pdu(rng, b["mode"])
+    dur = 3.6
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.01, seed=5)
+
+    def run(script):
+        fe = gpu.Frontend(fs, cf, freqs)
+        assert fe.geometry.demod_batch == 1
+        n, got = fe.input_size, []
+        for b in range(len(x) // n):
+            blk = x[b * n:(b + 1) * n]
+            act, chan_only = script[b % len(script)]
+            if chan_only:
+                fe.channelize_block(blk)
+                continue
+            fe.push_block(blk)
+            if act == "lag":
+                got += fe.poll_pdus(max_in_flight=1)
+            elif act == "drain":
+                got += fe.poll_pdus()
+            elif act == "sync":
+                fe.sync()
+            elif act == "stats":
+                fe.all_channel_stats()
+            elif act == "tap":
+                fe.read_tap(F.TAP_CHAN_OUT, 5)
+        got += fe.poll_pdus()
+        stats = fe.all_channel_stats()
+        fe.close()
+        return sorted(got, key=lambda p: (p["freq"], p["sample_index"])), stats
+
+    nblk = len(x) // gpu.plan_geometry(256, 250 / fs).input_size
+    skip = [bool(rng.random() < 0.05) for _ in range(nblk)]
+    skip[:3] = [False] * 3
+    plain = [("none", s) for s in skip]
+    mixed = [(str(rng.choice(["none", "lag", "lag", "drain", "sync", "stats", "tap"])), s) for s in skip]
+    ref, ref_stats = run(plain)
+    got, stats = run(mixed)
+    assert len(ref) >= 3 and got == ref and stats == ref_stats
+
+
 def test_full_pdu_ring_drops_and_counts(gpu, oracle, monkeypatch):
     """More frames finishing in one block than the device ring holds: the surplus is dropped and counted, what is
     delivered is intact, and the ring keeps working afterwards."""
