@@ -269,7 +269,8 @@ void orc_symsync_filters(float *mf, float *dmf)
 		float v = fabsf(H[i] * dH[i]);
 		if (v > hdh_max || i == 0) hdh_max = v;
 	}
-	for (int i = 0; i < HL; i++) dH[i] *= 0.06f / hdh_max;
+	const float dscale = orc_v.symsync_dmf_scale > 0.f ? orc_v.symsync_dmf_scale : 1.0f;
+	for (int i = 0; i < HL; i++) dH[i] *= dscale * 0.06f / hdh_max;
 	for (int b = 0; b < SS_NPFB; b++)
 		for (int k = 0; k < SS_TAPS; k++) {
 			mf[b * SS_TAPS + k] = H[b + k * SS_NPFB];
@@ -302,7 +303,7 @@ static void symsync_init(symsync_t *s, float lf_bw)
 {
 	memset(s, 0, sizeof(*s));
 	orc_symsync_filters(s->mf, s->dmf);
-	float alpha = 1.000f - lf_bw, beta = 0.220f * lf_bw, a = 0.500f, b = 0.495f;
+	float alpha = 1.000f - lf_bw, beta = 0.220f * lf_bw, a = 0.500f, b = orc_v.symsync_lf_b > 0.f ? orc_v.symsync_lf_b : 0.495f;
 	float B0 = beta, A0 = 1.00f - a * alpha, A1 = -b * alpha;
 	s->lf_b0 = B0 / A0; s->lf_b1 = 0.0f; s->lf_b2 = 0.0f;
 	s->lf_a1 = A1 / A0; s->lf_a2 = 0.0f;
@@ -563,7 +564,7 @@ orc_channel *orc_channel_create(int32_t sample_rate, int32_t decimation, float t
 		orc_channelizer_taps(&c->ddc, decimation, freq_shift, c->taps_fft, 0);
 	}
 	c->chan_out = malloc(sizeof(orc_cf) * (size_t)c->ddc.post_input_size);
-	c->agc.g = 1.0f; c->agc.y2 = 1.0f; c->agc.alpha = 0.01f;   /* src/hfdl.c:485-487 */
+	c->agc.g = 1.0f; c->agc.y2 = orc_v.agc_y2_init > 0.f ? orc_v.agc_y2_init : 1.0f; c->agc.alpha = 0.01f;   /* src/hfdl.c:485-487 */
 	c->noise_floor = 1.0f;                                     /* :490 */
 	c->loop.alpha = 0.1f;
 	c->loop.beta = 0.047f * c->loop.alpha * c->loop.alpha;     /* :240-245 */

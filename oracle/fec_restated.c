@@ -327,7 +327,7 @@ uint32_t orc_modem_demod_hard(int arity, orc_cf x, float *phase_error)
 
 static inline uint8_t clamp_soft(float llr16)
 {
-	int v = (int)(llr16 + 127);
+	int v = orc_v.soft_floor ? (int)floorf(llr16 + 127) : (int)(llr16 + 127);
 	if (v > 255) v = 255;
 	if (v < 0) v = 0;
 	return (uint8_t)v;
@@ -350,7 +350,7 @@ void orc_modem_demod_soft(int arity, orc_cf x, uint8_t *soft)
 	}
 	/* m>=3: nearest-neighbour approximation with p=2 neighbours, gamma = 1.2*M */
 	const uint32_t M = 1u << arity;
-	const float gamma = 1.2f * (float)M;
+	const float gamma = (orc_v.soft_gamma_scale > 0.f ? orc_v.soft_gamma_scale : 1.0f) * 1.2f * (float)M;
 	float d0[3], d1[3];
 	orc_cf xh = orc_modem_modulate(arity, sym);
 	float er = x.re - xh.re, ei = x.im - xh.im;

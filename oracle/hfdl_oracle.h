@@ -132,6 +132,12 @@ typedef struct {
 	int32_t perr_kind;           /* demodulator phase error: 0 = Im(r conj(x_hat)) (default), 1 = angle of r conj(x_hat) */
 	int32_t dot_order;           /* dot products: 0 = sequential (default), 1 = even / odd partial sums (a 4-lane SIMD dotprod) */
 	int32_t symsync_bank_floor;  /* filter-bank index: 0 = roundf(bf) (default), 1 = floorf(bf) */
+	/* recollected constants (0 = the value used, a factor otherwise): what a mis-remembered number would do */
+	float   symsync_dmf_scale;   /* derivative filter normalised to this * 0.06 / max|h dh| (0 -> 1.0) */
+	float   symsync_lf_b;        /* loop filter feed-back coefficient b (0 -> 0.495) */
+	float   soft_gamma_scale;    /* 8-PSK soft de-mapper gamma = this * 1.2 M (0 -> 1.0) */
+	int32_t soft_floor;          /* soft bit conversion: 0 = C cast of (llr * 16 + 127) (truncation, default), 1 = floor */
+	float   agc_y2_init;         /* AGC energy estimate at create (0 -> 1.0) */
 } orc_variant;
 void orc_variant_default(orc_variant *v);
 void orc_variant_set(const orc_variant *v);

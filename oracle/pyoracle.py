@@ -45,7 +45,9 @@ class Variant(C.Structure):
     """orc_variant (hfdl_oracle.h): switches for the unpinned readings; all zero / dmin 4.0 = the restatement the parity tests use."""
     _fields_ = [("symsync_reset_both", C.c_int32), ("resamp_kind", C.c_int32), ("kaiser_arg", C.c_int32), ("soft_dmin_init", C.c_float),
                 ("lfsr_kind", C.c_int32), ("eqlms_norm", C.c_int32), ("agc_double", C.c_int32), ("design_float", C.c_int32),
-                ("perr_kind", C.c_int32), ("dot_order", C.c_int32), ("symsync_bank_floor", C.c_int32)]
+                ("perr_kind", C.c_int32), ("dot_order", C.c_int32), ("symsync_bank_floor", C.c_int32),
+                ("symsync_dmf_scale", C.c_float), ("symsync_lf_b", C.c_float), ("soft_gamma_scale", C.c_float), ("soft_floor", C.c_int32),
+                ("agc_y2_init", C.c_float)]
 
 
 SINK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Pdu))

@@ -52,6 +52,12 @@ RX_VARIANTS = [
     ("agc_double", dict(agc_double=1), "AGC energy recursion evaluated in double (liquid's 1.0 literal)"),
     ("perr_angle", dict(perr_kind=1), "demodulator phase error = angle(r conj(x_hat)) instead of Im(r conj(x_hat))"),
     ("dot_even_odd", dict(dot_order=1), "dot products summed as even / odd partial sums (SIMD dotprod) instead of sequentially"),
+    ("symsync_dmf_x0.5", dict(symsync_dmf_scale=0.5), "symsync derivative filter normalised to 0.03 / max|h dh| instead of 0.06 (timing-error gain halved)"),
+    ("symsync_dmf_x2", dict(symsync_dmf_scale=2.0), "the same, 0.12 (gain doubled)"),
+    ("symsync_lf_b_0.5", dict(symsync_lf_b=0.5), "symsync loop filter feed-back coefficient 0.5 instead of 0.495"),
+    ("soft_gamma_x0.83", dict(soft_gamma_scale=1.0 / 1.2), "8-PSK soft de-mapper gamma = M instead of 1.2 M"),
+    ("soft_floor", dict(soft_floor=1), "soft bit = floor(llr * 16 + 127) instead of the C cast's truncation"),
+    ("agc_y2_init_0.01", dict(agc_y2_init=0.01), "AGC energy estimate starts at 0.01 instead of 1.0"),
     ("lfsr_old_api", dict(lfsr_kind=1), "scrambler through the pre-1.6 msequence API restated literally (src/hfdl.c:331-333): must equal the default"),
     ("lfsr_right_shift", dict(lfsr_kind=2), "scrambler as a right-shifting register (the other reading of the >= 1.6 API)"),
 ]

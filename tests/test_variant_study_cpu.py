@@ -28,7 +28,8 @@ def decode(fields, data):
 def test_default_variant_is_the_plain_oracle(oracle, bb20):
     data, sent = bb20
     assert oracle.get_variant() == dict(symsync_reset_both=0, resamp_kind=0, kaiser_arg=0, soft_dmin_init=4.0, lfsr_kind=0, eqlms_norm=0,
-                                        agc_double=0, design_float=0, perr_kind=0, dot_order=0, symsync_bank_floor=0)
+                                        agc_double=0, design_float=0, perr_kind=0, dot_order=0, symsync_bank_floor=0,
+                                        symsync_dmf_scale=0.0, symsync_lf_b=0.0, soft_gamma_scale=0.0, soft_floor=0, agc_y2_init=0.0)
     base, summ = decode({}, data)
     assert vs.score(base, sent) == len(base) >= 46 and summ["a2_found"] == 48
     # a channel that never saw set_variant() gives the same PDUs: the switches default to the restatement the parity tests use
@@ -89,7 +90,7 @@ def test_committed_table_reproduces(oracle, bb20):
     data, sent = bb20
     base, summ = decode({}, data)
     assert {sid for sid in data if not any(p[0] == sid for p in base)} == {s for s in lost if s in data}
-    # the readings that matter are the ones the table says: at >= +2 dB only the scrambler's direction and the un-normalised equaliser change octets
+    # the readings that matter are the ones the table says: at >= +4 dB only the scrambler's direction, the un-normalised equaliser and the symsync loop-filter coefficient change octets
     s1 = {n: [rep["sets"][k]["rows"][n]["vs_default"]["octets_changed"] for k in ("cfg3", "cfg4", "bb20", "snr+4", "snr+6", "snr+8", "snr+10")]
           for n in rep["rx_variants"] if n != "default"}
     for n, cells in s1.items():
@@ -97,6 +98,8 @@ def test_committed_table_reproduces(oracle, bb20):
             assert min(cells) > 200
         elif n == "eqlms_norm_none":
             assert cells[:3] == [0, 0, 0]
+        elif n == "symsync_lf_b_0.5":
+            assert min(cells[:3]) >= 30              # the timing loop's DC gain x 6: the 20 dB traffic breaks -- a constant to check against liquid
         else:
             assert cells == [0] * 7, (n, cells)
 
