@@ -55,15 +55,17 @@ __device__ __forceinline__ float row_scan_sum(float v)
 	x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));
 	return __int_as_float(x);
 }
-// inclusive scan-max inside every 16-lane row (lanes shifted in from outside the row read 0, so the result is max(0, ...))
+// inclusive scan-max inside every 16-lane row (lanes shifted in from outside the row read 0, so the result is max(0, ...)).
+// v_max_f32 with the DPP operand, one instruction per step: written through the compiler's fmaxf each step is a DPP move, a
+// canonicalising v_max x, x and the max itself.  (s_nop 1: the two wait states between a VALU write and a DPP read of the register.)
 __device__ __forceinline__ float row_scan_max(float v)
 {
-	int x = __float_as_int(v);
-	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true))));
-	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true))));
-	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true))));
-	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true))));
-	return __int_as_float(x);
+	asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+			"s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+			"s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+			"s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0"
+			: "+v"(v));
+	return v;
 }
 // x / 3.0f, correctly rounded, without the IEEE division sequence (12 instructions on the timing loop's output path): reciprocal
 // multiply plus one FMA residual correction (Markstein); checked against true division over 6e4 random floats
@@ -243,6 +245,10 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 struct CarrierRegs {
 	float eu, ev, ex2, ewx, ewy;   // equaliser: lane 1 + t (t < 15) of rows 0 and 1 = tap t (0 oldest); row 0 holds (x, y), row 1 (y, -x)
 	float px, py;                  // lane i < 16: PSK constellation entry i (demod_tables.h psk_pts)
+#ifdef HFDL_DM_PROBE               // experiment builds (profiles/probe_states.py): = 2 carrier-wave cycles per framer state, = 3 outputs per state,
+                                   // reported in the phase-cycle slots of the level tap
+	unsigned long long pa = 0, pb = 0, pc = 0;
+#endif
 };
 
 // The carrier wave's slicer.  modem_demodulate_psk takes arg(x), subtracts pi (1 - 1/M) and walks a binary reference ladder:
@@ -267,7 +273,7 @@ struct LaneSlicer {
 			const bool mine = lane >= base && lane < base + M;
 			const float d = mine ? x.x * px + x.y * py : -1.0f;
 			const float best = lane_value(row_scan_max(d), 15);        // >= 0: some point is within 90 degrees of x
-			const unsigned long long hit = __ballot(mine && d == best);
+			const unsigned long long hit = __builtin_amdgcn_fcmpf(d, best, 1 /* FCMP_OEQ */);       // lanes without a point hold -1: never equal
 			int win = hit ? (int)__builtin_ctzll(hit) : base;           // NaN input: no lane compares equal
 			const uint32_t lin = (uint32_t)(win - base);
 			sym = lin ^ (lin >> 1);
@@ -304,102 +310,178 @@ __device__ __forceinline__ void carrier_store(const CarrierRegs &c, ChanArrays &
 }
 
 // processes samples [k0, k1); returns the index of the sample during which the framer reset the timing loop (the wave stops
-// after that sample), or -1
+// after that sample), or -1.
+// The loop runs over the timing-recovery OUTPUTS of the chunk, not over its input samples: two of three input samples yield an
+// output, and a loop nest "per sample: level, noise-floor clock, output count; per output: ..." spends ~30 instructions and seven
+// branches per input sample on bookkeeping -- a quarter of this wave's time.  The input sample an output belongs to is the first one
+// whose cumulative output count exceeds the output's index (one compare across the lanes that hold the chunk's counts + s_ff1);
+// what the reference does per input sample (the noise-floor estimator's clock while searching, src/hfdl.c:700-702; the sample
+// counter) is caught up in closed form when the first output of a later sample comes along -- the framer state cannot change in
+// between, it only changes on outputs.
 template <bool TAPS>
 __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, const DemodShared &sh,
-		int k0, int k1, int &nsym, int lane)
+		int k0, int &k1, int &nsym, int lane)
 {
 	const int t = (lane & 15) - 1;
 	const bool row1 = (lane >> 4) & 1, act = t >= 0 && lane < 32;
+	int n = k1 - k0;                             // <= DM_CHUNK <= 64
 	// the chunk's levels, output counts and (up to 64) timing-recovery outputs, one per lane: the loop below takes them with
 	// v_readlane instead of a dependent LDS round trip per sample
-	const float lv_l = (k0 + lane < k1) ? io.lvl[k0 + lane] : 0.f;
-	const int cum_l = (k0 + lane < k1) ? (int)sh.cum[k0 + lane] : 0;
+	const float lv_l = (lane < n) ? io.lvl[k0 + lane] : 0.f;
+	const int cum_l = (lane < n) ? (int)sh.cum[k0 + lane] : 0x7fffffff;
 	const int jbase = k0 > 0 ? (int)sh.cum[k0 - 1] : 0;
 	const cf oq_l = (jbase + lane < sh.outq_cap) ? sh.outq[jbase + lane] : cf{0.f, 0.f};
-	int j = jbase;
-	bool runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
-	for (int k = k0; k < k1; k++, s.sample_cnt++) {
-		const float level = lane_value(lv_l, k - k0);
+	{   // the chunk's outputs are taken from the 64 lanes of oq_l: a chunk that produced more (a timing loop far off its rate: up to four
+		// outputs per input sample) is cut where they end, and k1 tells the caller
+		const unsigned long long over = __ballot(lane < n && cum_l - jbase > 64);
+		if (__builtin_expect(over != 0, 0)) { n = (int)__builtin_ctzll(over); k1 = k0 + n; }      // n >= 1: one sample yields at most 4 outputs
+	}
+	int jstop = __builtin_amdgcn_readlane(cum_l, n - 1);
+	if (jstop > sh.outq_cap) jstop = sh.outq_cap;
+	const uint64_t cnt0 = s.sample_cnt;
+	int kdone = 0;                               // input samples of the chunk whose per-sample bookkeeping is done: k0 .. k0 + kdone - 1
+	int reset_at = -1;
+	// noise-floor estimator clock of input samples [kdone, upto] of the chunk (src/hfdl.c:700-702): it ticks while the framer searches, and
+	// every 256th tick takes that sample's level.  The framer state is the same for all of them (no output in between).
+	// Called in front of every on-time output (the only place the framer state changes), so every sample is counted in the state the
+	// reference saw it in.
+	auto catch_up = [&](int upto) {
 		if (s.fr_state == FR_A1) {
-			// every 256th sample only: a scalar branch, not a select evaluated on every sample
-			s.nf_clk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s.nf_clk + 1u));
-			if ((s.nf_clk & 0xFFu) == 0xFFu) s.noise_floor = 0.65f * s.noise_floor + 0.35f * fminf(s.noise_floor, level) + 1e-6f;
+			const uint32_t d = (uint32_t)(upto + 1 - kdone), c0 = s.nf_clk;
+			uint32_t first = (0xFFu - c0) & 0xFFu;          // ticks until the low byte reads 0xFF (0: a whole turn)
+			if (first == 0) first = 256;
+			s.nf_clk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 + d));
+			if (first <= d) {                                // at most once: d <= 64
+				const float level = lane_value(lv_l, kdone + (int)first - 1);
+				s.noise_floor = 0.65f * s.noise_floor + 0.35f * fminf(s.noise_floor, level) + 1e-6f;
+			}
 		}
-		int j1 = __builtin_amdgcn_readlane(cum_l, k - k0);
-		if (j1 > sh.outq_cap) j1 = sh.outq_cap;
-		for (; j < j1; j++, s.symsync_out_idx++) {
-			cf oi;
-			if (__builtin_expect(j - jbase < 64, 1)) { oi.x = lane_value(oq_l.x, j - jbase); oi.y = lane_value(oq_l.y, j - jbase); }
-			else oi = sh.outq[j];
-			// costas_cccf_step + execute, :256-258, :284-292
-			{   // selects, not branches: a taken branch costs a lone wave ~4 instruction slots (profiles/micro)
-				const float ph = s.phi + s.dphi;
-				const float dn = ph - (float)(2.0 * M_PI), up = ph + (float)(2.0 * M_PI);
-				s.phi = ph > (float)M_PI ? dn : (ph < -(float)M_PI ? up : ph);
-			}
-			// |phi| <= pi: the hardware sin/cos (argument in revolutions) needs no range reduction
-#ifdef HFDL_DM_LIBM_TRIG              // experiment (profiles/r03_experiments.md): the library's accurate sincosf instead of v_sin / v_cos
-			float sp, cp;
-			sincosf(s.phi, &sp, &cp);
-#else
-			const float rev = s.phi * 0.15915494309189535f;
-			const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
+		kdone = upto + 1;
+	};
+	bool runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
+	for (int j = jbase; j < jstop; j++, s.symsync_out_idx++) {
+		// the input sample that produced output j: the first whose cumulative count exceeds j (lanes beyond the chunk hold INT_MAX)
+#ifdef HFDL_DM_PROBE
+		const unsigned long long tA0 = __builtin_amdgcn_s_memtime();
+		const int st0 = s.fr_state;
 #endif
-			cf r;
-			r.x = oi.x * cp + oi.y * sp;
-			r.y = oi.y * cp - oi.x * sp;
-			if (__builtin_expect(runaway, 0)) {  // costas run-away while searching (src/hfdl.c:709-716); dphi only moves in on_symbol()
-				s.dphi = s.phi = 0.f;
-				symsync_reset(s, a);
-				runaway = false;
-			}
-			// eqlms_cccf_push: the row moves down one lane and lane 15, which has no source inside the row, takes the new sample
-			{
-				const float x2n = r.x * r.x + r.y * r.y;
-				const float x2o = lane_value(c.ex2, 1);
-				const float nu = row1 ? r.y : r.x, nv = row1 ? -r.x : r.y;
-				c.eu = dpp_row_shl1(nu, c.eu);
-				c.ev = dpp_row_shl1(nv, c.ev);
-				c.ex2 = dpp_row_shl1(x2n, c.ex2);
-				s.eq_x2sum = s.eq_x2sum + x2n - x2o;
-				s.eq_count++;
-			}
-			if (s.symsync_out_idx & 1u) {
-				// eqlms_cccf_execute, sum conj(w_i) x_i: real part reduced in row 0, imaginary part in row 1, one scan
-				const float p = row_scan_sum(act ? c.ewx * c.eu + c.ewy * c.ev : 0.f);
-				cf y; y.x = lane_value(p, 15); y.y = lane_value(p, 31);
-				if (s.fr_state == FR_EQ_TRAIN) {
-					// eqlms_cccf_step(d = known T symbol, d_hat = y)
-					bool run = true;
-					if (!s.eq_full) { if (s.eq_count < (uint32_t)D_EQ) run = false; else s.eq_full = 1; }
-					if (run) {
-						const float tv = t_symbol(s.T_idx) * ((s.bitmask & 1u) ? -1.0f : 1.0f);
-						const float er = tv - y.x, ei = -(0.0f - y.y);
-						const float bx = row1 ? -c.ev : c.eu, by = row1 ? c.eu : c.ev;       // the window sample (x, y) in either row
-						const float pr = er * bx - ei * by, pi = er * by + ei * bx;
-						c.ewx = c.ewx + 0.1f * pr / s.eq_x2sum;
-						c.ewy = c.ewy + 0.1f * pi / s.eq_x2sum;
-					}
-					s.T_idx++;
+		cf oi;
+		oi.x = lane_value(oq_l.x, j - jbase); oi.y = lane_value(oq_l.y, j - jbase);
+		// costas_cccf_step + execute, :256-258, :284-292
+		{   // selects, not branches: a taken branch costs a lone wave ~4 instruction slots (profiles/micro)
+			const float ph = s.phi + s.dphi;
+			const float dn = ph - (float)(2.0 * M_PI), up = ph + (float)(2.0 * M_PI);
+			s.phi = ph > (float)M_PI ? dn : (ph < -(float)M_PI ? up : ph);
+		}
+		// |phi| <= pi: the hardware sin/cos (argument in revolutions) needs no range reduction
+#ifdef HFDL_DM_LIBM_TRIG              // experiment (profiles/r03_experiments.md): the library's accurate sincosf instead of v_sin / v_cos
+		float sp, cp;
+		sincosf(s.phi, &sp, &cp);
+#else
+		const float rev = s.phi * 0.15915494309189535f;
+		const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
+#endif
+		cf r;
+		r.x = oi.x * cp + oi.y * sp;
+		r.y = oi.y * cp - oi.x * sp;
+		if (__builtin_expect(runaway, 0)) {  // costas run-away while searching (src/hfdl.c:709-716); dphi only moves in on_symbol()
+			s.dphi = s.phi = 0.f;
+			symsync_reset(s, a);
+			runaway = false;
+		}
+		// eqlms_cccf_push: the row moves down one lane and lane 15, which has no source inside the row, takes the new sample
+		{
+			const float x2n = r.x * r.x + r.y * r.y;
+			const float x2o = lane_value(c.ex2, 1);
+			const float nu = row1 ? r.y : r.x, nv = row1 ? -r.x : r.y;
+			c.eu = dpp_row_shl1(nu, c.eu);
+			c.ev = dpp_row_shl1(nv, c.ev);
+			c.ex2 = dpp_row_shl1(x2n, c.ex2);
+			s.eq_x2sum = s.eq_x2sum + x2n - x2o;
+			s.eq_count++;
+		}
+		if (s.symsync_out_idx & 1u) {
+			// eqlms_cccf_execute, sum conj(w_i) x_i: real part reduced in row 0, imaginary part in row 1, one scan
+			const float p = row_scan_sum(act ? c.ewx * c.eu + c.ewy * c.ev : 0.f);
+			cf y; y.x = lane_value(p, 15); y.y = lane_value(p, 31);
+			if (s.fr_state == FR_EQ_TRAIN) {
+				// eqlms_cccf_step(d = known T symbol, d_hat = y)
+				bool run = true;
+				if (!s.eq_full) { if (s.eq_count < (uint32_t)D_EQ) run = false; else s.eq_full = 1; }
+				if (run) {
+					const float tv = t_symbol(s.T_idx) * ((s.bitmask & 1u) ? -1.0f : 1.0f);
+					const float er = tv - y.x, ei = -(0.0f - y.y);
+					const float bx = row1 ? -c.ev : c.eu, by = row1 ? c.eu : c.ev;       // the window sample (x, y) in either row
+					const float pr = er * bx - ei * by, pi = er * by + ei * bx;
+					c.ewx = c.ewx + 0.1f * pr / s.eq_x2sum;
+					c.ewy = c.ewy + 0.1f * pi / s.eq_x2sum;
 				}
-				if (TAPS && lane == 0) io.tap_symbols[nsym] = y;
-				nsym++;
+				s.T_idx++;
+			}
+			if (TAPS && lane == 0) io.tap_symbols[nsym] = y;
+			nsym++;
+			// The searching framer's symbol -- by far the commonest: a BPSK decision into the 127-bit window, the carrier loop's update, the
+			// correlation against the A sequence, and nothing found.  Decided BEFORE anything is changed: such a symbol is finished here in
+			// straight-line code; every other one (a detection, a frame in progress, the 13-frame re-centring) goes through on_symbol().
+			bool plain = false;
+			if (s.fr_state == FR_A1) {
+				const bool neg = !(y.x > 0);
+				const uint32_t bit = (neg ? 1u : 0u) ^ (s.bitmask & 1u);
+				const uint64_t nhi = ((s.bits_hi << 1) | (s.bits_lo >> 63)) & 0x7FFFFFFFFFFFFFFFull, nlo = (s.bits_lo << 1) | bit;
+				const int m = bits_correlate(nhi, nlo, T.a_hi, T.a_lo);
+				if (__builtin_expect(m > T.a1_lo && m < T.a1_hi && s.s_state == SAMPLER_BITS && s.cur_arity == 1 && s.symbols_wanted <= 1
+						&& s.symbol_cnt + 1 < (uint64_t)(13 * SINGLE_SLOT_FRAME_LEN), 1)) {
+					const float perr = y.y * (neg ? -1.0f : 1.0f) - y.x * 0.0f;      // modem phase error against (+-1, 0), as LaneSlicer writes it
+					const float e = 0.5f * (fabsf(perr + 1.0f) - fabsf(perr - 1.0f));      // costas_cccf_adjust, :276-281
+					s.err = e;
+					s.phi += 0.1f * e;
+					s.dphi += (0.047f * 0.1f * 0.1f) * e;
+					s.symbol_cnt++;
+					s.bits_hi = nhi; s.bits_lo = nlo;
+					runaway = fabsf(s.dphi) > 0.25f;
+					plain = true;
+				}
+			}
+			if (!plain) {
+				// the input sample that produced this output: the first whose cumulative count exceeds j (lanes beyond the chunk hold INT_MAX)
+				const int ki = (int)__builtin_ctzll(__ballot(cum_l > j));
+				if (ki >= kdone) catch_up(ki);       // before the framer state can change
+				const float level = lane_value(lv_l, ki);
+				s.sample_cnt = cnt0 + (uint64_t)ki;
 				on_symbol(s, *sh.S, a, T, io, y, level, LaneSlicer{c.px, c.py, lane});
 				runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
 			}
-			if (__builtin_expect((s.ev_flags & EV_EQ_RESET) != 0, 0)) {      // eqlms_cccf_reset ran (framer reset): mirror it in the register window
+		}
+#if defined(HFDL_DM_PROBE) && HFDL_DM_PROBE >= 2
+		{
+			const unsigned long long dt = HFDL_DM_PROBE == 2 ? __builtin_amdgcn_s_memtime() - tA0 : 1ull;
+			if (st0 == FR_A1) c.pa += dt; else if (st0 == FR_EQ_TRAIN) c.pb += dt; else if (st0 == FR_DATA_1 || st0 == FR_DATA_2) c.pc += dt;
+		}
+#endif
+		if (__builtin_expect(s.ev_flags != 0, 0)) {
+			if (s.ev_flags & EV_EQ_RESET) {      // eqlms_cccf_reset ran (framer reset): mirror it in the register window
 				c.eu = 0.f; c.ev = 0.f; c.ex2 = 0.f;
 				c.ewx = act ? T.eq_h0[t >= 0 ? t : 0] : 0.f; c.ewy = 0.f;
 				s.ev_flags &= ~(uint32_t)EV_EQ_RESET;
 			}
-		}
-		if (__builtin_expect((s.ev_flags & EV_SS_RESET) != 0, 0)) {          // the timing loop was reset during this sample: wave 1 restarts after it
-			s.ev_flags = 0;
-			s.sample_cnt++;
-			return k;
+			if ((s.ev_flags & EV_SS_RESET) != 0 && reset_at < 0) {
+				// the timing loop was reset during this output's input sample: the outputs it had already produced from that sample still
+				// go through (symsync_crcf_execute had returned them, src/hfdl.c:707-708), then the wave stops and wave 1 restarts after it
+				const int kr = (int)__builtin_ctzll(__ballot(cum_l > j));
+				if (kr >= kdone) catch_up(kr);       // only after an off-time output (carrier run-away), which leaves the framer state alone
+				reset_at = kr;
+				int j1 = __builtin_amdgcn_readlane(cum_l, kr);
+				if (j1 < jstop) jstop = j1;
+			}
 		}
 	}
+	if (reset_at >= 0) {
+		s.ev_flags = 0;
+		s.sample_cnt = cnt0 + (uint64_t)reset_at + 1u;
+		return k0 + reset_at;
+	}
+	if (kdone < n) catch_up(n - 1);              // input samples after the last output
+	s.sample_cnt = cnt0 + (uint64_t)n;
 	return -1;
 }
 
@@ -454,6 +536,9 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 	// of barriers, same mailbox reads), so that only its own stage's state is live in its registers.
 	unsigned long long busy = 0;
 	int nsym = 0;
+#ifdef HFDL_DM_PROBE
+	unsigned long long cr_probe[3] = { 0, 0, 0 };
+#endif
 	if (wave == 0) {
 		float agc_g = S.agc_g, agc_y2 = S.agc_y2;
 		PipeProgress pp;
@@ -510,6 +595,9 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 			pp.read(mb);
 		}
 		carrier_store(cr, a, lane);
+#ifdef HFDL_DM_PROBE
+		cr_probe[0] = cr.pa; cr_probe[1] = cr.pb; cr_probe[2] = cr.pc;
+#endif
 		if (lane == 0) {
 			// every field wave 2 owns (the timing-loop scalars it touched through symsync_reset() are wave 1's)
 			S.phi = s3.phi; S.dphi = s3.dphi; S.err = s3.err;
@@ -539,6 +627,10 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 		if (tid == 0) { io.tap_level[io.cap - 4] = (float)(tP0 - tR0); io.tap_level[io.cap - 3] = (float)(tP1 - tP0); }
 		if (wave == 1 && lane == 0) io.tap_level[io.cap - 2] = (float)busy;
 		if (wave == 2 && lane == 0) io.tap_level[io.cap - 1] = (float)busy;
+#ifdef HFDL_DM_PROBE
+		__syncthreads();
+		if (wave == 2 && lane == 0) { io.tap_level[io.cap - 4] = (float)cr_probe[0]; io.tap_level[io.cap - 3] = (float)cr_probe[1]; io.tap_level[io.cap - 2] = (float)cr_probe[2]; }
+#endif
 	}
 	return n_out;
 }
