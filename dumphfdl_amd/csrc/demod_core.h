@@ -40,6 +40,10 @@ __device__ __forceinline__ float dpp_row_shl1(float old, float src)      // lane
 {
 	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x101, 0xf, 0xf, false));
 }
+__device__ __forceinline__ float dpp_row_shl2(float old, float src)      // lane i <- src[i+2]; lanes 14, 15 of every row <- old
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x102, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float dpp_row_ror1(float src)                 // lane i <- src[i-1], lane 0 <- src[15] (inside the row)
 {
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x121, 0xf, 0xf, false));
@@ -88,6 +92,7 @@ struct DemodShared {
 	const float2 *sstab;           // [16 banks][64 lanes] {tap t, tap t+16} of the lane's row: rows 0,1 matched filter, rows 2,3 derivative
 	ChanScalars *S;                // the channel's scalars; every wave owns a disjoint set of fields
 	int *mbox;                     // [2][4] progress mailbox: {mf_ready, ss_to, s3_done, s3_reset}
+	float *sink;                   // [64] write-only scratch, one word per lane
 };
 
 // progress of the three stages as every wave sees it after a step's barrier
@@ -193,6 +198,13 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 	int bi = r.b < 0 ? 0 : (r.b >= D_SS_NPFB ? D_SS_NPFB - 1 : r.b);
 	float2 h = sh.sstab[bi * 64 + lane];
 	float w_lo = base[2 * k0], w_hi = base[2 * (k0 - 16)];
+	// An output's two components are the row totals in lanes 15 (re) and 31 (im): those two lanes store them themselves with an ALL-lane
+	// LDS write whose other lanes aim at a scratch word of their own -- no lane reads, no exec masking on the loop's path.  The
+	// per-sample output counts collect in a register, one lane per input sample of the chunk, and go to LDS once per chunk.
+	const bool out_lane = lane == 15 || lane == 31;
+	float *const out_base = out_lane ? (float *)sh.outq + (lane == 31 ? 1 : 0) : sh.sink + lane;
+	const int out_stride = out_lane ? 2 : 0;
+	int cum_v = 0;
 	for (int k = k0; k < k1; k++) {
 		// the next input sample's window entries are fetched now, a whole iteration before they can be needed (sample k1 belongs to
 		// the next chunk and may still be in the making: that value is never used)
@@ -207,11 +219,11 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 			do {
 				// four 18-tap dot products at once: row 0/1 = matched filter re/im, row 2/3 = derivative filter re/im
 				const float p = row_scan_sum(h.x * wl + h.y * wh);
-				const float mx = lane_value(p, 15), my = lane_value(p, 31);
-				if (lane == 0 && r.j < sh.outq_cap) { cf o; o.x = div3(mx); o.y = div3(my); sh.outq[r.j] = o; }
+				if (__builtin_expect(r.j < sh.outq_cap, 1)) out_base[out_stride * r.j] = div3(p);
 				r.j++;
 				if (r.decim == 2) {
 					r.decim = 0;
+					const float mx = lane_value(p, 15), my = lane_value(p, 31);
 					const float dx = lane_value(p, 47), dy = lane_value(p, 63);
 					float q = mx * dx + my * dy;
 					q = q > 1.0f ? 1.0f : (q < -1.0f ? -1.0f : q);
@@ -235,9 +247,10 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 		r.b -= D_SS_NPFB;
 		bi = r.b < 0 ? 0 : (r.b >= D_SS_NPFB ? D_SS_NPFB - 1 : r.b);
 		h = sh.sstab[bi * 64 + lane];                   // branch of the next input sample: fetched while the stores drain
-		if (lane == 0) sh.cum[k] = (uint16_t)(r.j < 65535 ? r.j : 65535);
+		cum_v = (lane == k - k0) ? (r.j < 65535 ? r.j : 65535) : cum_v;
 		w_lo = n_lo; w_hi = n_hi;
 	}
+	if (lane < k1 - k0) sh.cum[k0 + lane] = (uint16_t)cum_v;
 }
 
 // ---------------- wave 2: carrier loop, equaliser, slicer, framer (src/hfdl.c:709-891) ----------------
@@ -359,48 +372,97 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 		kdone = upto + 1;
 	};
 	bool runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
-	for (int j = jbase; j < jstop; j++, s.symsync_out_idx++) {
-		// the input sample that produced output j: the first whose cumulative count exceeds j (lanes beyond the chunk hold INT_MAX)
+	const int pair_sel = (lane & 1) << 2;        // byte offset of the pair's second output in a lane permute
+	for (int j = jbase; j < jstop;) {
 #ifdef HFDL_DM_PROBE
 		const unsigned long long tA0 = __builtin_amdgcn_s_memtime();
 		const int st0 = s.fr_state;
 #endif
-		cf oi;
-		oi.x = lane_value(oq_l.x, j - jbase); oi.y = lane_value(oq_l.y, j - jbase);
-		// costas_cccf_step + execute, :256-258, :284-292
-		{   // selects, not branches: a taken branch costs a lone wave ~4 instruction slots (profiles/micro)
-			const float ph = s.phi + s.dphi;
-			const float dn = ph - (float)(2.0 * M_PI), up = ph + (float)(2.0 * M_PI);
-			s.phi = ph > (float)M_PI ? dn : (ph < -(float)M_PI ? up : ph);
-		}
-		// |phi| <= pi: the hardware sin/cos (argument in revolutions) needs no range reduction
-#ifdef HFDL_DM_LIBM_TRIG              // experiment (profiles/r03_experiments.md): the library's accurate sincosf instead of v_sin / v_cos
-		float sp, cp;
-		sincosf(s.phi, &sp, &cp);
+		int jo;                                   // the output the rest of the iteration is about
+		bool on_time;
+		if (!(s.symsync_out_idx & 1u) && j + 1 < jstop && !runaway) {
+			// A symbol's two timing-recovery outputs at once, the off-time one in the even lanes and the on-time one in the odd lanes:
+			// one rotation (sin, cos, four products) and one two-lane move of the equaliser window serve both -- the window's newest
+			// entries are lanes 14 (even: the off-time sample) and 15 (odd: the on-time sample) of its row.  Same arithmetic per
+			// output as the single step below; only the carrier phase of each has to be stepped and wrapped on its own.
+			const int sel = ((j - jbase) << 2) + pair_sel;
+			cf oi;
+			oi.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oq_l.x)));
+			oi.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oq_l.y)));
+			float ph1, ph2;
+			{
+				const float ph = s.phi + s.dphi;
+				const float dn = ph - (float)(2.0 * M_PI), up = ph + (float)(2.0 * M_PI);
+				ph1 = ph > (float)M_PI ? dn : (ph < -(float)M_PI ? up : ph);
+			}
+			{
+				const float ph = ph1 + s.dphi;
+				const float dn = ph - (float)(2.0 * M_PI), up = ph + (float)(2.0 * M_PI);
+				ph2 = ph > (float)M_PI ? dn : (ph < -(float)M_PI ? up : ph);
+			}
+			s.phi = ph2;
+#ifdef HFDL_DM_LIBM_TRIG
+			float sp, cp;
+			sincosf((lane & 1) ? ph2 : ph1, &sp, &cp);
 #else
-		const float rev = s.phi * 0.15915494309189535f;
-		const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
+			const float rev = ((lane & 1) ? ph2 : ph1) * 0.15915494309189535f;
+			const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
 #endif
-		cf r;
-		r.x = oi.x * cp + oi.y * sp;
-		r.y = oi.y * cp - oi.x * sp;
-		if (__builtin_expect(runaway, 0)) {  // costas run-away while searching (src/hfdl.c:709-716); dphi only moves in on_symbol()
-			s.dphi = s.phi = 0.f;
-			symsync_reset(s, a);
-			runaway = false;
-		}
-		// eqlms_cccf_push: the row moves down one lane and lane 15, which has no source inside the row, takes the new sample
-		{
+			cf r;
+			r.x = oi.x * cp + oi.y * sp;
+			r.y = oi.y * cp - oi.x * sp;
 			const float x2n = r.x * r.x + r.y * r.y;
-			const float x2o = lane_value(c.ex2, 1);
+			const float x2n1 = lane_value(x2n, 0), x2n2 = lane_value(x2n, 1);
+			const float x2o1 = lane_value(c.ex2, 1), x2o2 = lane_value(c.ex2, 2);
 			const float nu = row1 ? r.y : r.x, nv = row1 ? -r.x : r.y;
-			c.eu = dpp_row_shl1(nu, c.eu);
-			c.ev = dpp_row_shl1(nv, c.ev);
-			c.ex2 = dpp_row_shl1(x2n, c.ex2);
-			s.eq_x2sum = s.eq_x2sum + x2n - x2o;
-			s.eq_count++;
+			c.eu = dpp_row_shl2(nu, c.eu);
+			c.ev = dpp_row_shl2(nv, c.ev);
+			c.ex2 = dpp_row_shl2(x2n, c.ex2);
+			s.eq_x2sum = s.eq_x2sum + x2n1 - x2o1;
+			s.eq_x2sum = s.eq_x2sum + x2n2 - x2o2;
+			s.eq_count += 2;
+			jo = j + 1; j += 2; s.symsync_out_idx += 2;
+			on_time = true;
+		} else {
+			cf oi;
+			oi.x = lane_value(oq_l.x, j - jbase); oi.y = lane_value(oq_l.y, j - jbase);
+			// costas_cccf_step + execute, :256-258, :284-292
+			{   // selects, not branches: a taken branch costs a lone wave ~4 instruction slots (profiles/micro)
+				const float ph = s.phi + s.dphi;
+				const float dn = ph - (float)(2.0 * M_PI), up = ph + (float)(2.0 * M_PI);
+				s.phi = ph > (float)M_PI ? dn : (ph < -(float)M_PI ? up : ph);
+			}
+			// |phi| <= pi: the hardware sin/cos (argument in revolutions) needs no range reduction
+#ifdef HFDL_DM_LIBM_TRIG              // experiment (profiles/r03_experiments.md): the library's accurate sincosf instead of v_sin / v_cos
+			float sp, cp;
+			sincosf(s.phi, &sp, &cp);
+#else
+			const float rev = s.phi * 0.15915494309189535f;
+			const float sp = __builtin_amdgcn_sinf(rev), cp = __builtin_amdgcn_cosf(rev);
+#endif
+			cf r;
+			r.x = oi.x * cp + oi.y * sp;
+			r.y = oi.y * cp - oi.x * sp;
+			if (__builtin_expect(runaway, 0)) {  // costas run-away while searching (src/hfdl.c:709-716); dphi only moves in on_symbol()
+				s.dphi = s.phi = 0.f;
+				symsync_reset(s, a);
+				runaway = false;
+			}
+			// eqlms_cccf_push: the row moves down one lane and lane 15, which has no source inside the row, takes the new sample
+			{
+				const float x2n = r.x * r.x + r.y * r.y;
+				const float x2o = lane_value(c.ex2, 1);
+				const float nu = row1 ? r.y : r.x, nv = row1 ? -r.x : r.y;
+				c.eu = dpp_row_shl1(nu, c.eu);
+				c.ev = dpp_row_shl1(nv, c.ev);
+				c.ex2 = dpp_row_shl1(x2n, c.ex2);
+				s.eq_x2sum = s.eq_x2sum + x2n - x2o;
+				s.eq_count++;
+			}
+			on_time = (s.symsync_out_idx & 1u) != 0;
+			jo = j; j++; s.symsync_out_idx++;
 		}
-		if (s.symsync_out_idx & 1u) {
+		if (on_time) {
 			// eqlms_cccf_execute, sum conj(w_i) x_i: real part reduced in row 0, imaginary part in row 1, one scan
 			const float p = row_scan_sum(act ? c.ewx * c.eu + c.ewy * c.ev : 0.f);
 			cf y; y.x = lane_value(p, 15); y.y = lane_value(p, 31);
@@ -442,9 +504,47 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 					plain = true;
 				}
 			}
+			else if (s.symbols_wanted > 1) {
+				// A frame in progress, between two framer transitions (on_symbol() returns in front of its state switch): decision and
+				// carrier loop update, the symbol to where the sampler wants it, the running signal level, the countdown -- the same
+				// statements in the same order, laid out as one straight line instead of on_symbol()'s general control flow (which costs
+				// this lone wave ten taken branches per symbol).  The framer state is not FR_A1 here and does not change.
+				const int ki = (int)__builtin_ctzll(__ballot(cum_l > jo));
+				if (ki >= kdone) kdone = ki + 1;      // the noise-floor clock stands still outside the search: nothing to catch up with
+				const float level = lane_value(lv_l, ki);
+				float perr;
+				uint32_t bits = LaneSlicer{c.px, c.py, lane}(s.cur_arity, y, &perr);
+				const float e = 0.5f * (fabsf(perr + 1.0f) - fabsf(perr - 1.0f));      // costas_cccf_adjust, :276-281
+				s.err = e;
+				s.phi += 0.1f * e;
+				s.dphi += (0.047f * 0.1f * 0.1f) * e;
+				s.symbol_cnt++;
+				if (s.s_state == SAMPLER_SYMBOLS) {
+					if (s.use_data) {
+						if (s.data_n < MAX_DATA_SYMBOLS) {
+							if (lane == 0) io.data[s.data_slot * MAX_DATA_SYMBOLS + s.data_n] = y;
+							s.data_n++;
+						}
+					} else if (s.training_n < T_LEN) {
+						a.training[s.training_n] = y;
+						s.training_n++;
+					}
+				} else if (s.s_state == SAMPLER_BITS) {
+					bits ^= s.bitmask;
+					for (int b = 0; b < s.cur_arity; b++, bits >>= 1) {
+						s.bits_hi = ((s.bits_hi << 1) | (s.bits_lo >> 63)) & 0x7FFFFFFFFFFFFFFFull;
+						s.bits_lo = (s.bits_lo << 1) | (bits & 1u);
+					}
+				}
+				s.signal_level = (s.signal_level * s.frame_symbol_cnt + level) / (s.frame_symbol_cnt + 1.0f);
+				s.frame_symbol_cnt += 1.0f;
+				s.symbols_wanted--;
+				runaway = false;                     // it only counts while searching
+				plain = true;
+			}
 			if (!plain) {
 				// the input sample that produced this output: the first whose cumulative count exceeds j (lanes beyond the chunk hold INT_MAX)
-				const int ki = (int)__builtin_ctzll(__ballot(cum_l > j));
+				const int ki = (int)__builtin_ctzll(__ballot(cum_l > jo));
 				if (ki >= kdone) catch_up(ki);       // before the framer state can change
 				const float level = lane_value(lv_l, ki);
 				s.sample_cnt = cnt0 + (uint64_t)ki;
@@ -467,7 +567,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 			if ((s.ev_flags & EV_SS_RESET) != 0 && reset_at < 0) {
 				// the timing loop was reset during this output's input sample: the outputs it had already produced from that sample still
 				// go through (symsync_crcf_execute had returned them, src/hfdl.c:707-708), then the wave stops and wave 1 restarts after it
-				const int kr = (int)__builtin_ctzll(__ballot(cum_l > j));
+				const int kr = (int)__builtin_ctzll(__ballot(cum_l > jo));
 				if (kr >= kdone) catch_up(kr);       // only after an off-time output (carrier run-away), which leaves the framer state alone
 				reset_at = kr;
 				int j1 = __builtin_amdgcn_readlane(cum_l, kr);

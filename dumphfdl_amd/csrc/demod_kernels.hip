@@ -56,7 +56,7 @@ __device__ __forceinline__ void stage_copy(T *__restrict__ dst, const T *__restr
 
 // LDS carve-up of a channel's workgroup, shared by the kernel and the host-side size computation
 struct DemodLds {
-	size_t arrays, scalars, sstab, mf, eq, m1, corr, mbox, rs, agc, mfo, lvl, outq, cum, rs_h, total;
+	size_t arrays, scalars, sstab, mf, eq, m1, corr, mbox, sink, rs, agc, mfo, lvl, outq, cum, rs_h, total;
 	__host__ __device__ explicit DemodLds(int cap)
 	{
 		size_t o = 0;
@@ -69,6 +69,7 @@ struct DemodLds {
 		m1 = take(sizeof(uint64_t) * 16);
 		corr = take(sizeof(float) * 128);
 		mbox = take(sizeof(int) * 8);
+		sink = take(sizeof(float) * 64);               // where the lanes of an all-lane LDS write that have nothing to say put it
 		rs = take(sizeof(cf) * (size_t)cap);
 		agc = take(sizeof(cf) * (size_t)cap);          // agc and mfo are adjacent: together they stage the block's input
 		mfo = take(sizeof(cf) * ((size_t)cap + SS_HIST)) + sizeof(cf) * SS_HIST;     // SS_HIST history entries sit right before mf[0]
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, Demod
 	sh.sstab = l_sstab;
 	sh.S = S;
 	sh.mbox = (int *)(lds + L.mbox);
+	sh.sink = (float *)(lds + L.sink);
 	demod_block<TAPS>(*A, K, io, sh, l_in, n_block);
 	__syncthreads();
 	{
