@@ -346,7 +346,10 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 	const cf oq_l = (jbase + lane < sh.outq_cap) ? sh.outq[jbase + lane] : cf{0.f, 0.f};
 	{   // the chunk's outputs are taken from the 64 lanes of oq_l: a chunk that produced more (a timing loop far off its rate: up to four
 		// outputs per input sample) is cut where they end, and k1 tells the caller
-		const unsigned long long over = __ballot(lane < n && cum_l - jbase > 64);
+#ifndef HFDL_DM_OUT_LANES            // (a smaller value makes every chunk take the cut: how that path was tested, profiles/r03_experiments.md)
+#define HFDL_DM_OUT_LANES 64
+#endif
+		const unsigned long long over = __ballot(lane < n && cum_l - jbase > HFDL_DM_OUT_LANES);
 		if (__builtin_expect(over != 0, 0)) { n = (int)__builtin_ctzll(over); k1 = k0 + n; }      // n >= 1: one sample yields at most 4 outputs
 	}
 	int jstop = __builtin_amdgcn_readlane(cum_l, n - 1);

@@ -756,8 +756,9 @@ extern "C" int hfdl_gpu_frontend_prefetch_cancel(hfdl_gpu_frontend *fe)
 	if (fe->prefetched == nullptr) return 0;
 	HIP_TRY(hipSetDevice(fe->device));
 	// the copy is in flight on stream C: let it finish (the caller gets its buffer back), then forget the block.  It keeps its host
-	// block number -- input_done_upto() of that number returns at once -- and its staging buffer is simply refilled by the next
-	// copy: ev_stage_free of that buffer was last recorded by the block that used it before, which stream C has already waited for.
+	// block number -- input_done_upto() of that number returns at once -- so the next block goes to the OTHER staging buffer, and
+	// this one is refilled by the copy after that: its ev_stage_free was last recorded by the block that used it before the
+	// cancelled one, which stream C has already waited for.
 	HIP_TRY(hipStreamSynchronize(fe->stream_c));
 	fe->prefetched = nullptr; fe->prefetched_sb = -1;
 	return 0;
