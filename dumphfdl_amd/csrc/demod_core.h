@@ -93,6 +93,7 @@ struct DemodShared {
 	ChanScalars *S;                // the channel's scalars; every wave owns a disjoint set of fields
 	int *mbox;                     // [2][4] progress mailbox: {mf_ready, ss_to, s3_done, s3_reset}
 	float *sink;                   // [64] write-only scratch, one word per lane
+	cf *stage;                     // [64] the carrier wave's data symbols of one chunk (a chunk has at most 64 outputs)
 };
 
 // progress of the three stages as every wave sees it after a step's barrier
@@ -190,6 +191,9 @@ __device__ __forceinline__ void symsync_store(const SymsyncRegs &r, ChanScalars 
 	}
 }
 
+// MASKED: some window entries of the chunk's first samples date from before the last timing-loop reset (only in the 18 samples after
+// one); the common chunk runs the variant without the per-sample test and selects (14 instructions of this wave's ~75 per sample).
+template <bool MASKED>
 __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &T, const BlockIo &io, const DemodShared &sh, int k0, int k1, int lane)
 {
 	const int row = lane >> 4, t = lane & 15;
@@ -211,7 +215,7 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 		const float n_lo = base[2 * (k + 1)], n_hi = base[2 * (k + 1 - 16)];
 		if (r.b < D_SS_NPFB) {
 			float wl = w_lo, wh = w_hi;
-			if (k - (D_SS_TAPS - 1) < r.valid_from && row < 2) {          // matched-filter window entries from before the last reset are empty
+			if (MASKED && k - (D_SS_TAPS - 1) < r.valid_from && row < 2) {          // matched-filter window entries from before the last reset are empty
 				if (k - t < r.valid_from) wl = 0.f;
 				if (k - t - 16 < r.valid_from) wh = 0.f;
 			}
@@ -357,6 +361,15 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 	const uint64_t cnt0 = s.sample_cnt;
 	int kdone = 0;                               // input samples of the chunk whose per-sample bookkeeping is done: k0 .. k0 + kdone - 1
 	int reset_at = -1;
+	// Data symbols of a frame in progress go to HBM (the frame buffer the burst decoder reads) a chunk at a time: every lane writes the
+	// (wave-uniform) symbol to the next slot of a 64-entry LDS stage, and one coalesced store per chunk moves them -- instead of a lane-0
+	// store under an exec mask with its 64-bit address arithmetic per symbol.  A chunk's staged symbols are consecutive in one frame buffer
+	// (a frame's data ends with the frame; the next frame's starts a preamble later).
+	int staged = 0, stage_at = 0;                // symbols in the stage, frame-buffer index of the first
+	auto flush_stage = [&]() {
+		if (lane < staged) io.data[stage_at + lane] = sh.stage[lane];
+		staged = 0;
+	};
 	// noise-floor estimator clock of input samples [kdone, upto] of the chunk (src/hfdl.c:700-702): it ticks while the framer searches, and
 	// every 256th tick takes that sample's level.  The framer state is the same for all of them (no output in between).
 	// Called in front of every on-time output (the only place the framer state changes), so every sample is counted in the state the
@@ -525,7 +538,8 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				if (s.s_state == SAMPLER_SYMBOLS) {
 					if (s.use_data) {
 						if (s.data_n < MAX_DATA_SYMBOLS) {
-							if (lane == 0) io.data[s.data_slot * MAX_DATA_SYMBOLS + s.data_n] = y;
+							if (staged == 0) stage_at = s.data_slot * MAX_DATA_SYMBOLS + s.data_n;
+							sh.stage[staged++] = y;
 							s.data_n++;
 						}
 					} else if (s.training_n < T_LEN) {
@@ -546,6 +560,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				plain = true;
 			}
 			if (!plain) {
+				if (staged) flush_stage();           // on_symbol() stores a data symbol itself: the stage holds consecutive symbols only
 				// the input sample that produced this output: the first whose cumulative count exceeds j (lanes beyond the chunk hold INT_MAX)
 				const int ki = (int)__builtin_ctzll(__ballot(cum_l > jo));
 				if (ki >= kdone) catch_up(ki);       // before the framer state can change
@@ -578,6 +593,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 			}
 		}
 	}
+	if (staged) flush_stage();
 	if (reset_at >= 0) {
 		s.ev_flags = 0;
 		s.sample_cnt = cnt0 + (uint64_t)reset_at + 1u;
@@ -672,7 +688,10 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 			const unsigned long long tb = TAPS ? __builtin_amdgcn_s_memtime() : 0ull;
 			if (pp.restart) symsync_restart(ss, sh, pp.ss_ready);
 			int to = pp.ss_ready + DM_CHUNK < pp.mf_ready ? pp.ss_ready + DM_CHUNK : pp.mf_ready;
-			if (to > pp.ss_ready) symsync_chunk(ss, T, io, sh, pp.ss_ready, to, lane); else to = pp.ss_ready;
+			if (to > pp.ss_ready) {
+				if (__builtin_expect(pp.ss_ready - (D_SS_TAPS - 1) < ss.valid_from, 0)) symsync_chunk<true>(ss, T, io, sh, pp.ss_ready, to, lane);
+				else symsync_chunk<false>(ss, T, io, sh, pp.ss_ready, to, lane);
+			} else to = pp.ss_ready;
 			if (lane == 0) mb[1] = to;
 			if (TAPS) busy += __builtin_amdgcn_s_memtime() - tb;
 			__syncthreads();

@@ -56,7 +56,7 @@ __device__ __forceinline__ void stage_copy(T *__restrict__ dst, const T *__restr
 
 // LDS carve-up of a channel's workgroup, shared by the kernel and the host-side size computation
 struct DemodLds {
-	size_t arrays, scalars, sstab, mf, eq, m1, corr, mbox, sink, rs, agc, mfo, lvl, outq, cum, rs_h, total;
+	size_t arrays, scalars, sstab, mf, eq, m1, corr, mbox, sink, stage, rs, agc, mfo, lvl, outq, cum, rs_h, total;
 	__host__ __device__ explicit DemodLds(int cap)
 	{
 		size_t o = 0;
@@ -70,6 +70,7 @@ struct DemodLds {
 		corr = take(sizeof(float) * 128);
 		mbox = take(sizeof(int) * 8);
 		sink = take(sizeof(float) * 64);               // where the lanes of an all-lane LDS write that have nothing to say put it
+		stage = take(sizeof(cf) * 64);                 // data symbols of the carrier wave's current chunk, on their way to HBM
 		rs = take(sizeof(cf) * (size_t)cap);
 		agc = take(sizeof(cf) * (size_t)cap);          // agc and mfo are adjacent: together they stage the block's input
 		mfo = take(sizeof(cf) * ((size_t)cap + SS_HIST)) + sizeof(cf) * SS_HIST;     // SS_HIST history entries sit right before mf[0]
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, Demod
 	sh.S = S;
 	sh.mbox = (int *)(lds + L.mbox);
 	sh.sink = (float *)(lds + L.sink);
+	sh.stage = (cf *)(lds + L.stage);
 	demod_block<TAPS>(*A, K, io, sh, l_in, n_block);
 	__syncthreads();
 	{
