@@ -333,8 +333,8 @@ __device__ __forceinline__ void carrier_store(const CarrierRegs &c, ChanArrays &
 // branches per input sample on bookkeeping -- a quarter of this wave's time.  The input sample an output belongs to is the first one
 // whose cumulative output count exceeds the output's index (one compare across the lanes that hold the chunk's counts + s_ff1);
 // what the reference does per input sample (the noise-floor estimator's clock while searching, src/hfdl.c:700-702; the sample
-// counter) is caught up in closed form when the first output of a later sample comes along -- the framer state cannot change in
-// between, it only changes on outputs.
+// counter) is caught up in closed form in front of every symbol that can change the framer state (those that go through on_symbol())
+// and at the end of the chunk -- the state is the same for all the samples in between, it only changes on such symbols.
 template <bool TAPS>
 __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, const DemodShared &sh,
 		int k0, int &k1, int &nsym, int lane)
@@ -372,8 +372,8 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 	};
 	// noise-floor estimator clock of input samples [kdone, upto] of the chunk (src/hfdl.c:700-702): it ticks while the framer searches, and
 	// every 256th tick takes that sample's level.  The framer state is the same for all of them (no output in between).
-	// Called in front of every on-time output (the only place the framer state changes), so every sample is counted in the state the
-	// reference saw it in.
+	// Called in front of every symbol handed to on_symbol() (the only place the framer state changes) and at the end of the chunk, so
+	// every sample is counted in the state the reference saw it in.
 	auto catch_up = [&](int upto) {
 		if (s.fr_state == FR_A1) {
 			const uint32_t d = (uint32_t)(upto + 1 - kdone), c0 = s.nf_clk;
