@@ -182,6 +182,37 @@ def test_end_to_end_small_matches_oracle(gpu, oracle):
         assert a["slot"] == b["slot"] and a["bit_rate"] == b["bit_rate"]
 
 
+def test_level_extremes_carrier_offsets_and_adjacent_channels(gpu, oracle):
+    """What real bands do to a receiver, GPU against oracle: channels 3 kHz apart (the HFDL raster) transmitting at once with 26 dB
+    between them; +-40 Hz of carrier offset (twice what the other tests use); a burst 7 dB above the in-channel noise beside a
+    near-full-scale one; a near-full-scale onset out of silence (the AGC swings through ~50 dB inside the prekey: the reference
+    chain, as restated, finds A1 and loses A2 -- and so must the device).  The gate is identity: same PDUs, same per-channel event
+    counters (checked by _run_both), whatever each burst's fate; nine of the eleven bursts are known to decode."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_930_000, 9_933_000, 10_037_000, 10_040_000, 10_081_000, 10_084_000]
+    rng = np.random.default_rng(404)
+    bursts = []
+
+    def add(f, mode, t0, amp, cfo):
+        bursts.append(dict(freq=f, mode=mode, octets=synth.make_pdu(rng, mode), t0=t0, amp=amp, cfo=cfo))
+
+    add(freqs[0], 3, 0.40, 0.30, +12.0); add(freqs[1], 1, 0.55, 0.015, -8.0)       # 26 dB between neighbours, overlapping in time
+    add(freqs[2], 2, 0.30, 0.05, +40.0); add(freqs[3], 0, 0.45, 0.05, -40.0)        # equal levels, opposite carrier offsets
+    add(freqs[4], 0, 0.35, 0.006, +3.0); add(freqs[5], 3, 0.50, 0.9, -20.0)         # +7 dB in-channel SNR beside a near-full-scale onset
+    add(freqs[0], 5, 3.2, 0.015, -30.0); add(freqs[1], 7, 3.3, 0.30, +30.0)         # levels swapped, double-slot modes
+    add(freqs[2], 4, 3.1, 0.006, 40.0); add(freqs[3], 6, 3.25, 0.3, -40.0)
+    add(freqs[5], 2, 3.4, 0.2, 0.0)
+    dur = 8.4
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.01, seed=404)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    decoded = {i for p in got for i, b in enumerate(bursts) if b["freq"] == p["freq"] and p["octets"][:len(b["octets"])] == b["octets"]}
+    assert decoded == {0, 1, 2, 3, 4, 7, 8, 9, 10}, decoded
+    for a, b in zip(sorted(got, key=key), sorted(want, key=key)):
+        assert abs(a["freq_err_hz"] - b["freq_err_hz"]) < 0.05 and abs(a["rssi_db"] - b["rssi_db"]) < 0.05
+
+
 def test_end_to_end_lpdu_lists(gpu, oracle):
     """MPDUs carrying real LPDU lists (down- and uplink; some LPDUs with a spoiled FCS) through the whole path: every PDU
     record's lpdus_* counts -- parse_lpdu_list + lpdu_parse's checks done by the burst decoder on the device -- equal both
