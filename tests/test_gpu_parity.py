@@ -213,6 +213,34 @@ def test_level_extremes_carrier_offsets_and_adjacent_channels(gpu, oracle):
         assert abs(a["freq_err_hz"] - b["freq_err_hz"]) < 0.05 and abs(a["rssi_db"] - b["rssi_db"]) < 0.05
 
 
+@pytest.mark.parametrize("delay_ms,echo_db,fade_hz,depth", [(0.5, -6, 0.7, 0.4), (2.0, -3, 0.3, 0.3)])
+def test_two_path_channel_with_fading(gpu, oracle, delay_ms, echo_db, fade_hz, depth):
+    """What the T/2-spaced LMS equaliser is there for (src/hfdl.c:717-733): a second path 0.5 / 2 ms late, 6 / 3 dB down, under a slow
+    fade of +-30..40 %.  The equaliser's training steps (two IEEE divisions and a weight update per known symbol) decide every frame here;
+    every burst decodes, and the device's PDUs, event counters and carrier / level readings are the oracle's."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_930_000, 9_978_000, 10_037_000, 10_081_500]
+    dur = 9.0
+    bursts = synth.plan_traffic(freqs, dur, seed=77, dense=True, amp=(0.02, 0.05), cfo_hz=15.0)
+    x0 = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.0, seed=77)
+    d = int(round(delay_ms * 1e-3 * fs))
+    echo = np.zeros_like(x0)
+    echo[d:] = x0[:-d]
+    t = np.arange(len(x0)) / fs
+    fade = 1.0 + depth * np.sin(2 * np.pi * fade_hz * t + 0.7)
+    rng = np.random.default_rng(77)
+    x = ((x0 + 10 ** (echo_db / 20) * np.exp(1j * 1.1) * echo) * fade
+         + rng.normal(0, 0.01, len(x0)) + 1j * rng.normal(0, 0.01, len(x0))).astype(np.complex64)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    assert len(got) == len(bursts) == 7
+    for p in got:
+        assert any(p["octets"][:len(b["octets"])] == b["octets"] for b in bursts if b["freq"] == p["freq"]), p["freq"]
+    for a, b in zip(sorted(got, key=key), sorted(want, key=key)):
+        assert abs(a["freq_err_hz"] - b["freq_err_hz"]) < 0.05 and abs(a["rssi_db"] - b["rssi_db"]) < 0.05
+
+
 def test_end_to_end_lpdu_lists(gpu, oracle):
     """MPDUs carrying real LPDU lists (down- and uplink; some LPDUs with a spoiled FCS) through the whole path: every PDU
     record's lpdus_* counts -- parse_lpdu_list + lpdu_parse's checks done by the burst decoder on the device -- equal both
