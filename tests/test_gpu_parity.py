@@ -515,9 +515,11 @@ def test_marginal_snr_same_pdus_even_when_wrong(gpu, oracle):
 
 
 @pytest.mark.parametrize("fs,offs", [(12_000, [-2_000]), (48_000, [-15_000, 9_000]), (768_000, [-300_000, 5_000, 333_000]),
-                                      (2_400_000, [-1_100_000, 1_050_000])])
+                                      (2_400_000, [-1_100_000, 1_050_000]), (345_600, [-100_000, 50_000]), (345_599, [-100_000, 50_000])])
 def test_other_sample_rates(gpu, oracle, fs, offs):
-    """Receiver rates outside BASELINE.json's configs (12 ksps = post_decimation only, Airspy 768 ksps, RTL 2.4 Msps):
+    """Receiver rates outside BASELINE.json's configs (12 ksps = post_decimation only, Airspy 768 ksps, RTL 2.4 Msps) and the two ends
+    of the resampler's range -- 345 600 sps = 5400 x 64: channel rate 5400, resampling rate exactly 1; one sample per second less:
+    decimation 32, channel rate 10 799.97, rate 0.500001 (at 0.5 msresamp would grow a half-band stage; the planner cannot reach it):
     geometry, channelizer output and decoded PDUs against the oracle."""
     cf = 10_000_000
     freqs = [cf + o for o in offs]
