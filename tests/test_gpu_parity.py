@@ -386,6 +386,23 @@ def test_degenerate_inputs(gpu, oracle):
     fe.close()
 
 
+def test_channels_at_the_very_band_edge(gpu, oracle):
+    """Channels 1 Hz inside +-fs/2 (the span check of src/main.c:214-226 admits them), whose carrier 1440 Hz above the channel frequency
+    and pass-band wrap around the band edge: fastddc's circular bin shift folds them onto the other end of the spectrum, so the channels
+    at -fs/2 + 1 and +fs/2 - 1 hear the same signals (2 Hz apart) and both decode the stronger of two overlapping bursts.  Identity with
+    the oracle on PDUs and per-channel counters (checked by _run_both) is the gate."""
+    fs, cf = 250000, 10_000_000
+    freqs = [cf - 124_999, cf - 124_000, cf + 122_000, cf + 124_999]
+    rng = np.random.default_rng(5)
+    bursts = [dict(freq=f, mode=i % 4, octets=synth.make_pdu(rng, i % 4), t0=0.4 + 0.05 * i, amp=0.05, cfo=float(rng.uniform(-10, 10)))
+              for i, f in enumerate(freqs)]
+    x = synth.synth_wideband(fs, cf, int(3.4 * fs), bursts, noise_sigma=0.01, seed=5)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    assert sorted((p["freq"] - cf, p["mode"]) for p in got) == [(-124_999, 3), (-124_000, 1), (122_000, 2), (124_999, 3)]
+
+
 def test_many_frames_in_one_block(gpu, oracle):
     """64 channels whose bursts end inside the same block: the burst-decoder queue takes them all at once."""
     fs, cf = 1_000_000, 10_000_000
