@@ -403,6 +403,23 @@ def test_channels_at_the_very_band_edge(gpu, oracle):
     assert sorted((p["freq"] - cf, p["mode"]) for p in got) == [(-124_999, 3), (-124_000, 1), (122_000, 2), (124_999, 3)]
 
 
+def test_six_hundred_channels(gpu, oracle):
+    """More channels than any BASELINE.json config has (600; every frequency ten times over, as a receiver list with duplicates
+    would): the fold's slice count drops to one, the demodulator and burst-decoder grids and the frame queue grow with the channel
+    count.  Twenty bursts, each heard by ten channels: 200 PDUs, the oracle's."""
+    fs, cf = 250000, 10_000_000
+    base = [int(cf + (i - 30) * 4_000 + 500) for i in range(60)]
+    freqs = [f for f in base for _ in range(10)]
+    rng = np.random.default_rng(9)
+    bursts = [dict(freq=f, mode=i % 4, octets=synth.make_pdu(rng, i % 4), t0=0.3 + 0.01 * i, amp=0.02, cfo=float(rng.uniform(-8, 8)))
+              for i, f in enumerate(base) if i % 3 == 0]
+    x = synth.synth_wideband(fs, cf, int(3.4 * fs), bursts, noise_sigma=0.004, seed=9)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    assert len(got) == 10 * len(bursts) == 200
+
+
 def test_many_frames_in_one_block(gpu, oracle):
     """64 channels whose bursts end inside the same block: the burst-decoder queue takes them all at once."""
     fs, cf = 1_000_000, 10_000_000
