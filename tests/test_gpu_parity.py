@@ -241,6 +241,31 @@ def test_two_path_channel_with_fading(gpu, oracle, delay_ms, echo_db, fade_hz, d
         assert abs(a["freq_err_hz"] - b["freq_err_hz"]) < 0.05 and abs(a["rssi_db"] - b["rssi_db"]) < 0.05
 
 
+def test_carriers_and_impulses_in_the_band(gpu, oracle):
+    """Interference an HF band is full of: a steady carrier 400 Hz beside one channel's own (a few dB under its bursts), a carrier
+    sweeping through another channel during its bursts, and 900 full-scale impulses over the nine seconds.  All seven bursts still decode;
+    PDUs, counters and readings are the oracle's."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_930_000, 9_978_000, 10_037_000, 10_081_500]
+    dur = 9.0
+    bursts = synth.plan_traffic(freqs, dur, seed=55, dense=True, amp=(0.02, 0.05), cfo_hz=15.0)
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.01, seed=55)
+    t = np.arange(len(x)) / fs
+    rng = np.random.default_rng(55)
+    x = x + 0.012 * np.exp(2j * np.pi * (freqs[0] + 1440 + 400 - cf) * t)
+    sweep_hz = (freqs[2] + 1440 - cf) - 3000 + 6000 * (t / dur)
+    x = x + 0.01 * np.exp(2j * np.pi * np.cumsum(sweep_hz) / fs)
+    at = rng.integers(0, len(x), 900)
+    x[at] += rng.normal(0, 1.0, len(at)) + 1j * rng.normal(0, 1.0, len(at))
+    x = x.astype(np.complex64)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    assert len(got) == len(bursts) == 7
+    for p in got:
+        assert any(p["octets"][:len(b["octets"])] == b["octets"] for b in bursts if b["freq"] == p["freq"]), p["freq"]
+
+
 def test_end_to_end_lpdu_lists(gpu, oracle):
     """MPDUs carrying real LPDU lists (down- and uplink; some LPDUs with a spoiled FCS) through the whole path: every PDU
     record's lpdus_* counts -- parse_lpdu_list + lpdu_parse's checks done by the burst decoder on the device -- equal both
