@@ -445,6 +445,28 @@ def test_six_hundred_channels(gpu, oracle):
     assert len(got) == 10 * len(bursts) == 200
 
 
+def test_constant_payloads_in_every_mode(gpu, oracle):
+    """All-zero, all-one and alternating payloads in each of the eight modes (scrambler, interleaver and Viterbi on their least random
+    input; none of these is a valid MPDU / SPDU, so the on-device triage sees bad frame checks throughout): the device's PDUs are the
+    oracle's, and 23 of the 24 payloads come back octet for octet (the 24th is lost to the preamble search on both sides)."""
+    fs, cf = 1_000_000, 10_000_000
+    freqs = [int(cf + (i - 12) * 14_000 + 3_000) for i in range(24)]
+    bursts = []
+    for i, f in enumerate(freqs):
+        mode, pat = i % 8, (0x00, 0xFF, 0x55)[i // 8]
+        bursts.append(dict(freq=f, mode=mode, octets=bytes([pat]) * synth.mode_sizes(mode)["max_payload"], t0=0.3 + 0.02 * i, amp=0.03,
+                           cfo=float((i * 7) % 31 - 15)))
+    dur = 0.3 + 0.02 * 24 + synth.burst_symbols_len(7) / 1800 + 0.4
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.02, seed=21)
+    got, want, _ = _run_both(gpu, oracle, fs, cf, freqs, x)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    good = sum(1 for p in got if any(b["freq"] == p["freq"] and b["mode"] == p["mode"] and p["octets"][:len(b["octets"])] == b["octets"] for b in bursts))
+    assert good == len(got) == 23
+    for p in got:
+        assert (p["fcs_status"], p["pdu_kind"], p["hdr_len"]) == oracle.pdu_triage(p["octets"])
+
+
 def test_many_frames_in_one_block(gpu, oracle):
     """64 channels whose bursts end inside the same block: the burst-decoder queue takes them all at once."""
     fs, cf = 1_000_000, 10_000_000
