@@ -408,6 +408,12 @@ def alg_bytes_per_block(g):
     return 8 * g.input_size + g.channels * 8 * g.fft_size + g.channels * 8 * (g.post_input_size // g.post_decimation)
 
 
+def alg_bytes_per_launch(g, nb):
+    """The same model per FOLD LAUNCH when a launch serves `nb` queued blocks with one pass over the filter taps:
+    nb blocks of input, the C*N taps ONCE, nb blocks of channel outputs.  nb = 1 gives alg_bytes_per_block."""
+    return 8 * nb * g.input_size + g.channels * 8 * g.fft_size + g.channels * 8 * nb * (g.post_input_size // g.post_decimation)
+
+
 class stdout_to_stderr:
     """Anything the communication libraries print to file descriptor 1 while they come up (RCCL's version banner, gloo's connection
     report) goes to stderr instead: rank 0's stdout carries ONE JSON line and nothing else."""
@@ -526,6 +532,7 @@ def cfg2_leg(torch, hf, F, dev_index, steps=256, warmup=8):
     el, raw, step = timed_blocks(torch, fe, push, steps, step, nblocks)
     pdus = [p for buf, n in raw for p in fe.pdus_to_dicts(buf, n)]
     fold_ms, fold_n = fe.fold_time_ms()
+    fold_blk = fe.fold_blocks()
     dm_ms, dm_n, dm_blk = fe.demod_time_ms()
     period = fe.step_period_ms()
     fe.reset_timers(False)
@@ -533,12 +540,13 @@ def cfg2_leg(torch, hf, F, dev_index, steps=256, warmup=8):
     fe.close()
     del dev
     hf.host_free(hbuf)
-    ab = alg_bytes_per_block(g)
+    nb = (fold_blk / fold_n) if fold_n else 1.0
+    ab = alg_bytes_per_launch(g, nb) / nb          # per block, the taps shared by the blocks of a launch
     return dict(workload=w["name"], value=steps * g.input_size / el / 1e6, unit="Msamples/s", steps=steps, warmup=warmup, ms_per_step=el / steps * 1e3,
                 steady_state_ms_per_step=period, block_samples=g.input_size, channels=g.channels,
                 demod_kernel_ms_per_block=(dm_ms / dm_blk) if dm_blk else None, demod_kernel_launches=dm_n, demod_blocks_per_launch=g.demod_batch,
-                fold_kernel_avg_ms=(fold_ms / fold_n) if fold_n else None,
-                algorithmic_bytes_per_block=ab,
+                fold_kernel_avg_ms=(fold_ms / fold_n) if fold_n else None, fold_blocks_per_launch=nb,
+                algorithmic_bytes_per_block=ab, algorithmic_bytes_per_block_unbatched=alg_bytes_per_block(g),
                 whole_step_frac_of_hbm_peak=(ab / (period * 1e-3) / 1e9 / HBM_PEAK_GBS) if period else None,
                 bound="demod_kernel: a serial recurrence per channel (latency), not HBM",
                 pdus=len(pdus), pdus_matching_sent_payload=sum(1 for p in pdus if matches_sent(p, by_freq)),
@@ -638,6 +646,7 @@ def main():
     pdus = [p for buf, n in raw for p in fe.pdus_to_dicts(buf, n)]     # Python-side unpacking for the checks below: not part of the path
     npdus = len(pdus)
     fold_ms, fold_n = fe.fold_time_ms()
+    fold_blk = fe.fold_blocks()
     dm_ms, dm_n, dm_blk = fe.demod_time_ms()
     period_ms = fe.step_period_ms()
     barrier()
@@ -669,7 +678,11 @@ def main():
         extra["fec"] = fec_capacity(hf, dev_index)
     geom = dict(channels=g.channels, fft_size=g.fft_size, fft_inv_size=g.fft_inv_size, input_size=g.input_size)
     demod_batch = g.demod_batch
-    alg_bytes = alg_bytes_per_block(g)
+    fold_nb = (fold_blk / fold_n) if fold_n else 1.0           # blocks per fold launch in the timed region (geometry.fold_batch when every half was full)
+    alg_bytes = alg_bytes_per_launch(g, fold_nb)
+    alg_bytes_block = alg_bytes / fold_nb
+    alg_bytes_unbatched = alg_bytes_per_block(g)
+    fold_batch = g.fold_batch
     # every rank releases its front end (16 GiB of filter taps each) before the legs that build others / before leaving
     fe.close()
     del dev
@@ -721,10 +734,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fold_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n,
-                         "literal_bytes_per_launch": 16 * geom["fft_size"] * (geom["channels"] + 1),      # SURVEY 8(d) secondary figure
+                         "blocks_per_launch": fold_nb, "fold_batch": fold_batch,
+                         "model": "8*NB*input_size + C*8*N + C*8*NB*outputs_per_block per launch: NB queued blocks share ONE pass over the C*N filter "
+                                  "taps (NB = blocks_per_launch; NB = 1 is SURVEY.md 8(d)'s per-block figure, algorithmic_bytes_per_block_unbatched)",
+                         "algorithmic_bytes_per_block": alg_bytes_block, "algorithmic_bytes_per_block_unbatched": alg_bytes_unbatched,
+                         "literal_bytes_per_launch": 16 * geom["fft_size"] * (geom["channels"] + fold_nb),      # SURVEY 8(d) secondary figure, NB spectra
                          "stream_read_GBs": stream_gbs,
                          "frac_of_stream_read": (achieved / stream_gbs) if (achieved and stream_gbs) else None,
-                         "whole_step_frac": (alg_bytes / (period_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if period_ms else None},
+                         "whole_step_frac": (alg_bytes_block / (period_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if period_ms else None},
             "setup_s": {"frontend_create": round(t_create, 2), "input_synthesis": round(t_gen, 2)},
         }
         out.update(extra)

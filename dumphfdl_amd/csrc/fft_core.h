@@ -100,12 +100,28 @@ __device__ __forceinline__ int nco_output_count(const NcoState &st, int input_si
 	return st.decimation_remain < input_size ? (input_size - st.decimation_remain + q - 1) / q : 0;
 }
 
-// segment `job.seg` of the phasor table, lanes over channels: thread = channel
+// carried state after a block of `cnt` outputs (src/libcsdr_gpl.c:67-72): remainder of the decimation stride, phase advanced in
+// double and wrapped to (-pi, pi], stored as float
+__device__ __forceinline__ void nco_advance(NcoState &st, int cnt, int q, int input_size, float rate)
+{
+	const int last = st.decimation_remain + q * cnt;
+	st.decimation_remain = last - input_size;
+	const double phase = (double)st.starting_phase + (double)rate * M_PI * (double)cnt;
+	float fp = (float)phase;
+	while ((double)fp > M_PI) fp = (float)((double)fp - 2 * M_PI);
+	while ((double)fp < -M_PI) fp = (float)((double)fp + 2 * M_PI);
+	st.starting_phase = fp;
+	st.output_size = cnt;
+}
+
+// segment `job.seg` of the phasor table, lanes over channels: thread = channel.  Segment 0 snapshots the carried state for the
+// block's inverse-FFT kernel, the last segment advances it for the next block (kernels.h NcoJob).
 __device__ __forceinline__ void nco_table_segment(const NcoJob &job, int c)
 {
 	if (c >= job.nch) return;
 	const ChanConst k = job.cc[c];
-	const NcoState st = job.nco[c];
+	NcoState st = job.chain[c];
+	if (job.seg == 0) job.snap[c] = st;
 	const int cnt = nco_output_count(st, job.post_input_size, job.post);
 	const int per = (job.outs + job.nseg - 1) / job.nseg;
 	const int i0 = job.seg * per, i1 = (job.seg + 1) * per < cnt ? (job.seg + 1) * per : cnt;
@@ -116,6 +132,10 @@ __device__ __forceinline__ void nco_table_segment(const NcoJob &job, int c)
 		nco_phasor_step(p.x, p.y, k.nco_cosdelta, k.nco_sindelta);
 	}
 	job.cont[c] = p;
+	if (job.seg == job.nseg - 1) {
+		nco_advance(st, cnt, job.post, job.post_input_size, k.nco_rate);
+		job.chain[c] = st;
+	}
 }
 
 }  // namespace hfdl

@@ -27,11 +27,26 @@ __device__ __forceinline__ float4 load_stream(const float4 *p)
 	return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// U float4 (= 2U bins) per thread per alias row; NT = non-temporal tap loads; R = alias rows per loop trip;
-// CS = column split: a workgroup covers 1/CS of a row; NC = channels per workgroup sharing every spectrum load
-template <int U, bool NT, int R, int CS, int NC>
+// One complex multiply-accumulate per bin, spelled out as FMAs in a FIXED order so that every instantiation below -- any
+// (U, CS, NC, NB) -- rounds a (block, channel, bin) sum exactly alike: a block folded alone and the same block folded beside three
+// others give the same 32 bits (tests/test_gpu_parity.py::test_fold_batching_changes_nothing).
+__device__ __forceinline__ void cmac2(float4 &a, const float4 h, const float4 x)
+{
+	a.x = __builtin_fmaf(h.x, x.x, a.x); a.x = __builtin_fmaf(-h.y, x.y, a.x);
+	a.y = __builtin_fmaf(h.x, x.y, a.y); a.y = __builtin_fmaf(h.y, x.x, a.y);
+	a.z = __builtin_fmaf(h.z, x.z, a.z); a.z = __builtin_fmaf(-h.w, x.w, a.z);
+	a.w = __builtin_fmaf(h.z, x.w, a.w); a.w = __builtin_fmaf(h.w, x.z, a.w);
+}
+
+// U float4 (= 2U bins) per thread per alias row; R = alias rows per loop trip; CS = column split: a workgroup covers 1/CS of a
+// row; NC = channels per workgroup sharing every spectrum load; NB = BLOCKS per launch sharing every tap load: the spectra of NB
+// consecutive blocks (`spec_stride4` apart) are folded against ONE pass over the taps -- the taps are 99.9 % of a block's bytes and
+// identical from block to block, so when blocks are queued (replay, catch-up, the bench) a launch serves NB of them for the HBM
+// traffic of one (src/fastddc.c:123-150 run NB times).  Register tile: acc[NB][NC][U], an NB x NC outer product per column.
+template <int U, int R, int CS, int NC, int NB>
 __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__restrict__ taps, const float4 *__restrict__ spec,
-		float4 *__restrict__ partial, size_t chan_stride4, size_t row_stride4, int m, int slices, int rows, int c_base)
+		float4 *__restrict__ partial, size_t chan_stride4, size_t row_stride4, size_t spec_stride4, size_t partial_stride4,
+		int m, int slices, int rows, int c_base)
 {
 	const int cpart = blockIdx.x % CS;
 	const int bs = blockIdx.x / CS;
@@ -40,50 +55,48 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__rest
 	const size_t col = (size_t)cpart * U * FOLD_THREADS + threadIdx.x;
 	const float4 *tp = taps + (size_t)c0 * chan_stride4 + (size_t)s * rows * row_stride4 + col;
 	const float4 *sp = spec + (((size_t)s * rows * (size_t)m) >> 1) + col;
-	const size_t cstride = chan_stride4;                      // float4 between consecutive channels' taps
-	float4 acc[NC][U];
+	float4 acc[NB][NC][U];
 #pragma unroll
-	for (int k = 0; k < NC; k++)
+	for (int b = 0; b < NB; b++)
 #pragma unroll
-		for (int u = 0; u < U; u++) acc[k][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+		for (int k = 0; k < NC; k++)
+#pragma unroll
+			for (int u = 0; u < U; u++) acc[b][k][u] = make_float4(0.f, 0.f, 0.f, 0.f);
 	const bool live = (U * CS > 1) || ((int)threadIdx.x < row4);
 	if (live) {
 		for (int r = 0; r < rows; r += R) {
-			float4 h[NC][R][U], x[R][U];
+			float4 h[NC][R][U], x[NB][R][U];
 #pragma unroll
 			for (int q = 0; q < R; q++) {
 #pragma unroll
 				for (int u = 0; u < U; u++) {
 #pragma unroll
-					for (int k = 0; k < NC; k++) {
-						const float4 *p = tp + (size_t)k * cstride + (size_t)q * row_stride4 + u * FOLD_THREADS;
-						h[k][q][u] = NT ? load_stream(p) : *p;
-					}
-					x[q][u] = sp[(size_t)q * row4 + u * FOLD_THREADS];
+					for (int k = 0; k < NC; k++)
+						h[k][q][u] = load_stream(tp + (size_t)k * chan_stride4 + (size_t)q * row_stride4 + u * FOLD_THREADS);
+#pragma unroll
+					for (int b = 0; b < NB; b++)
+						x[b][q][u] = sp[(size_t)b * spec_stride4 + (size_t)q * row4 + u * FOLD_THREADS];
 				}
 			}
 #pragma unroll
-			for (int k = 0; k < NC; k++) {
+			for (int q = 0; q < R; q++)       // rows strictly in order: the sum over a slice's rows is the same chain in every variant
 #pragma unroll
-				for (int q = 0; q < R; q++) {
+				for (int b = 0; b < NB; b++)
 #pragma unroll
-					for (int u = 0; u < U; u++) {
-						acc[k][u].x += h[k][q][u].x * x[q][u].x - h[k][q][u].y * x[q][u].y;
-						acc[k][u].y += h[k][q][u].x * x[q][u].y + h[k][q][u].y * x[q][u].x;
-						acc[k][u].z += h[k][q][u].z * x[q][u].z - h[k][q][u].w * x[q][u].w;
-						acc[k][u].w += h[k][q][u].z * x[q][u].w + h[k][q][u].w * x[q][u].z;
-					}
-				}
-			}
+					for (int k = 0; k < NC; k++)
+#pragma unroll
+						for (int u = 0; u < U; u++) cmac2(acc[b][k][u], h[k][q][u], x[b][q][u]);
 			tp += (size_t)R * row_stride4;
 			sp += (size_t)R * row4;
 		}
 #pragma unroll
-		for (int k = 0; k < NC; k++) {
-			float4 *po = partial + (((size_t)(c0 + k) * slices + s) * (size_t)m >> 1) + (size_t)cpart * U * FOLD_THREADS + threadIdx.x;
+		for (int b = 0; b < NB; b++)
 #pragma unroll
-			for (int u = 0; u < U; u++) po[u * FOLD_THREADS] = acc[k][u];
-		}
+			for (int k = 0; k < NC; k++) {
+				float4 *po = partial + (size_t)b * partial_stride4 + (((size_t)(c0 + k) * slices + s) * (size_t)m >> 1) + (size_t)cpart * U * FOLD_THREADS + threadIdx.x;
+#pragma unroll
+				for (int u = 0; u < U; u++) po[u * FOLD_THREADS] = acc[b][k][u];
+			}
 	}
 }
 
@@ -122,7 +135,7 @@ void launch_stream_read(int variant, const float2 *src, size_t bytes, float *sin
 	}
 }
 
-// generic fallback for row sizes that are not 512*2^k bins
+// generic fallback for row sizes that are not 512*2^k bins (same FMA chain per bin; one block per launch)
 __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel_generic(const float2 *__restrict__ taps, const float2 *__restrict__ spec,
 		float2 *__restrict__ partial, size_t chan_stride, size_t row_stride, int m, int slices, int rows)
 {
@@ -133,43 +146,138 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel_generic(const float2
 		float2 acc = make_float2(0.f, 0.f);
 		for (int r = 0; r < rows; r++) {
 			float2 h = tp[(size_t)r * row_stride], x = sp[(size_t)r * m];
-			acc.x += h.x * x.x - h.y * x.y;
-			acc.y += h.x * x.y + h.y * x.x;
+			acc.x = __builtin_fmaf(h.x, x.x, acc.x); acc.x = __builtin_fmaf(-h.y, x.y, acc.x);
+			acc.y = __builtin_fmaf(h.x, x.y, acc.y); acc.y = __builtin_fmaf(h.y, x.x, acc.y);
 		}
 		partial[((size_t)c * slices + s) * (size_t)m + j] = acc;
 	}
 }
 
-void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st,
-		hipEvent_t start, hipEvent_t stop)
+// ---- the compiled register tilings ----
+struct FoldArgs {
+	const float4 *taps, *spec;
+	float4 *partial;
+	size_t cs4, rs4, ss4, ps4;
+	int m, slices, rows, nch;
+	hipStream_t st;
+	hipEvent_t start, stop;
+};
+
+// channel groups of NC first; the nch % NC channels left over get single-channel workgroups in a launch of their own
+template <int U, int R, int CS, int NC, int NB>
+static int fold_go(const FoldArgs &a)
 {
 	const dim3 block(FOLD_THREADS);
-	const size_t cs4 = (size_t)g.tap_chan_stride >> 1, rs4 = (size_t)g.tap_row_stride >> 1;     // in float4
-	const int u = g.m / (2 * FOLD_THREADS);
-	const int pairs = g.nch / 2, odd = g.nch & 1;
-	// channel pairs first; an odd last channel gets its own single-channel launch
-#define FOLD_LAUNCH(U, CS, NC, GROUPS) do { \
-	if ((GROUPS) > 0) hipExtLaunchKernelGGL((fold_kernel<U, true, 1, CS, NC>), dim3((unsigned)((GROUPS) * g.slices * CS)), block, 0, st, \
-		start, odd ? nullptr : stop, 0, \
-		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, cs4, rs4, g.m, g.slices, g.rows_per_slice, 0); \
-	if (odd) hipExtLaunchKernelGGL((fold_kernel<U, true, 1, CS, 1>), dim3((unsigned)(g.slices * CS)), block, 0, st, \
-		(GROUPS) > 0 ? nullptr : start, stop, 0, \
-		(const float4 *)taps, (const float4 *)spectrum, (float4 *)partial, cs4, rs4, g.m, g.slices, g.rows_per_slice, g.nch - 1); } while (0)
-	// Variants measured on cfg3 (profiles/r01_experiments.md).  What pays: non-temporal tap loads (+7 %) and TWO channels per
-	// workgroup sharing every spectrum load (+14 %: halves the L2->L1 spectrum traffic, which equals the HBM tap traffic
-	// when each channel re-reads the spectrum).  A workgroup = (channel pair, slice, half of the columns).
-	if (g.m == 2 * FOLD_THREADS * u && u >= 1) {
-		switch (u) {
-		case 1: FOLD_LAUNCH(1, 1, 2, pairs); return;
-		case 2: FOLD_LAUNCH(1, 2, 2, pairs); return;
-		case 4: FOLD_LAUNCH(2, 2, 2, pairs); return;
-		case 8: FOLD_LAUNCH(4, 2, 2, pairs); return;
-		case 16: FOLD_LAUNCH(8, 2, 2, pairs); return;
-		default: break;
-		}
+	const int groups = a.nch / NC, rest = a.nch - groups * NC;
+	int launches = 0;
+	if (groups > 0) {
+		hipExtLaunchKernelGGL((fold_kernel<U, R, CS, NC, NB>), dim3((unsigned)(groups * a.slices * CS)), block, 0, a.st, a.start, rest ? nullptr : a.stop, 0,
+			a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, 0);
+		launches++;
 	}
-	hipExtLaunchKernelGGL(fold_kernel_generic, dim3((unsigned)(g.nch * g.slices)), block, 0, st, start, stop, 0, taps, spectrum, partial, (size_t)g.tap_chan_stride, (size_t)g.tap_row_stride, g.m, g.slices, g.rows_per_slice);
-#undef FOLD_LAUNCH
+	if (rest > 0) {
+		hipExtLaunchKernelGGL((fold_kernel<U, R, CS, 1, NB>), dim3((unsigned)(rest * a.slices * CS)), block, 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+			a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, groups * NC);
+		launches++;
+	}
+	return launches;
+}
+
+struct FoldVariant { int u, r, cs, nc, nb; int (*go)(const FoldArgs &); };
+#define FV(U, R, CS, NC, NB) { U, R, CS, NC, NB, fold_go<U, R, CS, NC, NB> }
+// A row of M bins = U * CS * 512.  Measured on cfg3 (M = 4096) with profiles/fold_variants.py: profiles/r04_fold_variants.md.
+// What paid at one block per launch (profiles/r01_experiments.md): non-temporal tap loads (+7 %) and TWO channels per workgroup
+// sharing every spectrum load (+14 %: halves the L2 -> L1 spectrum traffic).  With NB blocks per launch the spectrum traffic is
+// NB / NC times the tap traffic, so the tile trades registers between the two (acc = 4 * NB * NC * U VGPRs).
+static const FoldVariant fold_variants[] = {
+	// M = 512 .. 8192 at one block per launch: the round-1 tilings
+	FV(1, 1, 1, 2, 1), FV(1, 1, 2, 2, 1), FV(2, 1, 2, 2, 1), FV(4, 1, 2, 2, 1), FV(8, 1, 2, 2, 1),
+	// two blocks
+	FV(1, 1, 1, 2, 2), FV(1, 1, 2, 2, 2), FV(2, 1, 2, 2, 2), FV(4, 1, 2, 2, 2), FV(2, 2, 4, 2, 2), FV(2, 1, 4, 4, 2), FV(4, 1, 4, 2, 2),
+	// four blocks
+	FV(1, 1, 1, 2, 4), FV(1, 1, 2, 2, 4), FV(2, 1, 2, 2, 4), FV(2, 1, 4, 2, 4), FV(1, 2, 8, 2, 4), FV(1, 1, 8, 4, 4), FV(1, 2, 8, 4, 4),
+	FV(4, 1, 2, 1, 4), FV(2, 2, 4, 1, 4), FV(2, 1, 4, 4, 4), FV(4, 1, 2, 2, 4), FV(1, 1, 8, 2, 4), FV(2, 1, 8, 2, 4),
+	// eight blocks
+	FV(1, 1, 1, 2, 8), FV(1, 1, 2, 2, 8), FV(1, 1, 4, 2, 8), FV(1, 1, 8, 2, 8), FV(1, 1, 8, 4, 8), FV(2, 1, 4, 1, 8), FV(2, 1, 4, 2, 8), FV(2, 1, 8, 2, 8), FV(1, 1, 16, 2, 8),
+};
+#undef FV
+constexpr int N_FOLD_VARIANTS = (int)(sizeof(fold_variants) / sizeof(fold_variants[0]));
+
+int fold_variant_count() { return N_FOLD_VARIANTS; }
+
+int fold_variant_describe(int v, int desc[5])
+{
+	if (v < 0 || v >= N_FOLD_VARIANTS) return -1;
+	const FoldVariant &f = fold_variants[v];
+	desc[0] = f.u; desc[1] = f.r; desc[2] = f.cs; desc[3] = f.nc; desc[4] = f.nb;
+	return 0;
+}
+
+static bool variant_fits(const FoldVariant &f, const Geometry &g)
+{
+	return g.m == 2 * FOLD_THREADS * f.u * f.cs && g.rows_per_slice % f.r == 0;
+}
+
+// the tiling used for `nb` blocks of this geometry: the first entry of the preference list that fits (HFDL_GPU_FOLD_TILE =
+// "U,R,CS,NC" overrides it for A/B measurements when such a variant is compiled)
+static const FoldVariant *pick_variant(const Geometry &g, int nb)
+{
+	static int want[4] = { 0, 0, 0, 0 };
+	static bool parsed = false;
+	if (!parsed) {
+		parsed = true;
+		if (const char *e = getenv("HFDL_GPU_FOLD_TILE"))
+			if (sscanf(e, "%d,%d,%d,%d", &want[0], &want[1], &want[2], &want[3]) != 4) want[0] = 0;
+	}
+	if (want[0])
+		for (const FoldVariant &f : fold_variants)
+			if (f.nb == nb && f.u == want[0] && f.r == want[1] && f.cs == want[2] && f.nc == want[3] && variant_fits(f, g)) return &f;
+	for (const FoldVariant &f : fold_variants)
+		if (f.nb == nb && variant_fits(f, g)) return &f;
+	return nullptr;
+}
+
+static FoldArgs fold_args(const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial, size_t partial_stride,
+		hipStream_t st, hipEvent_t start, hipEvent_t stop)
+{
+	FoldArgs a;
+	a.taps = (const float4 *)taps; a.spec = (const float4 *)spectrum; a.partial = (float4 *)partial;
+	a.cs4 = (size_t)g.tap_chan_stride >> 1; a.rs4 = (size_t)g.tap_row_stride >> 1; a.ss4 = spec_stride >> 1; a.ps4 = partial_stride >> 1;
+	a.m = g.m; a.slices = g.slices; a.rows = g.rows_per_slice; a.nch = g.nch;
+	a.st = st; a.start = start; a.stop = stop;
+	return a;
+}
+
+int launch_fold_variant(int v, const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial,
+		size_t partial_stride, hipStream_t st, hipEvent_t start, hipEvent_t stop)
+{
+	if (v < 0 || v >= N_FOLD_VARIANTS || !variant_fits(fold_variants[v], g)) return -1;
+	return fold_variants[v].go(fold_args(g, taps, spectrum, spec_stride, partial, partial_stride, st, start, stop));
+}
+
+int launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial, size_t partial_stride,
+		int nb, int nb_max, hipStream_t st, hipEvent_t start, hipEvent_t stop)
+{
+	int launches = 0;
+	// greedy split into launches of 8 / 4 / 2 / 1 blocks (a ragged batch of 3 = 2 + 1): every block's sums are the same whatever its company
+	for (int done = 0; done < nb;) {
+		int take = 1;
+		const FoldVariant *f = nullptr;
+		for (int t = 8; t >= 1; t >>= 1)
+			if (t <= nb - done && t <= nb_max && (f = pick_variant(g, t)) != nullptr) { take = t; break; }
+		const bool first = done == 0, last = done + take >= nb;
+		const float2 *sp = spectrum + (size_t)done * spec_stride;
+		float2 *pp = partial + (size_t)done * partial_stride;
+		if (f) {
+			launches += f->go(fold_args(g, taps, sp, spec_stride, pp, partial_stride, st, first ? start : nullptr, last ? stop : nullptr));
+		} else {
+			hipExtLaunchKernelGGL(fold_kernel_generic, dim3((unsigned)(g.nch * g.slices)), dim3(FOLD_THREADS), 0, st, first ? start : nullptr, last ? stop : nullptr, 0,
+				taps, sp, pp, (size_t)g.tap_chan_stride, (size_t)g.tap_row_stride, g.m, g.slices, g.rows_per_slice);
+			launches++;
+		}
+		done += take;
+	}
+	return launches;
 }
 
 // ---- inverse FFT + scrap + NCO/decimate : one workgroup per channel, M bins in LDS ----
@@ -199,35 +307,22 @@ __device__ __forceinline__ float2 nco_rotate(float2 p, float2 v)
 	return make_float2(re, im);
 }
 
-// carried state after a block of `cnt` outputs (:67-72): remainder of the decimation stride, phase advanced in double and
-// wrapped to (-pi, pi], stored as float
-__device__ __forceinline__ void nco_advance(NcoState &st, int cnt, int q, int input_size, float rate)
-{
-	const int last = st.decimation_remain + q * cnt;
-	st.decimation_remain = last - input_size;
-	const double phase = (double)st.starting_phase + (double)rate * M_PI * (double)cnt;
-	float fp = (float)phase;
-	while ((double)fp > M_PI) fp = (float)((double)fp - 2 * M_PI);
-	while ((double)fp < -M_PI) fp = (float)((double)fp + 2 * M_PI);
-	st.starting_phase = fp;
-	st.output_size = cnt;
-}
-
-
-__global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__restrict__ partial, const ChanConst *__restrict__ cc,
-		NcoState *__restrict__ nco, const float2 *__restrict__ ph, const float2 *__restrict__ tw, float2 *__restrict__ chan_out, int *__restrict__ out_count,
-		Geometry g, int logm)
+// grid = channels x blocks of the batch; every block has its own partial sums, carried-state snapshot and phasor table (both made
+// by the riders of that block's forward FFT), so the blocks of a batch are independent here
+__global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__restrict__ partial, size_t partial_stride, const ChanConst *__restrict__ cc,
+		const NcoState *__restrict__ snap, const float2 *__restrict__ ph, size_t ph_stride, const float2 *__restrict__ tw, float2 *__restrict__ chan_out,
+		int *__restrict__ out_count, Geometry g, int logm)
 {
 	extern __shared__ float2 sm[];          // m bins
-	const int c = blockIdx.x;
+	const int c = blockIdx.x % g.nch, b = blockIdx.x / g.nch;
 	const ChanConst k = cc[c];
 	const int m = g.m, mask = m - 1;
-	NcoState st = nco[c];
+	const NcoState st = snap[(size_t)b * g.nch + c];
 	const int q = g.post;
 	const int cnt = nco_output_count(st, g.post_input_size, q);
 	{
 		const int h0 = (int)(((long long)g.n - k.offsetbin + m / 2) % m);
-		const float2 *pc = partial + (size_t)c * g.slices * (size_t)m;
+		const float2 *pc = partial + (size_t)b * partial_stride + (size_t)c * g.slices * (size_t)m;
 		for (int u = threadIdx.x; u < m; u += IFFT_THREADS) {
 			const int j = (u - h0 - m / 2) & mask;
 			float2 acc = make_float2(0.f, 0.f);
@@ -242,18 +337,15 @@ __global__ __launch_bounds__(IFFT_THREADS) void ifft_nco_kernel(const float2 *__
 	lds_fft_columns<+1>(sm, m, logm, 1, 0, tw);
 
 	const float norm = (float)g.pre * (float)m;
-	float2 *o = chan_out + (size_t)c * g.outs;
+	float2 *o = chan_out + ((size_t)b * g.nch + c) * g.outs;
+	const float2 *phb = ph + (size_t)b * ph_stride;
 	for (int i = threadIdx.x; i < cnt; i += IFFT_THREADS) {
 		const int idx = g.scrap + st.decimation_remain + q * i;
 		float2 v = sm[(int)(__brev((unsigned)idx) >> (32 - logm))];
 		v.x = __fdiv_rn(v.x, norm); v.y = __fdiv_rn(v.y, norm);
-		o[i] = nco_rotate(ph[(size_t)i * g.nch + c], v);       // the block's phasor table, made beside its forward FFT (kernels.h NcoJob)
+		o[i] = nco_rotate(phb[(size_t)i * g.nch + c], v);       // the block's phasor table, made beside its forward FFT (kernels.h NcoJob)
 	}
-	if (threadIdx.x == 0) {
-		nco_advance(st, cnt, q, g.post_input_size, k.nco_rate);
-		nco[c] = st;
-		out_count[c] = cnt;      // per-buffer copy: the demodulator of this block may run while the next block updates nco[]
-	}
+	if (threadIdx.x == 0) out_count[(size_t)b * g.nch + c] = cnt;      // the carried state itself is advanced by the riders (fft_core.h)
 }
 
 // the NCO / decimator stage on its own (stage entry point hfdl_gpu_nco_decimate): the same device functions the channelizer
@@ -286,13 +378,14 @@ hipError_t prepare_ifft_nco(int m)
 	return hipFuncSetAttribute((const void *)ifft_nco_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco, const float2 *ph,
-		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st, hipEvent_t done)
+void launch_ifft_nco(const Geometry &g, const float2 *partial, size_t partial_stride, const ChanConst *cc, const NcoState *snap, const float2 *ph,
+		size_t ph_stride, const float2 *tw_m, float2 *chan_out, int *out_count, int nb, hipStream_t st, hipEvent_t done)
 {
 	int logm = 0;
 	while ((1 << logm) < g.m) logm++;
 	size_t lds = sizeof(float2) * ((size_t)g.m + 1);
-	hipExtLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)g.nch), dim3(IFFT_THREADS), (unsigned)lds, st, nullptr, done, 0, partial, cc, nco, ph, tw_m, chan_out, out_count, g, logm);
+	hipExtLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)(g.nch * nb)), dim3(IFFT_THREADS), (unsigned)lds, st, nullptr, done, 0, partial, partial_stride, cc, snap, ph, ph_stride,
+			tw_m, chan_out, out_count, g, logm);
 }
 
 }  // namespace hfdl

@@ -115,8 +115,9 @@ struct hfdl_gpu_frontend {
 	hipStream_t stream_b = nullptr;     // B: demodulator (+ burst decoder, unless it has its own stream) of block k-1, concurrent with the fold of block k
 	hipStream_t stream_d = nullptr;     // D: burst decoder + PDU snapshot when the demodulator bounds the block (few channels); else == stream_b
 	bool own_decode_stream = false;
-	hipEvent_t ev_dm[2] = { nullptr, nullptr };      // demodulator kernel of the block in buffer 0 / 1 done (chan_out free; the decoder may start)
-	hipEvent_t ev_dm_cur[2] = { nullptr, nullptr };  // the event that stands for it now: ev_dm[i], or (timing on) the stop event of a timed pair
+	static constexpr int MAX_HALF = 8;  // blocks per half at most
+	hipEvent_t ev_dm[2][MAX_HALF] = {};              // demodulator launch j of the half in buffer 0 / 1 done (the decoder may start)
+	hipEvent_t ev_dm_cur[2] = { nullptr, nullptr };  // LAST demodulator launch of that half done (chan_out free): an ev_dm, or (timing on) the stop event of a timed pair
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_dmt;      // timed demodulator launches not yet read
 	double demod_ms = 0;
 	int64_t demod_launches = 0, demod_timed_blocks = 0;
@@ -137,31 +138,41 @@ struct hfdl_gpu_frontend {
 	std::vector<ChanConst> cc;
 	float2 *d_hist[2] = { nullptr, nullptr }, *d_work = nullptr, *d_spec = nullptr, *d_taps = nullptr, *d_partial = nullptr;
 	float2 *d_tw_m = nullptr, *d_stage[2] = { nullptr, nullptr };
-	// Channelizer output, double-buffered between stream A and stream B in two HALVES of `batch` blocks each: [2][batch][nch][outs].
-	// A demodulator launch takes the blocks of one half (one block when batch == 1) while the channelizer fills the other.
+	// Channelizer output, double-buffered between stream A and stream B in two HALVES of `half_blocks` blocks each:
+	// [2][half_blocks][nch][outs].  The forward FFT of a block is queued when it is pushed; the fold and the inverse FFTs run when a
+	// half is closed (full, or a sync / poll found it part-filled): ONE pass over the filter taps serves up to `fold_nb` blocks.
+	// The demodulator then takes the half `batch` blocks per launch while the channelizer fills the other half.
 	float2 *d_chan_all = nullptr;
-	int *d_cnt_all = nullptr;           // [2][batch][nch] outputs per channel of each block
+	int *d_cnt_all = nullptr;           // [2][half_blocks][nch] outputs per channel of each block
 	int batch = 1;                      // blocks per demodulator launch (see pick_demod_batch)
-	int cur_half = 0, batch_fill = 0;   // the half being filled and the blocks already in it
-	int last_slot = 0;                  // slot (half * batch + index) of the newest block: what HFDL_GPU_TAP_CHAN_OUT reads
+	int fold_nb = 1;                    // blocks per fold launch (see pick_fold_batch)
+	int half_blocks = 1;                // slots per half: a multiple of fold_nb, at least `batch`
+	int cur_half = 0, batch_fill = 0;   // the half being filled and the blocks already in it (forward FFT queued, fold not yet)
+	int last_slot = 0;                  // slot (half * half_blocks + index) of the newest channelized block: what HFDL_GPU_TAP_CHAN_OUT reads
+	int last_index = 0;                 // its index inside the half: spectrum / phasor-table slot of the newest block
 	float2 *chan_slot(int slot) const { return d_chan_all + (size_t)slot * (size_t)geo.nch * (size_t)geo.outs; }
 	int *cnt_slot(int slot) const { return d_cnt_all + (size_t)slot * (size_t)geo.nch; }
+	float2 *spec_slot(int i) const { return d_spec + (size_t)i * (size_t)geo.n; }
+	size_t partial_stride() const { return (size_t)geo.nch * (size_t)geo.slices * (size_t)geo.m; }
+	size_t ph_stride() const { return (size_t)geo.nch * (size_t)geo.outs; }
 	ChanConst *d_cc = nullptr;
-	NcoState *d_nco = nullptr;
-	float2 *d_ph = nullptr, *d_ph_cont = nullptr;      // the block's NCO phasor table [outs][nch] and the riders' segment hand-over [nch]
+	NcoState *d_nco = nullptr;          // [nch] carried NCO state, owned by the forward FFT's rider workgroups (kernels.h NcoJob)
+	NcoState *d_nco_snap = nullptr;     // [half_blocks][nch] the state each block of the half starts from
+	float2 *d_ph = nullptr, *d_ph_cont = nullptr;      // [half_blocks] NCO phasor tables [outs][nch] and the riders' segment hand-over [nch]
 	size_t stage_cap[2] = { 0, 0 };
 	Demod demod;
 	// fold timing
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;      // timing events made by reset_timers(), outside any timed region
+	std::vector<int> ev_blocks;         // blocks folded between each pair of `ev`
 	double fold_ms = 0;
-	int64_t fold_launches = 0;
+	int64_t fold_launches = 0, fold_timed_blocks = 0, fold_last_blocks = 0;
 	hipEvent_t ev_first_fold = nullptr;  // start of the first timed fold since reset_timers: anchor of the steady-state step period
 	double span_ms = 0;                 // first timed fold start -> last timed fold start
 	uint64_t blocks = 0;
 	FftOutLayout tap_layout;
-	int pending_demod_buf = -1;         // half whose demodulator launch is held back until the next forward FFT is queued ...
+	int pending_demod_buf = -1;         // half whose demodulator launches are held back until the next half's forward FFTs are queued ...
 	int pending_demod_nblk = 0;         // ... and the blocks in it
 	bool frames_wait_on_a = false;      // stream A has waited for the frame queue the next demodulator launch reuses
 	hipEvent_t ev_fft = nullptr;
@@ -178,7 +189,8 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamSynchronize(fe->stream_d);
 	if (fe->stream_c) (void)hipStreamSynchronize(fe->stream_c);
 	for (int i = 0; i < 2; i++)
-		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_dm[i], fe->ev_stage_ready[i], fe->ev_stage_free[i], fe->ev_copy[i], fe->ev_copy[i + 2] }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_stage_ready[i], fe->ev_stage_free[i], fe->ev_copy[i], fe->ev_copy[i + 2] }) if (e) (void)hipEventDestroy(e);
+	for (auto &h : fe->ev_dm) for (hipEvent_t e : h) if (e) (void)hipEventDestroy(e);
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	for (auto &e : fe->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	for (auto &e : fe->ev_dmt) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -187,7 +199,7 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	fe->demod.release();
 	fe->fft.release();
 	void *ptrs[] = { fe->d_hist[0], fe->d_hist[1], fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_all, fe->d_tw_m,
-		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_ph, fe->d_ph_cont, fe->d_cnt_all };
+		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_nco_snap, fe->d_ph, fe->d_ph_cont, fe->d_cnt_all };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (fe->stream) (void)hipStreamDestroy(fe->stream);
 	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamDestroy(fe->stream_d);
@@ -228,6 +240,21 @@ static int pick_demod_batch(const hfdl_gpu_frontend *fe)
 	if (const char *e = getenv("HFDL_GPU_DEMOD_BATCH")) {       // A/B measurements; 1 = a launch per block
 		const long v = strtol(e, nullptr, 10);
 		if (v >= 1 && v <= 8) want = (int)v;
+	}
+	return want;
+}
+
+// Blocks per fold launch.  The filter taps are 99.9 % of a block's bytes on the fold-bound geometries (cfg3: 16 GiB of taps against
+// a 64 MiB spectrum) and they are the same for every block: when blocks are pushed faster than they are collected (file replay,
+// catching up, the bench) the spectra of up to `fold_nb` consecutive blocks are folded in ONE pass over the taps
+// (fold_kernels.hip, NB).  Every block's sums are bit-identical to a launch of its own (fixed FMA chain per bin); a caller that polls
+// or syncs after every block (live input) still gets one launch per block: a sync / poll closes the half as it is.
+static int pick_fold_batch()
+{
+	int want = 4;
+	if (const char *e = getenv("HFDL_GPU_FOLD_BATCH")) {        // A/B measurements; 1 = a pass over the taps per block
+		const long v = strtol(e, nullptr, 10);
+		if (v >= 1 && v <= hfdl_gpu_frontend::MAX_HALF) want = (int)v;
 	}
 	return want;
 }
@@ -352,7 +379,7 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_copy[i + 2], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_chan[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_demod[i], hipEventDisableTiming));
-		FE_TRY(hipEventCreateWithFlags(&fe->ev_dm[i], hipEventDisableTiming));
+		for (auto &e : fe->ev_dm[i]) FE_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	}
 	if ((rc = fe->fft.build(pl.n))) { frontend_free(fe); return rc; }
 	const size_t n = (size_t)pl.n;
@@ -361,12 +388,9 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 		FE_TRY(hipMemsetAsync(fe->d_hist[i], 0, sizeof(float2) * (size_t)pl.overlap, fe->stream));   // calloc'ed history, src/fft.c:79
 	}
 	FE_TRY(hipMalloc(&fe->d_work, sizeof(float2) * n));
-	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n));
 	FE_TRY(hipMalloc(&fe->d_taps, sizeof(float2) * n * (size_t)nch));
-	FE_TRY(hipMalloc(&fe->d_partial, sizeof(float2) * (size_t)nch * g.slices * (size_t)g.m));
 	FE_TRY(hipMalloc(&fe->d_nco, sizeof(NcoState) * (size_t)nch));
 	FE_TRY(hipMemsetAsync(fe->d_nco, 0, sizeof(NcoState) * (size_t)nch, fe->stream));
-	FE_TRY(hipMalloc(&fe->d_ph, sizeof(float2) * (size_t)nch * g.outs));
 	FE_TRY(hipMalloc(&fe->d_ph_cont, sizeof(float2) * (size_t)nch));
 	FE_TRY(hipMalloc(&fe->d_cc, sizeof(ChanConst) * (size_t)nch));
 	{
@@ -384,9 +408,16 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	float resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)fe->decimation);
 	if ((rc = fe->demod.init(nch, g.outs, resamp_rate, fe->freqs.data(), fe->stream, pick_demod_batch(fe)))) { frontend_free(fe); return rc; }
 	fe->batch = fe->demod.batch;        // what fits the demodulator's LDS
-	FE_TRY(hipMalloc(&fe->d_chan_all, sizeof(float2) * 2 * (size_t)fe->batch * (size_t)nch * g.outs));
-	FE_TRY(hipMalloc(&fe->d_cnt_all, sizeof(int) * 2 * (size_t)fe->batch * (size_t)nch));
-	FE_TRY(hipMemsetAsync(fe->d_cnt_all, 0, sizeof(int) * 2 * (size_t)fe->batch * (size_t)nch, fe->stream));
+	fe->fold_nb = pick_fold_batch();
+	fe->half_blocks = std::min((int)hfdl_gpu_frontend::MAX_HALF, ((std::max(fe->fold_nb, fe->batch) + fe->fold_nb - 1) / fe->fold_nb) * fe->fold_nb);
+	const size_t hb = (size_t)fe->half_blocks;
+	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n * hb));
+	FE_TRY(hipMalloc(&fe->d_partial, sizeof(float2) * fe->partial_stride() * hb));
+	FE_TRY(hipMalloc(&fe->d_ph, sizeof(float2) * fe->ph_stride() * hb));
+	FE_TRY(hipMalloc(&fe->d_nco_snap, sizeof(NcoState) * (size_t)nch * hb));
+	FE_TRY(hipMalloc(&fe->d_chan_all, sizeof(float2) * 2 * hb * (size_t)nch * g.outs));
+	FE_TRY(hipMalloc(&fe->d_cnt_all, sizeof(int) * 2 * hb * (size_t)nch));
+	FE_TRY(hipMemsetAsync(fe->d_cnt_all, 0, sizeof(int) * 2 * hb * (size_t)nch, fe->stream));
 	FE_TRY(hipStreamSynchronize(fe->stream));
 #undef FE_TRY
 	*out = fe;
@@ -406,6 +437,7 @@ extern "C" int hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_
 	g->max_outputs_per_block = (p.post_input_size + p.post - 1) / p.post;
 	g->channels = fe->geo.nch; g->fold_slices = fe->geo.slices;
 	g->demod_batch = fe->batch;
+	g->fold_batch = fe->fold_nb;
 	g->transition_bw = fe->tbw;
 	g->resamp_rate = (float)(1800 * 3) / ((float)fe->sample_rate / (float)fe->decimation);
 	return 0;
@@ -521,34 +553,39 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 }
 
 // Where the demodulator's 256 single-wave workgroups land decides how much they disturb the fold kernel they run beside.
-// Launched the moment the channelizer of block k is done, they race the next block's forward-FFT workgroups for LDS and
+// Launched the moment the channelizer of a half is done, they race the next blocks' forward-FFT workgroups for LDS and
 // the outcome depends on details as small as the FFT's LDS footprint: measured on MI355X, the same fold kernel took
-// 2.56 ms or 2.87 ms per launch (profiles/r01_experiments.md).  So the launch of demod(k) is held back until the forward
-// FFT of block k+1 has finished: the workgroups then arrive while only the LDS-free fold kernel is resident, spread
-// evenly, and the fold time is the good one every time.  A sync / poll launches a held-back demodulator at once.
+// 2.56 ms or 2.87 ms per launch (profiles/r01_experiments.md).  So the demodulator launches of a half are held back until the
+// forward FFTs of the NEXT half have been queued: the workgroups then arrive while only the LDS-free fold kernel is resident, spread
+// evenly, and the fold time is the good one every time.  A sync / poll launches held-back demodulators at once.
+// A half of `nblk` blocks is demodulated `batch` blocks per launch, each launch followed by its burst decoder.
 static int launch_demod(hfdl_gpu_frontend *fe, int buf, int nblk, bool after_fft)
 {
-	// the forward FFT of the next block follows this block's inverse FFT on stream A, so its event covers ev_chan too
+	// the forward FFTs of the next half follow this half's inverse FFT on stream A, so their event covers ev_chan too
 	if (after_fft) HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_fft, 0));
 	else HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
-	// ev_dm rides on the kernel's dispatch; with the decoder on its own stream the channelizer has already waited for the frame
-	// queue (enqueue_channelizer), so on the demodulator-bound geometries ONE barrier packet separates consecutive demodulators
-	hipEvent_t t_start = nullptr, done = fe->ev_dm[buf];
-	if (fe->timing && !fe->ev_pool.empty()) {
-		// the kernel's own start / stop events (no extra packet): the stop event doubles as this launch's "done" event
-		std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
-		fe->ev_pool.pop_back();
-		t_start = e.first; done = e.second;
-		fe->ev_dmt.push_back(e);
-		fe->demod_timed_blocks += nblk;
+	for (int j0 = 0, l = 0; j0 < nblk; j0 += fe->batch, l++) {
+		const int take = std::min(fe->batch, nblk - j0);
+		// the done event rides on the kernel's dispatch; with the decoder on its own stream the channelizer has already waited for the
+		// frame queue (close_half), so on the demodulator-bound geometries ONE barrier packet separates consecutive demodulators
+		hipEvent_t t_start = nullptr, done = fe->ev_dm[buf][l];
+		if (fe->timing && !fe->ev_pool.empty()) {
+			// the kernel's own start / stop events (no extra packet): the stop event doubles as this launch's "done" event
+			std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
+			fe->ev_pool.pop_back();
+			t_start = e.first; done = e.second;
+			fe->ev_dmt.push_back(e);
+			fe->demod_timed_blocks += take;
+		}
+		fe->ev_dm_cur[buf] = done;           // after the loop: the LAST launch of the half
+		const int slot = buf * fe->half_blocks + j0;
+		int rc = fe->demod.enqueue_demod(fe->chan_slot(slot), fe->cnt_slot(slot), take, fe->stream_b, done, l == 0 && fe->frames_wait_on_a, t_start);
+		if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
+		if (fe->own_decode_stream) HIP_TRY(hipStreamWaitEvent(fe->stream_d, done, 0));
+		rc = fe->demod.enqueue_decode(buf, fe->stream_d);
+		if (rc) return fail(rc, "burst decoder enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 	}
-	fe->ev_dm_cur[buf] = done;
-	int rc = fe->demod.enqueue_demod(fe->chan_slot(buf * fe->batch), fe->cnt_slot(buf * fe->batch), nblk, fe->stream_b, done, fe->frames_wait_on_a, t_start);
 	fe->frames_wait_on_a = false;
-	if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
-	if (fe->own_decode_stream) HIP_TRY(hipStreamWaitEvent(fe->stream_d, done, 0));
-	rc = fe->demod.enqueue_decode(buf, fe->stream_d);
-	if (rc) return fail(rc, "burst decoder enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 	HIP_TRY(hipEventRecord(fe->ev_demod[buf], fe->stream_d));
 	return 0;
 }
@@ -561,45 +598,44 @@ static int flush_pending_demod(hfdl_gpu_frontend *fe, bool after_fft)
 	return launch_demod(fe, buf, nblk, after_fft);
 }
 
-// the half being filled is handed to the demodulator as it is (a full batch, or what a sync / poll finds waiting)
-static int close_batch(hfdl_gpu_frontend *fe, bool launch_now)
-{
-	if (fe->batch_fill == 0) return 0;
-	const int half = fe->cur_half, nblk = fe->batch_fill;
-	fe->cur_half ^= 1;
-	fe->batch_fill = 0;
-	fe->prev_demod_buf = fe->demod_buf;      // what poll_pdus_ready(.., 1) waits for: the launch before the newest one
-	fe->demod_buf = half;
-	if (launch_now) return launch_demod(fe, half, nblk, false);
-	fe->pending_demod_buf = half;
-	fe->pending_demod_nblk = nblk;
-	return 0;
-}
-
-// Stream A runs the channelizer of a block into the next slot of the half being filled; stream B demodulates a half (one block, or
-// `batch` blocks) at a time.  A's inverse FFT may not overwrite a half before the demodulator launch that read it last (two launches
-// ago) is done; B may not start before A has filled what it is given.
-static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx, int *buf_out, bool with_demod)
+// Stream A, when a block is pushed: its forward FFT into the next spectrum slot of the half being filled (the block's NCO phasor
+// table and carried state ride on the three pass launches).  Nothing else happens until the half is closed.
+static int enqueue_fft(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx)
 {
 	const Geometry &g = fe->geo;
-	const int buf = fe->cur_half, slot = fe->cur_half * fe->batch + fe->batch_fill;
+	const int i = fe->batch_fill;
 	// The events other streams (and the bench's fold timer) wait for ride on the kernel dispatches themselves
 	// (hipExtLaunchKernelGGL start / stop events): a separate hipEventRecord is one more barrier packet in the queue, ~5 us
 	// of idle machine each (profiles/r01_experiments.md).
-	const bool pend = fe->pending_demod_buf >= 0;
+	const bool pend = fe->pending_demod_buf >= 0 && i + 1 == fe->half_blocks;      // the last forward FFT of this half: held-back demodulators follow it
 	if (pend && !fe->ev_fft) HIP_TRY(hipEventCreateWithFlags(&fe->ev_fft, hipEventDisableTiming));
-	// the block's NCO phasor table rides on the three FFT pass launches (the carried NcoState is final: the previous block's
-	// inverse-FFT kernel precedes them on this stream)
 	NcoJob job;
-	job.cc = fe->d_cc; job.nco = fe->d_nco; job.ph = fe->d_ph; job.cont = fe->d_ph_cont;
+	job.cc = fe->d_cc; job.chain = fe->d_nco; job.snap = fe->d_nco_snap + (size_t)i * (size_t)g.nch;
+	job.ph = fe->d_ph + (size_t)i * fe->ph_stride(); job.cont = fe->d_ph_cont;
 	job.nch = g.nch; job.outs = g.outs; job.post_input_size = g.post_input_size; job.post = g.post;
-	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->d_spec, true, fe->stream,
+	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->spec_slot(i), true, fe->stream,
 			FftOutLayout(), pend ? fe->ev_fft : nullptr, job);
 	if (pend) {
 		int rc = flush_pending_demod(fe, true);
 		if (rc) return rc;
 	}
 	if (stage_idx >= 0) HIP_TRY(hipEventRecord(fe->ev_stage_free[stage_idx], fe->stream));   // input consumed: the copy stream may refill it
+	HIP_TRY(hipGetLastError());
+	fe->blocks++;
+	fe->batch_fill++;
+	return 0;
+}
+
+// Stream A, when a half is closed (full, or as a sync / poll finds it): ONE pass over the filter taps per `fold_nb` spectra, then the
+// inverse FFT / NCO of every block of the half in one launch.  A's inverse FFT may not overwrite a half before the demodulator
+// launches that read it last (two halves ago) are done; B may not start before A has filled what it is given.
+// with_demod: hand the half to the demodulator (now, or held back until the next half's forward FFTs are queued).
+static int close_half(hfdl_gpu_frontend *fe, bool launch_now, bool with_demod = true)
+{
+	const int nblk = fe->batch_fill;
+	if (nblk == 0) return 0;
+	const Geometry &g = fe->geo;
+	const int half = fe->cur_half;
 	if (fe->timing) {
 		std::pair<hipEvent_t, hipEvent_t> e;
 		if (!fe->ev_pool.empty()) {                 // made by reset_timers(): no event creation between the timed launches
@@ -609,27 +645,35 @@ static int enqueue_channelizer(hfdl_gpu_frontend *fe, const void *fresh, int fmt
 			HIP_TRY(hipEventCreate(&e.first));
 			HIP_TRY(hipEventCreate(&e.second));
 		}
-		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream, e.first, e.second);
+		launch_fold(g, fe->d_taps, fe->d_spec, (size_t)g.n, fe->d_partial, fe->partial_stride(), nblk, fe->fold_nb, fe->stream, e.first, e.second);
 		fe->ev.push_back(e);
+		fe->ev_blocks.push_back(nblk);
 	} else {
-		launch_fold(g, fe->d_taps, fe->d_spec, fe->d_partial, fe->stream);
+		launch_fold(g, fe->d_taps, fe->d_spec, (size_t)g.n, fe->d_partial, fe->partial_stride(), nblk, fe->fold_nb, fe->stream);
 	}
-	// this half is free once the demodulator launch that read it last (two launches ago) is done; the first block of a batch waits
-	if (fe->batch_fill == 0 && fe->ev_dm_cur[buf]) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm_cur[buf], 0));
-	if (with_demod && fe->own_decode_stream && fe->batch_fill == 0) {
-		// this block's demodulator (launched right after this kernel, on stream B) reuses the frame queue the decoder of two
+	// this half is free once the demodulator launches that read it last (two halves ago) are done
+	if (fe->ev_dm_cur[half]) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm_cur[half], 0));
+	if (with_demod && fe->own_decode_stream) {
+		// this half's first demodulator (launched right after this kernel, on stream B) reuses the frame queue the decoder of two
 		// launches ago read: wait for it HERE, where the stream has slack, instead of in front of the demodulator
 		hipEvent_t e = fe->demod.frames_free_event();
 		if (e) HIP_TRY(hipStreamWaitEvent(fe->stream, e, 0));
 		fe->frames_wait_on_a = true;
 	}
-	// ev_chan[half] is re-recorded by every block of the batch: when the demodulator is launched it stands for the last one
-	launch_ifft_nco(g, fe->d_partial, fe->d_cc, fe->d_nco, fe->d_ph, fe->d_tw_m, fe->chan_slot(slot), fe->cnt_slot(slot), fe->stream, fe->ev_chan[buf]);
+	const int slot0 = half * fe->half_blocks;
+	launch_ifft_nco(g, fe->d_partial, fe->partial_stride(), fe->d_cc, fe->d_nco_snap, fe->d_ph, fe->ph_stride(), fe->d_tw_m,
+			fe->chan_slot(slot0), fe->cnt_slot(slot0), nblk, fe->stream, fe->ev_chan[half]);
 	HIP_TRY(hipGetLastError());
-	fe->blocks++;
-	fe->last_slot = slot;
-	fe->batch_fill++;
-	if (buf_out) *buf_out = buf;
+	fe->last_slot = slot0 + nblk - 1;
+	fe->last_index = nblk - 1;
+	fe->cur_half ^= 1;
+	fe->batch_fill = 0;
+	if (!with_demod) return 0;                   // channelize-only: the half is simply left behind
+	fe->prev_demod_buf = fe->demod_buf;          // what poll_pdus_ready(.., 1) waits for: the half before the newest one
+	fe->demod_buf = half;
+	if (launch_now) return launch_demod(fe, half, nblk, false);
+	fe->pending_demod_buf = half;
+	fe->pending_demod_nblk = nblk;
 	return 0;
 }
 
@@ -639,25 +683,24 @@ extern "C" int hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const f
 	int sidx = -1;
 	int rc = stage_input(fe, iq, nsamples, SFMT_CF32, on_device, &fresh, &sidx);
 	if (rc) return rc;
-	if ((rc = close_batch(fe, true))) return rc;            // blocks pushed for the demodulator and not yet handed to it
-	if ((rc = enqueue_channelizer(fe, fresh, SFMT_CF32, sidx, nullptr, false))) return rc;
-	fe->cur_half ^= 1;                                      // this block is never demodulated: its half is simply left behind
-	fe->batch_fill = 0;
-	return 0;
+	if ((rc = flush_pending_demod(fe, false))) return rc;
+	if ((rc = close_half(fe, true))) return rc;             // blocks pushed for the demodulator and not yet handed to it
+	if ((rc = enqueue_fft(fe, fresh, SFMT_CF32, sidx))) return rc;
+	return close_half(fe, false, false);                    // this block is never demodulated
 }
 
 static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int fmt, int on_device)
 {
 	const void *fresh = nullptr;
-	int buf = 0, sidx = -1;
+	int sidx = -1;
 	int rc = stage_input(fe, raw, nsamples, fmt, on_device, &fresh, &sidx);
 	if (rc) return rc;
-	if ((rc = enqueue_channelizer(fe, fresh, fmt, sidx, &buf, true))) return rc;
-	if (fe->batch_fill < fe->batch) return 0;               // the batch is still filling (demodulator-bound geometries)
+	if ((rc = enqueue_fft(fe, fresh, fmt, sidx))) return rc;
+	if (fe->batch_fill < fe->half_blocks) return 0;         // the half is still filling
 	// demodulator-bound geometry (few channels): the fold is short, there is nothing to place the demodulator under, and
-	// holding it back until the NEXT block's forward FFT would put that block's host -> device copy on the demodulator's
+	// holding it back until the NEXT half's forward FFTs would put those blocks' host -> device copies on the demodulator's
 	// critical path (cfg2 fed from host memory: 0.56 -> 0.33 ms per block): launched at once.  Otherwise held back (launch_demod).
-	return close_batch(fe, fe->own_decode_stream);
+	return close_half(fe, fe->own_decode_stream);
 }
 
 extern "C" int hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
@@ -672,11 +715,14 @@ extern "C" int hfdl_gpu_frontend_push_block_raw(hfdl_gpu_frontend *fe, const voi
 
 static int drain_events(hfdl_gpu_frontend *fe)
 {
-	for (auto &e : fe->ev) {
+	for (size_t i = 0; i < fe->ev.size(); i++) {
+		auto &e = fe->ev[i];
 		float ms = 0;
 		HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
 		fe->fold_ms += ms;
 		fe->fold_launches++;
+		fe->fold_timed_blocks += fe->ev_blocks[i];
+		fe->fold_last_blocks = fe->ev_blocks[i];
 		if (!fe->ev_first_fold) {
 			fe->ev_first_fold = e.first;            // kept until the next reset
 			HIP_TRY(hipEventCreate(&e.first));
@@ -687,6 +733,7 @@ static int drain_events(hfdl_gpu_frontend *fe)
 		fe->ev_pool.push_back(e);                   // both events are complete: reused by later launches
 	}
 	fe->ev.clear();
+	fe->ev_blocks.clear();
 	for (auto &e : fe->ev_dmt) {
 		float ms = 0;
 		HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
@@ -695,7 +742,8 @@ static int drain_events(hfdl_gpu_frontend *fe)
 		fe->ev_pool.push_back(e);
 	}
 	fe->ev_dmt.clear();
-	fe->ev_dm_cur[0] = fe->ev_dm[0]; fe->ev_dm_cur[1] = fe->ev_dm[1];      // everything is complete: the pooled events may be reused
+	// everything is complete: the pooled events may be reused (a completed event stands for "done" as well as the half's own)
+	for (int i = 0; i < 2; i++) if (fe->ev_dm_cur[i]) fe->ev_dm_cur[i] = fe->ev_dm[i][0];
 	return 0;
 }
 
@@ -704,7 +752,7 @@ extern "C" int hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe)
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	HIP_TRY(hipSetDevice(fe->device));
 	{ int rc = flush_pending_demod(fe, false); if (rc) return rc; }
-	{ int rc = close_batch(fe, true); if (rc) return rc; }          // blocks waiting for their batch to fill: demodulated now
+	{ int rc = close_half(fe, true); if (rc) return rc; }           // blocks waiting for their half to fill: folded and demodulated now
 	HIP_TRY(hipStreamSynchronize(fe->stream_c));
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipStreamSynchronize(fe->stream_b));
@@ -769,7 +817,7 @@ extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
-	fe->fold_ms = 0; fe->fold_launches = 0; fe->timing = enable != 0;
+	fe->fold_ms = 0; fe->fold_launches = 0; fe->fold_timed_blocks = 0; fe->fold_last_blocks = 0; fe->timing = enable != 0;
 	fe->demod_ms = 0; fe->demod_launches = 0; fe->demod_timed_blocks = 0;
 	if (fe->ev_first_fold) { (void)hipEventDestroy(fe->ev_first_fold); fe->ev_first_fold = nullptr; }
 	fe->span_ms = 0;
@@ -825,6 +873,66 @@ extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *tot
 	return 0;
 }
 
+extern "C" int hfdl_gpu_frontend_fold_blocks(hfdl_gpu_frontend *fe, int64_t *blocks)
+{
+	if (!fe || !blocks) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	*blocks = fe->fold_timed_blocks;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_fold_variant_count(void) { return fold_variant_count(); }
+
+extern "C" int hfdl_gpu_fold_variant_describe(int variant, int32_t desc[5])
+{
+	int d[5];
+	if (!desc || fold_variant_describe(variant, d)) return fail(HFDL_GPU_EINVAL, "no fold variant %d", variant);
+	for (int i = 0; i < 5; i++) desc[i] = d[i];
+	return 0;
+}
+
+// Measurement aid (profiles/fold_variants.py): `reps` launches of one compiled tiling over the front end's own taps and the spectra /
+// partial sums of the half (whatever the last blocks left there), timed by the kernels' own events; *checksum = a 64-bit sum over the
+// partial sums' bit patterns, equal across tilings of the same NB when they are bit-identical.
+extern "C" int hfdl_gpu_frontend_fold_variant_probe(hfdl_gpu_frontend *fe, int variant, int reps, double *avg_ms, double *best_ms, uint64_t *checksum)
+{
+	if (!fe || !avg_ms || reps < 1) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	int d[5];
+	if (fold_variant_describe(variant, d)) return fail(HFDL_GPU_EINVAL, "no fold variant %d", variant);
+	if (d[4] > fe->half_blocks) return fail(HFDL_GPU_ERANGE, "variant folds %d blocks, a half holds %d", d[4], fe->half_blocks);
+	const Geometry &g = fe->geo;
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	double sum = 0, best = 1e30;
+	for (int i = 0; i < reps + 1; i++) {
+		if (launch_fold_variant(variant, g, fe->d_taps, fe->d_spec, (size_t)g.n, fe->d_partial, fe->partial_stride(), fe->stream, e0, e1) < 0) {
+			(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+			return fail(HFDL_GPU_ERANGE, "fold variant %d does not fit this geometry (M = %d)", variant, g.m);
+		}
+		HIP_TRY(hipEventSynchronize(e1));
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+		if (i > 0) { sum += ms; best = std::min(best, (double)ms); }       // first launch: code load
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	HIP_TRY(hipGetLastError());
+	*avg_ms = sum / reps;
+	if (best_ms) *best_ms = best;
+	if (checksum) {
+		const size_t words = 2 * fe->partial_stride() * (size_t)d[4];
+		std::vector<uint32_t> h(words);
+		HIP_TRY(hipMemcpy(h.data(), fe->d_partial, sizeof(uint32_t) * words, hipMemcpyDeviceToHost));
+		uint64_t acc = 0;
+		for (size_t i = 0; i < words; i++) acc += (uint64_t)h[i] * (uint64_t)(2 * (i % 65521) + 1);
+		*checksum = acc;
+	}
+	return 0;
+}
+
 extern "C" int hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches, int64_t *blocks)
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
@@ -841,7 +949,9 @@ extern "C" int hfdl_gpu_frontend_step_period_ms(hfdl_gpu_frontend *fe, double *p
 	if (!fe || !period_ms) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
-	*period_ms = fe->fold_launches > 1 ? fe->span_ms / (double)(fe->fold_launches - 1) : 0.0;
+	// first timed fold start -> last timed fold start covers every timed block but the last launch's; per BLOCK
+	const int64_t covered = fe->fold_timed_blocks - fe->fold_last_blocks;
+	*period_ms = (fe->fold_launches > 1 && covered > 0) ? fe->span_ms / (double)covered : 0.0;
 	return 0;
 }
 
@@ -922,17 +1032,22 @@ extern "C" int hfdl_gpu_frontend_channel_stats(hfdl_gpu_frontend *fe, int32_t ch
 	return 0;
 }
 
-extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel, float *dst, size_t cap, size_t *n_floats)
+extern "C" int hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what, int32_t channel, int32_t back, float *dst, size_t cap, size_t *n_floats)
 {
 	if (!fe || !dst || !n_floats) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
 	const Geometry &g = fe->geo;
+	// the channelizer's own buffers hold every block of the newest half: `back` blocks before the newest one
+	if (back < 0 || back > fe->last_index) return fail(HFDL_GPU_ERANGE, "block %d back is not held any more (%d are)", back, fe->last_index);
+	if (back && what != HFDL_GPU_TAP_SPECTRUM && what != HFDL_GPU_TAP_CHAN_OUT && what != HFDL_GPU_TAP_NCO_PHASORS)
+		return fail(HFDL_GPU_EINVAL, "tap %d holds the last launch only", what);
+	const int slot = fe->last_slot - back, index = fe->last_index - back;
 	if (what != HFDL_GPU_TAP_SPECTRUM && (channel < 0 || channel >= g.nch)) return fail(HFDL_GPU_EINVAL, "channel out of range");
 	const void *src = nullptr;
 	size_t nf = 0;
 	switch (what) {
-	case HFDL_GPU_TAP_SPECTRUM: src = fe->d_spec; nf = 2 * (size_t)g.n; break;
+	case HFDL_GPU_TAP_SPECTRUM: src = fe->spec_slot(index); nf = 2 * (size_t)g.n; break;
 	case HFDL_GPU_TAP_FILTER: {
 		// rows of M bins, tap_row_stride apart: gather them into the caller's contiguous cf32[N]
 		if (2 * (size_t)g.n > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", 2 * (size_t)g.n, cap);
@@ -942,14 +1057,14 @@ extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32
 		return 0; }
 	case HFDL_GPU_TAP_CHAN_OUT: {
 		int cnt = 0;
-		HIP_TRY(hipMemcpy(&cnt, fe->cnt_slot(fe->last_slot) + channel, sizeof(cnt), hipMemcpyDeviceToHost));
-		src = fe->chan_slot(fe->last_slot) + (size_t)channel * g.outs; nf = 2 * (size_t)cnt; break; }
+		HIP_TRY(hipMemcpy(&cnt, fe->cnt_slot(slot) + channel, sizeof(cnt), hipMemcpyDeviceToHost));
+		src = fe->chan_slot(slot) + (size_t)channel * g.outs; nf = 2 * (size_t)cnt; break; }
 	case HFDL_GPU_TAP_NCO_PHASORS: {
 		int cnt = 0;
-		HIP_TRY(hipMemcpy(&cnt, fe->cnt_slot(fe->last_slot) + channel, sizeof(cnt), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&cnt, fe->cnt_slot(slot) + channel, sizeof(cnt), hipMemcpyDeviceToHost));
 		if (2 * (size_t)cnt > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", 2 * (size_t)cnt, cap);
 		// column `channel` of the [outs][nch] table
-		if (cnt) HIP_TRY(hipMemcpy2D(dst, sizeof(float2), fe->d_ph + channel, sizeof(float2) * (size_t)g.nch, sizeof(float2), (size_t)cnt, hipMemcpyDeviceToHost));
+		if (cnt) HIP_TRY(hipMemcpy2D(dst, sizeof(float2), fe->d_ph + (size_t)index * fe->ph_stride() + channel, sizeof(float2) * (size_t)g.nch, sizeof(float2), (size_t)cnt, hipMemcpyDeviceToHost));
 		*n_floats = 2 * (size_t)cnt;
 		return 0; }
 	case HFDL_GPU_TAP_PHASE_CYCLES: src = fe->demod.d_tap_lvl + (size_t)channel * fe->demod.cap + fe->demod.cap - 4; nf = 4; break;
@@ -961,6 +1076,11 @@ extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32
 	if (nf) HIP_TRY(hipMemcpy(dst, src, sizeof(float) * nf, hipMemcpyDeviceToHost));
 	*n_floats = nf;
 	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel, float *dst, size_t cap, size_t *n_floats)
+{
+	return hfdl_gpu_frontend_read_tap_block(fe, what, channel, 0, dst, cap, n_floats);
 }
 
 // ---------------------------------------------------------------- stage-level entry points

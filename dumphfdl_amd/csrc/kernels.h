@@ -41,12 +41,16 @@ struct Geometry {
 
 // The NCO phasor table of a block, made while that block's forward FFT runs.  decimating_shift_addition_cc's phasor recurrence
 // (src/libcsdr_gpl.c:48-66) is 1792 strictly serial fp32 steps per channel at cfg3 -- 47 us for a lone lane, which used to be the
-// whole duration of the inverse-FFT kernel.  It depends on the carried NcoState only, which is final when the previous block's
-// kernel has run: one extra workgroup per FFT pass launch runs a third of it, LANES OVER CHANNELS (256 channels = 4 wavefronts),
-// hidden inside the pass.  Table layout [output index][channel] so the lanes' stores coalesce.
+// whole duration of the inverse-FFT kernel.  It depends on the carried NcoState only: one extra workgroup per FFT pass launch runs
+// a third of it, LANES OVER CHANNELS (256 channels = 4 wavefronts), hidden inside the pass.  Table layout [output index][channel]
+// so the lanes' stores coalesce.
+// The riders also OWN the carried state (decimating_shift_addition_status_t): the forward FFTs of several blocks are queued before
+// the first of their inverse FFTs runs (fold batching, hfdl_gpu.cpp), so the state cannot wait for that kernel.  Segment 0 leaves the
+// state the block starts from in `snap` (what the block's inverse-FFT kernel reads), the last segment advances `chain` (:67-72).
 struct NcoJob {
 	const ChanConst *cc = nullptr;     // null: no rider workgroup on this launch
-	const NcoState *nco = nullptr;     // state before the block (decimating_shift_addition_status_t)
+	NcoState *chain = nullptr;         // [nch] carried state: before this block on entry, after it once the last segment has run
+	NcoState *snap = nullptr;          // [nch] copy of the state before this block, for its inverse-FFT / NCO kernel
 	float2 *ph = nullptr;              // [outs][nch] phasor table of the block
 	float2 *cont = nullptr;            // [nch] phasor at the start of the next segment
 	int32_t nch = 0, outs = 0, post_input_size = 0, post = 0;
@@ -73,12 +77,20 @@ void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh,
 		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay = FftOutLayout(), hipEvent_t done = nullptr,
 		NcoJob nco = NcoJob());
 // optional events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL): no separate barrier packets in the queue
-void launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, float2 *partial, hipStream_t st,
-		hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// `nb` consecutive blocks: spectra `spec_stride` cf32 apart, partial sums `partial_stride` apart; launches of at most `nb_max` blocks
+// sharing one pass over the taps.  Returns the number of kernel launches made.
+int launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial, size_t partial_stride,
+		int nb, int nb_max, hipStream_t st, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// measurement aid (profiles/fold_variants.py): the compiled register tilings; launch one of them on `nb` spectra
+int fold_variant_count();
+int fold_variant_describe(int variant, int desc[5]);            // U, R, CS, NC, NB
+int launch_fold_variant(int variant, const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial,
+		size_t partial_stride, hipStream_t st, hipEvent_t start, hipEvent_t stop);
 hipError_t prepare_ifft_nco(int m);     // LDS attribute of the inverse-FFT kernel for this size (checked at create time)
-// `ph`: the block's phasor table [outs][nch] (NcoJob riders of the forward FFT)
-void launch_ifft_nco(const Geometry &g, const float2 *partial, const ChanConst *cc, NcoState *nco, const float2 *ph,
-		const float2 *tw_m, float2 *chan_out, int *out_count, hipStream_t st, hipEvent_t done = nullptr);
+// `nb` blocks in one launch (grid nch x nb): partial sums, carried-state snapshots, phasor tables [outs][nch], outputs and counts of
+// consecutive blocks lie `partial_stride` / nch / `ph_stride` / nch * outs / nch apart
+void launch_ifft_nco(const Geometry &g, const float2 *partial, size_t partial_stride, const ChanConst *cc, const NcoState *snap, const float2 *ph,
+		size_t ph_stride, const float2 *tw_m, float2 *chan_out, int *out_count, int nb, hipStream_t st, hipEvent_t done = nullptr);
 void launch_nco_decimate(const float2 *in, int input_size, float cosdelta, float sindelta, float rate, int decimation,
 		NcoState *state, float2 *phasor_scratch, float2 *out, hipStream_t st);
 int stream_read_variants();

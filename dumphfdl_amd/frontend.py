@@ -23,7 +23,7 @@ class Geometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "sample_rate", "decimation", "pre_decimation", "post_decimation", "taps_length", "overlap_length",
         "fft_size", "fft_inv_size", "input_size", "post_input_size", "scrap", "outputs_per_block",
-        "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float), ("max_outputs_per_block", C.c_int32), ("demod_batch", C.c_int32)]
+        "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float), ("max_outputs_per_block", C.c_int32), ("demod_batch", C.c_int32), ("fold_batch", C.c_int32)]
 
 
 class Pdu(C.Structure):
@@ -62,9 +62,21 @@ EXPORTS = [
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_input_done_upto", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_demod_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
+    "hfdl_gpu_frontend_fold_blocks", "hfdl_gpu_frontend_read_tap_block", "hfdl_gpu_fold_variant_count", "hfdl_gpu_fold_variant_describe", "hfdl_gpu_frontend_fold_variant_probe",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk", "hfdl_gpu_frontend_prefetch_block_raw", "hfdl_gpu_frontend_prefetch_cancel", "hfdl_gpu_psk_slice",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
+
+
+def fold_variants():
+    """The fold kernel's compiled register tilings: [(U, R, CS, NC, NB)] (measurement aid)."""
+    L = load()
+    out = []
+    for v in range(L.hfdl_gpu_fold_variant_count()):
+        d = (C.c_int32 * 5)()
+        _check(L.hfdl_gpu_fold_variant_describe(v, C.byref(d)))
+        out.append(tuple(d))
+    return out
 
 
 def load():
@@ -102,10 +114,14 @@ def load():
     L.hfdl_gpu_frontend_stream.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_stream.restype = C.c_void_p
     L.hfdl_gpu_frontend_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.hfdl_gpu_frontend_read_tap_block.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.hfdl_gpu_frontend_enable_taps.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_frontend_channel_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ChannelStats)]
     L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_demod_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.hfdl_gpu_frontend_fold_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.hfdl_gpu_fold_variant_describe.argtypes = [C.c_int, C.POINTER(C.c_int32 * 5)]
+    L.hfdl_gpu_frontend_fold_variant_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_frontend_stream_read_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.hfdl_gpu_fft_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
@@ -256,12 +272,13 @@ class Frontend:
         _check(load().hfdl_gpu_frontend_all_channel_stats(self._h, buf, nch, C.byref(n)))
         return [{k: getattr(buf[i], k) for k, _ in ChannelStats._fields_} for i in range(n.value)]
 
-    def read_tap(self, what, channel=0):
+    def read_tap(self, what, channel=0, back=0):
+        """back: TAP_SPECTRUM / TAP_CHAN_OUT / TAP_NCO_PHASORS of the block `back` blocks before the newest (within the newest half)."""
         g = self.geometry
         cap = 2 * g.fft_size if what in (TAP_SPECTRUM, TAP_FILTER) else 2 * (g.post_input_size + 64) * max(1, g.demod_batch)   # demodulator taps cover a launch
         buf = np.empty(cap, np.float32)
         n = C.c_size_t(0)
-        _check(load().hfdl_gpu_frontend_read_tap(self._h, what, channel, _p(buf), cap, C.byref(n)))
+        _check(load().hfdl_gpu_frontend_read_tap_block(self._h, what, channel, back, _p(buf), cap, C.byref(n)))
         out = buf[:n.value].copy()
         return out if what in (TAP_AGC_LEVEL, TAP_PHASE_CYCLES) else out.view(np.complex64)
 
@@ -281,6 +298,18 @@ class Frontend:
         n = C.c_int64(0)
         _check(load().hfdl_gpu_frontend_fold_time_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def fold_blocks(self):
+        """Blocks covered by the timed fold launches (a launch folds up to geometry.fold_batch blocks)."""
+        n = C.c_int64(0)
+        _check(load().hfdl_gpu_frontend_fold_blocks(self._h, C.byref(n)))
+        return n.value
+
+    def fold_variant_probe(self, variant, reps=3):
+        """(avg ms, best ms, checksum of the partial sums) of `reps` launches of one compiled fold tiling (measurement aid)."""
+        avg, best, chk = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        _check(load().hfdl_gpu_frontend_fold_variant_probe(self._h, variant, reps, C.byref(avg), C.byref(best), C.byref(chk)))
+        return avg.value, best.value, chk.value
 
     def demod_time_ms(self):
         ms = C.c_double(0)

@@ -73,6 +73,11 @@ typedef struct {
 	int32_t demod_batch;             /* blocks one demodulator launch takes when they are pushed faster than they are collected (1 where the
 	                                    channelizer bounds the block; up to 8 on the small, demodulator-bound geometries).  Results do not
 	                                    depend on it; a poll / sync always demodulates what has been pushed.  0 from hfdl_gpu_plan_geometry() */
+	int32_t fold_batch;              /* blocks whose spectra one fold launch multiplies against ONE pass over the per-channel filter taps when
+	                                    they are pushed faster than they are collected (src/fastddc.c:123-150 run for that many blocks; the taps are
+	                                    > 99 % of a block's bytes on the 256-channel geometries).  Every block's result is bit-identical to a launch
+	                                    of its own; a poll / sync always folds what has been pushed.  HFDL_GPU_FOLD_BATCH=1..8 overrides the default
+	                                    of 4 at create time.  0 from hfdl_gpu_plan_geometry() */
 } hfdl_gpu_geometry;
 
 /* one decoded PDU: what dispatch_pdu() hands to pdu_decoder_queue_push (src/hfdl.c:1058-1080,
@@ -117,7 +122,9 @@ int  hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int32_t sampl
 void hfdl_gpu_frontend_destroy(hfdl_gpu_frontend *fe);
 int  hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_geometry *g);
 
-/* Enqueue one block: exactly geometry.input_size new complex samples (interleaved I,Q float32).  Asynchronous.
+/* Enqueue one block: exactly geometry.input_size new complex samples (interleaved I,Q float32).  Asynchronous: the block's forward
+ * FFT is queued at once; fold, inverse FFT, demodulator and burst decoder follow when geometry.fold_batch blocks are waiting or the
+ * caller syncs / polls, whichever comes first (the results do not depend on which).
  * on_device != 0: `iq` is a device pointer that stays valid until the next sync.
  * on_device == 0: the host -> device copy runs on its own stream into one of two staging buffers, so the copy of block
  *   k+1 overlaps the kernels of block k.  A buffer from hfdl_gpu_host_alloc() (page-locked) is read by DMA after the call
@@ -216,15 +223,28 @@ enum {
 int  hfdl_gpu_frontend_enable_taps(hfdl_gpu_frontend *fe, int enable);
 /* dst holds `cap` floats; *n_floats receives the number written */
 int  hfdl_gpu_frontend_read_tap(hfdl_gpu_frontend *fe, int what, int32_t channel, float *dst, size_t cap, size_t *n_floats);
+/* taps 1, 3 and 9 of the block `back` blocks before the newest one (0 = read_tap): the channelizer keeps the blocks of the newest half
+ * -- what was pushed since the half before it filled (geometry.fold_batch blocks, or max(fold_batch, demod_batch)) or since the last
+ * sync / poll; HFDL_GPU_ERANGE beyond that */
+int  hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what, int32_t channel, int32_t back, float *dst, size_t cap, size_t *n_floats);
 
-/* timing of the dominant kernel (fold) measured with HIP events on the front end's stream */
+/* timing of the dominant kernel (fold) measured with HIP events on the front end's stream; a launch folds up to geometry.fold_batch
+ * blocks: hfdl_gpu_frontend_fold_blocks() = the blocks the timed launches covered */
 int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
+int  hfdl_gpu_frontend_fold_blocks(hfdl_gpu_frontend *fe, int64_t *blocks);
+/* measurement aids (profiles/fold_variants.py): the register tilings of the fold kernel compiled into the library --
+ * desc = { float4 per thread and row, rows per trip, column split, channels per workgroup, blocks per launch } -- and `reps` timed
+ * launches of one of them over the front end's resident taps and the spectra of its last blocks; *checksum sums the bit patterns
+ * of the partial sums (equal for bit-identical tilings of the same block count) */
+int  hfdl_gpu_fold_variant_count(void);
+int  hfdl_gpu_fold_variant_describe(int variant, int32_t desc[5]);
+int  hfdl_gpu_frontend_fold_variant_probe(hfdl_gpu_frontend *fe, int variant, int reps, double *avg_ms, double *best_ms, uint64_t *checksum);
 int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
 /* the same for the demodulator kernel (the kernel that bounds the small geometries), from its dispatch's own start / stop events;
  * *blocks = the blocks those launches covered (a launch takes up to geometry.demod_batch blocks) */
 int  hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches, int64_t *blocks);
-/* steady-state period of one block: (start of the last timed fold launch - start of the first) / (launches - 1), free of
- * the pipeline fill before the first block and the demodulator / burst-decoder drain after the last */
+/* steady-state period of one block: (start of the last timed fold launch - start of the first) / (blocks folded by all timed launches
+ * but the last), free of the pipeline fill before the first block and the demodulator / burst-decoder drain after the last */
 int  hfdl_gpu_frontend_step_period_ms(hfdl_gpu_frontend *fe, double *period_ms);
 /* what the board's HBM delivers to a read-only streaming kernel with the fold's access pattern (reads the resident taps) */
 int  hfdl_gpu_frontend_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_per_s);

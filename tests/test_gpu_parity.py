@@ -842,6 +842,66 @@ def test_demodulator_batching_changes_nothing(gpu, oracle, monkeypatch):
                 assert have[k + "_corr_avg"] == pytest.approx(want[k + "_corr_total"] / want[cnt], rel=1e-5)
 
 
+@pytest.mark.parametrize("fs,nch", [(250000, 5), (2_400_000, 130)])
+def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
+    """One fold launch multiplies the spectra of up to geometry.fold_batch queued blocks against ONE pass over the filter taps
+    (fold_kernels.hip, NB; src/fastddc.c:123-150 run for that many blocks).  Every bin's sum is the same FMA chain whatever the
+    company, so the channelizer output of EVERY block -- read back per block, compared as uint32 -- and every PDU equal those of a
+    pass over the taps per block (HFDL_GPU_FOLD_BATCH=1), for full batches, batches of 8, and the ragged batches that draining
+    polls / syncs cut (3 + 1, 2, 7 = 4 + 2 + 1 ...).  5 channels: demodulator-bound geometry (decoder on its own stream, 4 blocks per
+    demodulator launch, an odd channel left over for the single-channel tiling); 130 channels: fold-bound shape (one block per
+    demodulator launch, launches held back behind the next half's forward FFTs)."""
+    cf = 10_000_000
+    rng = np.random.default_rng(nch)
+    if nch == 5:
+        freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000, 10_101_000]
+        dur = 9.0
+        bursts = synth.plan_traffic(freqs, dur, seed=31, dense=True, gap_s=0.12, amp=(0.02, 0.1))
+    else:
+        freqs = [int(cf + (i - nch // 2) * 15_000 + 4_000) for i in range(nch)]
+        dur = 2.6
+        bursts = [dict(freq=freqs[c], mode=int(rng.integers(0, 4)), octets=b"", t0=float(rng.uniform(0.1, 0.5)), amp=0.03, cfo=float(rng.uniform(-10, 10)))
+                  for c in (0, 3, 64, 77, 128, 129)]
+        for b in bursts:
+            b["octets"] = synth.make_pdu(rng, b["mode"])
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.012, seed=31)
+    watch = sorted(set([0, 1, nch // 2, nch - 2, nch - 1]))
+
+    def run(fold_env, cuts):
+        monkeypatch.setenv("HFDL_GPU_FOLD_BATCH", str(fold_env))
+        fe = gpu.Frontend(fs, cf, freqs)
+        g = fe.geometry
+        assert g.fold_batch == fold_env
+        n, nblk = fe.input_size, len(x) // fe.input_size
+        outs, got, b, i = [], [], 0, 0
+        while b < nblk:
+            k = min(cuts[i % len(cuts)], nblk - b)
+            i += 1
+            for j in range(k):
+                fe.push_block(x[(b + j) * n:(b + j + 1) * n])
+            got += fe.poll_pdus()                 # closes the half as it is: a batch of k blocks (split 8 / 4 / 2 / 1 inside)
+            half = min(8, -(-max(g.fold_batch, g.demod_batch) // g.fold_batch) * g.fold_batch)      # blocks a half holds (hfdl_gpu.cpp half_blocks)
+            held = min(k, ((k - 1) % half) + 1)   # blocks of the newest half: what read_tap(back=...) still reaches
+            for j in range(held):
+                outs.append((b + k - held + j, [fe.read_tap(F.TAP_CHAN_OUT, c, back=held - 1 - j).view(np.uint32).copy() for c in watch]))
+            b += k
+        stats = fe.all_channel_stats()
+        fe.close()
+        return dict(outs), sorted(got, key=lambda p: (p["freq"], p["sample_index"])), stats
+
+    ref_outs, ref_pdus, ref_stats = run(1, [1])
+    assert len(ref_outs) == len(x) // (28672 if fs == 250000 else 458752)
+    assert len(ref_pdus) >= len(bursts) - 2
+    for fold_env, cuts in ((4, [4]), (4, [3, 1, 2, 4]), (8, [8]), (8, [7, 5, 8, 3]), (2, [2, 1])):
+        outs, pdus, stats = run(fold_env, cuts)
+        assert outs, (fold_env, cuts)
+        for blk, chans in outs.items():
+            for c, a in zip(watch, chans):
+                assert np.array_equal(a, ref_outs[blk][watch.index(c)]), (fold_env, cuts, blk, c)
+        assert pdus == ref_pdus, (fold_env, cuts)       # every field of every PDU
+        assert stats == ref_stats, (fold_env, cuts)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_random_call_sequences_equal_a_launch_per_block(gpu, monkeypatch, seed):
     """The batching state machine under random use: after every pushed block one of {nothing, lagging collection, draining poll, sync,
