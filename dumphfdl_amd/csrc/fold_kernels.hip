@@ -30,7 +30,7 @@ __device__ __forceinline__ float4 load_stream(const float4 *p)
 // One complex multiply-accumulate per bin, spelled out as FMAs in a FIXED order so that every instantiation below -- any
 // (U, CS, NC, NB) -- rounds a (block, channel, bin) sum exactly alike: a block folded alone and the same block folded beside three
 // others give the same 32 bits (tests/test_gpu_parity.py::test_fold_batching_changes_nothing).
-__device__ __forceinline__ void cmac2(float4 &a, const float4 h, const float4 x)
+__device__ __forceinline__ void cmac2(v4f &a, const v4f h, const v4f x)
 {
 	a.x = __builtin_fmaf(h.x, x.x, a.x); a.x = __builtin_fmaf(-h.y, x.y, a.x);
 	a.y = __builtin_fmaf(h.x, x.y, a.y); a.y = __builtin_fmaf(h.y, x.x, a.y);
@@ -39,43 +39,62 @@ __device__ __forceinline__ void cmac2(float4 &a, const float4 h, const float4 x)
 }
 
 // U float4 (= 2U bins) per thread per alias row; R = alias rows per loop trip; CS = column split: a workgroup covers 1/CS of a
-// row; NC = channels per workgroup sharing every spectrum load; NB = BLOCKS per launch sharing every tap load: the spectra of NB
+// row; NC = channels per thread sharing every spectrum load; NB = BLOCKS per launch sharing every tap load: the spectra of NB
 // consecutive blocks (`spec_stride4` apart) are folded against ONE pass over the taps -- the taps are 99.9 % of a block's bytes and
 // identical from block to block, so when blocks are queued (replay, catch-up, the bench) a launch serves NB of them for the HBM
 // traffic of one (src/fastddc.c:123-150 run NB times).  Register tile: acc[NB][NC][U], an NB x NC outer product per column.
-template <int U, int R, int CS, int NC, int NB>
-__global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__restrict__ taps, const float4 *__restrict__ spec,
+// WV = waves over channels: the workgroup's four wavefronts cover the SAME 64 * U columns and four different groups of NC channels,
+// so one wave's spectrum loads fill the CU's L1 and the other three hit it: with NB blocks per launch the spectrum traffic out of
+// L2 is NB / NC times the tap traffic (measured: what bounds the launch, profiles/r04_fold_variants.md), NB / (4 NC) this way.
+// waves per SIMD the register tile allows (512 VGPRs per lane and SIMD).  Told to the compiler: with a bare __launch_bounds__(256) it
+// aims at 8 waves per SIMD, squeezes the kernel into 64 VGPRs and gets there by issuing a load or two, waiting, multiplying, loading
+// again -- one or two kilobytes in flight per wave where the trip has eight or more to ask for at once.
+constexpr int fold_waves(int u, int r, int nc, int nb)
+{
+	const int regs = 4 * (nb * nc * u + nc * r * u + nb * r * u) + 24;
+	return regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
+}
+
+template <int U, int R, int CS, int NC, int NB, bool WV>
+__global__ __launch_bounds__(FOLD_THREADS) __attribute__((amdgpu_waves_per_eu(fold_waves(U, R, NC, NB), fold_waves(U, R, NC, NB)))) void fold_kernel(
+		const float4 *__restrict__ taps, const float4 *__restrict__ spec,
 		float4 *__restrict__ partial, size_t chan_stride4, size_t row_stride4, size_t spec_stride4, size_t partial_stride4,
 		int m, int slices, int rows, int c_base)
 {
+	constexpr int LANES = WV ? 64 : FOLD_THREADS;             // threads side by side along a row
 	const int cpart = blockIdx.x % CS;
 	const int bs = blockIdx.x / CS;
-	const int s = bs % slices, c0 = c_base + (bs / slices) * NC;
+	const int wave = WV ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, lane = WV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+	const int s = bs % slices, c0 = c_base + ((bs / slices) * (WV ? 4 : 1) + wave) * NC;
 	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row of the spectrum
-	const size_t col = (size_t)cpart * U * FOLD_THREADS + threadIdx.x;
-	const float4 *tp = taps + (size_t)c0 * chan_stride4 + (size_t)s * rows * row_stride4 + col;
-	const float4 *sp = spec + (((size_t)s * rows * (size_t)m) >> 1) + col;
-	float4 acc[NB][NC][U];
+	const size_t col = (size_t)cpart * U * LANES + lane;
+	// Addresses = a wave-uniform base per stream (scalar registers, stepped by scalar adds) + ONE 32-bit byte offset per thread + an
+	// immediate: a load costs no vector arithmetic, and the whole trip's loads go out back to back.
+	const unsigned voff = (unsigned)lane * 16u;
+	const char *tb = (const char *)(taps + (size_t)c0 * chan_stride4 + (size_t)s * rows * row_stride4 + (size_t)cpart * U * LANES);
+	const char *sb = (const char *)(spec + (((size_t)s * rows * (size_t)m) >> 1) + (size_t)cpart * U * LANES);
+	const size_t cs_b = chan_stride4 * 16, rs_b = row_stride4 * 16, ss_b = spec_stride4 * 16, r4_b = (size_t)row4 * 16;
+	v4f acc[NB][NC][U];
 #pragma unroll
 	for (int b = 0; b < NB; b++)
 #pragma unroll
 		for (int k = 0; k < NC; k++)
 #pragma unroll
-			for (int u = 0; u < U; u++) acc[b][k][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-	const bool live = (U * CS > 1) || ((int)threadIdx.x < row4);
+			for (int u = 0; u < U; u++) acc[b][k][u] = (v4f)(0.f);
+	const bool live = WV || (U * CS > 1) || ((int)threadIdx.x < row4);
 	if (live) {
 		for (int r = 0; r < rows; r += R) {
-			float4 h[NC][R][U], x[NB][R][U];
+			v4f h[NC][R][U], x[NB][R][U];
 #pragma unroll
 			for (int q = 0; q < R; q++) {
 #pragma unroll
 				for (int u = 0; u < U; u++) {
 #pragma unroll
 					for (int k = 0; k < NC; k++)
-						h[k][q][u] = load_stream(tp + (size_t)k * chan_stride4 + (size_t)q * row_stride4 + u * FOLD_THREADS);
+						h[k][q][u] = __builtin_nontemporal_load((const v4f *)(tb + (size_t)k * cs_b + (size_t)q * rs_b + (size_t)voff + (size_t)(u * LANES * 16)));
 #pragma unroll
 					for (int b = 0; b < NB; b++)
-						x[b][q][u] = sp[(size_t)b * spec_stride4 + (size_t)q * row4 + u * FOLD_THREADS];
+						x[b][q][u] = *(const v4f *)(sb + (size_t)b * ss_b + (size_t)q * r4_b + (size_t)voff + (size_t)(u * LANES * 16));
 				}
 			}
 #pragma unroll
@@ -86,16 +105,19 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(const float4 *__rest
 					for (int k = 0; k < NC; k++)
 #pragma unroll
 						for (int u = 0; u < U; u++) cmac2(acc[b][k][u], h[k][q][u], x[b][q][u]);
-			tp += (size_t)R * row_stride4;
-			sp += (size_t)R * row4;
+			// the trip as the scheduler is to lay it out: every load first, then the multiplies as their operands arrive
+			__builtin_amdgcn_sched_group_barrier(0x020, (NC + NB) * R * U, 0);
+			__builtin_amdgcn_sched_group_barrier(0x002, NB * NC * U * R * 8, 0);
+			tb += (size_t)R * rs_b;
+			sb += (size_t)R * r4_b;
 		}
 #pragma unroll
 		for (int b = 0; b < NB; b++)
 #pragma unroll
 			for (int k = 0; k < NC; k++) {
-				float4 *po = partial + (size_t)b * partial_stride4 + (((size_t)(c0 + k) * slices + s) * (size_t)m >> 1) + (size_t)cpart * U * FOLD_THREADS + threadIdx.x;
+				v4f *po = (v4f *)partial + (size_t)b * partial_stride4 + (((size_t)(c0 + k) * slices + s) * (size_t)m >> 1) + col;
 #pragma unroll
-				for (int u = 0; u < U; u++) po[u * FOLD_THREADS] = acc[b][k][u];
+				for (int u = 0; u < U; u++) po[u * LANES] = acc[b][k][u];
 			}
 	}
 }
@@ -163,75 +185,85 @@ struct FoldArgs {
 	hipEvent_t start, stop;
 };
 
-// channel groups of NC first; the nch % NC channels left over get single-channel workgroups in a launch of their own
-template <int U, int R, int CS, int NC, int NB>
+// channel groups first (NC channels, or 4 * NC with the waves over channels); the channels left over get single-channel workgroups
+// (one column range per workgroup) in a launch of their own
+template <int U, int R, int CS, int NC, int NB, bool WV>
 static int fold_go(const FoldArgs &a)
 {
 	const dim3 block(FOLD_THREADS);
-	const int groups = a.nch / NC, rest = a.nch - groups * NC;
+	constexpr int GC = WV ? 4 * NC : NC;                  // channels per workgroup
+	constexpr int RU = WV ? (U >= 4 ? U / 4 : 1) : U, RCS = WV ? (U >= 4 ? CS : CS * U / 4) : CS;      // the same row as RU * RCS * 256 columns
+	const int groups = a.nch / GC, rest = a.nch - groups * GC;
 	int launches = 0;
 	if (groups > 0) {
-		hipExtLaunchKernelGGL((fold_kernel<U, R, CS, NC, NB>), dim3((unsigned)(groups * a.slices * CS)), block, 0, a.st, a.start, rest ? nullptr : a.stop, 0,
+		hipExtLaunchKernelGGL((fold_kernel<U, R, CS, NC, NB, WV>), dim3((unsigned)(groups * a.slices * CS)), block, 0, a.st, a.start, rest ? nullptr : a.stop, 0,
 			a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, 0);
 		launches++;
 	}
 	if (rest > 0) {
-		hipExtLaunchKernelGGL((fold_kernel<U, R, CS, 1, NB>), dim3((unsigned)(rest * a.slices * CS)), block, 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
-			a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, groups * NC);
+		hipExtLaunchKernelGGL((fold_kernel<RU, 1, RCS, 1, NB, false>), dim3((unsigned)(rest * a.slices * RCS)), block, 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+			a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, groups * GC);
 		launches++;
 	}
 	return launches;
 }
 
-struct FoldVariant { int u, r, cs, nc, nb; int (*go)(const FoldArgs &); };
-#define FV(U, R, CS, NC, NB) { U, R, CS, NC, NB, fold_go<U, R, CS, NC, NB> }
-// A row of M bins = U * CS * 512.  Measured on cfg3 (M = 4096) with profiles/fold_variants.py: profiles/r04_fold_variants.md.
+struct FoldVariant { int u, r, cs, nc, nb, wv; int (*go)(const FoldArgs &); };
+#define FV(U, R, CS, NC, NB) { U, R, CS, NC, NB, 0, fold_go<U, R, CS, NC, NB, false> }
+#define FW(U, R, CS, NC, NB) { U, R, CS, NC, NB, 1, fold_go<U, R, CS, NC, NB, true> }
+// A row of M bins = U * CS * 512 (FV) or U * CS * 128 (FW: waves over channels).  Measured on cfg3 (M = 4096) with
+// profiles/fold_variants.py: profiles/r04_fold_variants.md.
 // What paid at one block per launch (profiles/r01_experiments.md): non-temporal tap loads (+7 %) and TWO channels per workgroup
 // sharing every spectrum load (+14 %: halves the L2 -> L1 spectrum traffic).  With NB blocks per launch the spectrum traffic is
 // NB / NC times the tap traffic, so the tile trades registers between the two (acc = 4 * NB * NC * U VGPRs).
 static const FoldVariant fold_variants[] = {
-	// M = 512 .. 8192 at one block per launch: the round-1 tilings
+	// the first entry of a block count that fits the geometry is the one used; the rest are kept for profiles/fold_variants.py
+	// one block per launch, M = 512 .. 8192: the round-1 tilings
 	FV(1, 1, 1, 2, 1), FV(1, 1, 2, 2, 1), FV(2, 1, 2, 2, 1), FV(4, 1, 2, 2, 1), FV(8, 1, 2, 2, 1),
+	FV(4, 2, 2, 2, 1), FW(4, 1, 8, 2, 1),
 	// two blocks
-	FV(1, 1, 1, 2, 2), FV(1, 1, 2, 2, 2), FV(2, 1, 2, 2, 2), FV(4, 1, 2, 2, 2), FV(2, 2, 4, 2, 2), FV(2, 1, 4, 4, 2), FV(4, 1, 4, 2, 2),
+	FV(1, 1, 1, 2, 2), FV(1, 1, 2, 2, 2), FV(1, 1, 4, 4, 2), FV(2, 1, 4, 4, 2), FV(4, 1, 4, 2, 2),
+	FV(4, 1, 2, 2, 2), FV(2, 1, 2, 2, 2), FW(2, 1, 16, 4, 2), FV(1, 1, 8, 4, 2), FV(1, 1, 8, 8, 2),
 	// four blocks
-	FV(1, 1, 1, 2, 4), FV(1, 1, 2, 2, 4), FV(2, 1, 2, 2, 4), FV(2, 1, 4, 2, 4), FV(1, 2, 8, 2, 4), FV(1, 1, 8, 4, 4), FV(1, 2, 8, 4, 4),
-	FV(4, 1, 2, 1, 4), FV(2, 2, 4, 1, 4), FV(2, 1, 4, 4, 4), FV(4, 1, 2, 2, 4), FV(1, 1, 8, 2, 4), FV(2, 1, 8, 2, 4),
+	FV(1, 1, 1, 2, 4), FV(1, 1, 2, 4, 4), FV(1, 1, 4, 8, 4), FV(1, 1, 8, 8, 4), FV(2, 1, 8, 4, 4),
+	FV(1, 1, 2, 2, 4), FV(1, 1, 4, 4, 4), FV(2, 1, 4, 4, 4), FV(1, 1, 8, 4, 4), FW(2, 1, 16, 4, 4), FW(1, 1, 32, 4, 4), FW(1, 1, 32, 8, 4), FV(2, 1, 2, 2, 4),
 	// eight blocks
-	FV(1, 1, 1, 2, 8), FV(1, 1, 2, 2, 8), FV(1, 1, 4, 2, 8), FV(1, 1, 8, 2, 8), FV(1, 1, 8, 4, 8), FV(2, 1, 4, 1, 8), FV(2, 1, 4, 2, 8), FV(2, 1, 8, 2, 8), FV(1, 1, 16, 2, 8),
+	FV(1, 1, 1, 2, 8), FV(1, 1, 2, 4, 8), FV(1, 1, 4, 4, 8), FW(1, 1, 32, 4, 8), FV(1, 1, 16, 4, 8),
+	FV(1, 1, 8, 4, 8), FV(1, 1, 2, 2, 8), FV(1, 1, 4, 2, 8), FV(1, 1, 8, 2, 8), FW(1, 1, 32, 2, 8),
 };
 #undef FV
+#undef FW
 constexpr int N_FOLD_VARIANTS = (int)(sizeof(fold_variants) / sizeof(fold_variants[0]));
 
 int fold_variant_count() { return N_FOLD_VARIANTS; }
 
-int fold_variant_describe(int v, int desc[5])
+int fold_variant_describe(int v, int desc[6])
 {
 	if (v < 0 || v >= N_FOLD_VARIANTS) return -1;
 	const FoldVariant &f = fold_variants[v];
-	desc[0] = f.u; desc[1] = f.r; desc[2] = f.cs; desc[3] = f.nc; desc[4] = f.nb;
+	desc[0] = f.u; desc[1] = f.r; desc[2] = f.cs; desc[3] = f.nc; desc[4] = f.nb; desc[5] = f.wv;
 	return 0;
 }
 
 static bool variant_fits(const FoldVariant &f, const Geometry &g)
 {
-	return g.m == 2 * FOLD_THREADS * f.u * f.cs && g.rows_per_slice % f.r == 0;
+	return g.m == 2 * (f.wv ? 64 : FOLD_THREADS) * f.u * f.cs && g.rows_per_slice % f.r == 0;
 }
 
 // the tiling used for `nb` blocks of this geometry: the first entry of the preference list that fits (HFDL_GPU_FOLD_TILE =
-// "U,R,CS,NC" overrides it for A/B measurements when such a variant is compiled)
+// "U,R,CS,NC[,W]" overrides it for A/B measurements when such a variant is compiled)
 static const FoldVariant *pick_variant(const Geometry &g, int nb)
 {
-	static int want[4] = { 0, 0, 0, 0 };
+	static int want[5] = { 0, 0, 0, 0, 0 };
 	static bool parsed = false;
 	if (!parsed) {
 		parsed = true;
 		if (const char *e = getenv("HFDL_GPU_FOLD_TILE"))
-			if (sscanf(e, "%d,%d,%d,%d", &want[0], &want[1], &want[2], &want[3]) != 4) want[0] = 0;
+			if (sscanf(e, "%d,%d,%d,%d,%d", &want[0], &want[1], &want[2], &want[3], &want[4]) < 4) want[0] = 0;
 	}
 	if (want[0])
 		for (const FoldVariant &f : fold_variants)
-			if (f.nb == nb && f.u == want[0] && f.r == want[1] && f.cs == want[2] && f.nc == want[3] && variant_fits(f, g)) return &f;
+			if (f.nb == nb && f.u == want[0] && f.r == want[1] && f.cs == want[2] && f.nc == want[3] && f.wv == want[4] && variant_fits(f, g)) return &f;
 	for (const FoldVariant &f : fold_variants)
 		if (f.nb == nb && variant_fits(f, g)) return &f;
 	return nullptr;

@@ -884,11 +884,11 @@ extern "C" int hfdl_gpu_frontend_fold_blocks(hfdl_gpu_frontend *fe, int64_t *blo
 
 extern "C" int hfdl_gpu_fold_variant_count(void) { return fold_variant_count(); }
 
-extern "C" int hfdl_gpu_fold_variant_describe(int variant, int32_t desc[5])
+extern "C" int hfdl_gpu_fold_variant_describe(int variant, int32_t desc[6])
 {
-	int d[5];
+	int d[6];
 	if (!desc || fold_variant_describe(variant, d)) return fail(HFDL_GPU_EINVAL, "no fold variant %d", variant);
-	for (int i = 0; i < 5; i++) desc[i] = d[i];
+	for (int i = 0; i < 6; i++) desc[i] = d[i];
 	return 0;
 }
 
@@ -900,7 +900,7 @@ extern "C" int hfdl_gpu_frontend_fold_variant_probe(hfdl_gpu_frontend *fe, int v
 	if (!fe || !avg_ms || reps < 1) return fail(HFDL_GPU_EINVAL, "bad arguments");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
-	int d[5];
+	int d[6];
 	if (fold_variant_describe(variant, d)) return fail(HFDL_GPU_EINVAL, "no fold variant %d", variant);
 	if (d[4] > fe->half_blocks) return fail(HFDL_GPU_ERANGE, "variant folds %d blocks, a half holds %d", d[4], fe->half_blocks);
 	const Geometry &g = fe->geo;

@@ -83,7 +83,7 @@ int launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, s
 		int nb, int nb_max, hipStream_t st, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // measurement aid (profiles/fold_variants.py): the compiled register tilings; launch one of them on `nb` spectra
 int fold_variant_count();
-int fold_variant_describe(int variant, int desc[5]);            // U, R, CS, NC, NB
+int fold_variant_describe(int variant, int desc[6]);            // U, R, CS, NC, NB, WV
 int launch_fold_variant(int variant, const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial,
 		size_t partial_stride, hipStream_t st, hipEvent_t start, hipEvent_t stop);
 hipError_t prepare_ifft_nco(int m);     // LDS attribute of the inverse-FFT kernel for this size (checked at create time)

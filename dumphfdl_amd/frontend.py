@@ -69,11 +69,11 @@ EXPORTS = [
 
 
 def fold_variants():
-    """The fold kernel's compiled register tilings: [(U, R, CS, NC, NB)] (measurement aid)."""
+    """The fold kernel's compiled register tilings: [(U, R, CS, NC, NB, WV)] (measurement aid)."""
     L = load()
     out = []
     for v in range(L.hfdl_gpu_fold_variant_count()):
-        d = (C.c_int32 * 5)()
+        d = (C.c_int32 * 6)()
         _check(L.hfdl_gpu_fold_variant_describe(v, C.byref(d)))
         out.append(tuple(d))
     return out
@@ -120,7 +120,7 @@ def load():
     L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_demod_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_fold_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
-    L.hfdl_gpu_fold_variant_describe.argtypes = [C.c_int, C.POINTER(C.c_int32 * 5)]
+    L.hfdl_gpu_fold_variant_describe.argtypes = [C.c_int, C.POINTER(C.c_int32 * 6)]
     L.hfdl_gpu_frontend_fold_variant_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_frontend_stream_read_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]

@@ -233,11 +233,11 @@ int  hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what, int32_t c
 int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
 int  hfdl_gpu_frontend_fold_blocks(hfdl_gpu_frontend *fe, int64_t *blocks);
 /* measurement aids (profiles/fold_variants.py): the register tilings of the fold kernel compiled into the library --
- * desc = { float4 per thread and row, rows per trip, column split, channels per workgroup, blocks per launch } -- and `reps` timed
+ * desc = { float4 per thread and row, rows per trip, column split, channels per thread, blocks per launch, waves over channels } -- and `reps` timed
  * launches of one of them over the front end's resident taps and the spectra of its last blocks; *checksum sums the bit patterns
  * of the partial sums (equal for bit-identical tilings of the same block count) */
 int  hfdl_gpu_fold_variant_count(void);
-int  hfdl_gpu_fold_variant_describe(int variant, int32_t desc[5]);
+int  hfdl_gpu_fold_variant_describe(int variant, int32_t desc[6]);
 int  hfdl_gpu_frontend_fold_variant_probe(hfdl_gpu_frontend *fe, int variant, int reps, double *avg_ms, double *best_ms, uint64_t *checksum);
 int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
 /* the same for the demodulator kernel (the kernel that bounds the small geometries), from its dispatch's own start / stop events;

@@ -31,8 +31,8 @@ for b in range(8):      # eight spectra into the half (no sync in between: they 
     fe.push_block(dev.data_ptr() + 8 * b * g.input_size)
 fe.poll_pdus()
 rows, ref = [], {}
-for v, (u, r, cs, nc, nb) in enumerate(F.fold_variants()):
-    if g.fft_inv_size != 512 * u * cs:
+for v, (u, r, cs, nc, nb, wv) in enumerate(F.fold_variants()):
+    if g.fft_inv_size != (128 if wv else 512) * u * cs:
         continue
     try:
         avg, best, chk = fe.fold_variant_probe(v, reps)
@@ -41,7 +41,7 @@ for v, (u, r, cs, nc, nb) in enumerate(F.fold_variants()):
         continue
     ref.setdefault(nb, None)
     byt = bench.alg_bytes_per_launch(g, nb)
-    rows.append(dict(variant=v, U=u, R=r, CS=cs, NC=nc, NB=nb, avg_ms=avg, best_ms=best, ms_per_block=avg / nb, GBs=byt / (avg * 1e-3) / 1e9,
+    rows.append(dict(variant=v, WV=wv, U=u, R=r, CS=cs, NC=nc, NB=nb, avg_ms=avg, best_ms=best, ms_per_block=avg / nb, GBs=byt / (avg * 1e-3) / 1e9,
                      frac=byt / (avg * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, checksum=chk))
 # bit identity: block 0 .. NB-1 of every tiling with the same NB must give the same partial sums
 first = {}
@@ -51,10 +51,10 @@ for r_ in rows:
 print("# fold kernel tilings on %s (M = %d, %d channels, %d slices x %d alias rows; %d launches each after one untimed)" %
       (wl, g.fft_inv_size, g.channels, g.fold_slices, g.pre_decimation // g.fold_slices, reps))
 print()
-print("| U | R | CS | NC | NB | ms / launch (avg) | best | ms / block | algorithmic GB/s | of 8 TB/s | same bits as first NB tiling |")
-print("|---|---|---|---|---|---|---|---|---|---|---|")
+print("| W | U | R | CS | NC | NB | ms / launch (avg) | best | ms / block | algorithmic GB/s | of 8 TB/s | same bits as first NB tiling |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 for r_ in rows:
-    print("| %d | %d | %d | %d | %d | %.3f | %.3f | %.3f | %.0f | %.3f | %s |" % (r_["U"], r_["R"], r_["CS"], r_["NC"], r_["NB"], r_["avg_ms"], r_["best_ms"],
+    print("| %d | %d | %d | %d | %d | %d | %.3f | %.3f | %.3f | %.0f | %.3f | %s |" % (r_["WV"], r_["U"], r_["R"], r_["CS"], r_["NC"], r_["NB"], r_["avg_ms"], r_["best_ms"],
                                                                              r_["ms_per_block"], r_["GBs"], r_["frac"], "yes" if r_["bit_identical_to_first_of_NB"] else "NO"))
 print()
 print("```json")

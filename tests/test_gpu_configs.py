@@ -108,7 +108,9 @@ def test_two_rank_bench_on_one_gpu():
     assert abs(r["value"] * 1e6 * (r["ms_per_step"] * 16e-3) - samples) < 1e-6 * samples
     assert r["pdus_in_timed_region"] > 0
     assert r["pdus_matching_sent_payload"] == r["pdus_in_timed_region"]
-    assert r["roofline"]["launches"] == 16 and 0.05 < r["roofline"]["frac"] < 1.0
+    # 16 timed blocks per rank, folded fold_batch at a time (one pass over the filter taps per launch)
+    assert r["roofline"]["launches"] * r["roofline"]["blocks_per_launch"] == pytest.approx(16) and r["roofline"]["blocks_per_launch"] >= 2
+    assert 0.05 < r["roofline"]["frac"] < 1.0
     assert "cpu_baseline" not in r                       # rank 0 at N = 1 only
     # every rank's own numbers, in rank order: a straggler shows here, not only in the max
     pr = r["per_rank"]
