@@ -49,9 +49,9 @@ __device__ __forceinline__ void cmac2(v4f &a, const v4f h, const v4f x)
 // waves per SIMD the register tile allows (512 VGPRs per lane and SIMD).  Told to the compiler: with a bare __launch_bounds__(256) it
 // aims at 8 waves per SIMD, squeezes the kernel into 64 VGPRs and gets there by issuing a load or two, waiting, multiplying, loading
 // again -- one or two kilobytes in flight per wave where the trip has eight or more to ask for at once.
-constexpr int fold_waves(int u, int r, int nc, int nb)
+constexpr int fold_waves(int u, int r, int nc, int nb, bool lds = false)
 {
-	const int regs = 4 * (nb * nc * u + nc * r * u + nb * r * u) + 24;
+	const int regs = 4 * (nb * nc * u + nc * r * u + nb * r * u) + (lds ? 16 : 24);
 	return regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
 }
 
@@ -120,6 +120,115 @@ __global__ __launch_bounds__(FOLD_THREADS) __attribute__((amdgpu_waves_per_eu(fo
 				for (int u = 0; u < U; u++) po[u * LANES] = acc[b][k][u];
 			}
 	}
+}
+
+// The same fold with the block spectra staged through LDS.  With NB blocks per launch every tap byte out of HBM wants NB / NC
+// spectrum bytes out of L2, and the vector memory path (one 64-byte lane group per clock and CU, whatever level answers) is what
+// bounds the launch from NB / NC = 1 up (profiles/r04_fold_variants.md: 2.5 ms at 0.5, 3.1 at 1, 4.3 at 2, 6 at 4).  Here the WPW
+// wavefronts of a workgroup cover the SAME 64 * U columns and WPW different groups of NC channels: each alias row's spectrum tile
+// (NB blocks x 64 * U columns) is fetched ONCE per workgroup -- every wave loads 1 / WPW of it -- written to LDS and read from
+// there by all of them (ds_read_b128: 256 B per clock and CU, four times the vector memory path), so the spectrum costs
+// NB / (WPW * NC) of the tap traffic.  Two LDS stages: the tile of trip t + 1 is fetched into registers while trip t is multiplied,
+// stored to the other stage at the end of the trip, one workgroup barrier per trip.  Same FMA chain per bin as fold_kernel.
+template <int U, int R, int NC, int NB, int WPW>
+__global__ __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(fold_waves(U, R, NC, NB, true), fold_waves(U, R, NC, NB, true)))) void fold_kernel_lds(
+		const float4 *__restrict__ taps, const float4 *__restrict__ spec,
+		float4 *__restrict__ partial, size_t chan_stride4, size_t row_stride4, size_t spec_stride4, size_t partial_stride4,
+		int m, int slices, int rows, int c_base)
+{
+	constexpr int PIECES = NB * R * U;                         // 1 KiB wave-loads per spectrum tile
+	constexpr int MINE = (PIECES + WPW - 1) / WPW;              // ... and this wave's share
+	__shared__ v4f tile[2][PIECES][64];
+	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row of the spectrum
+	const int cs = row4 / (64 * U);                           // column parts per row
+	const int cpart = blockIdx.x % cs;
+	const int bs = blockIdx.x / cs;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+	const int s = bs % slices, c0 = c_base + ((bs / slices) * WPW + wave) * NC;
+	const size_t col = (size_t)cpart * U * 64 + lane;
+	const unsigned voff = (unsigned)lane * 16u;
+	const char *tb = (const char *)(taps + (size_t)c0 * chan_stride4 + (size_t)s * rows * row_stride4 + (size_t)cpart * U * 64);
+	const char *sb = (const char *)(spec + (((size_t)s * rows * (size_t)m) >> 1) + (size_t)cpart * U * 64);
+	const size_t cs_b = chan_stride4 * 16, rs_b = row_stride4 * 16, ss_b = spec_stride4 * 16, r4_b = (size_t)row4 * 16;
+	v4f acc[NB][NC][U];
+#pragma unroll
+	for (int b = 0; b < NB; b++)
+#pragma unroll
+		for (int k = 0; k < NC; k++)
+#pragma unroll
+			for (int u = 0; u < U; u++) acc[b][k][u] = (v4f)(0.f);
+	// piece p = (b, q, u) of a trip's tile; this wave fetches pieces wave, wave + WPW, ...
+	v4f xs[MINE];
+	auto fetch = [&](const char *base) {
+#pragma unroll
+		for (int i = 0; i < MINE; i++) {
+			const int p = wave + i * WPW;
+			if (PIECES % WPW == 0 || p < PIECES) {
+				const int b = p / (R * U), q = (p / U) % R, u = p % U;
+				xs[i] = *(const v4f *)(base + (size_t)b * ss_b + (size_t)q * r4_b + (size_t)voff + (size_t)(u * 64 * 16));
+			}
+		}
+	};
+	auto stash = [&](int stage) {
+#pragma unroll
+		for (int i = 0; i < MINE; i++) {
+			const int p = wave + i * WPW;
+			if (PIECES % WPW == 0 || p < PIECES) tile[stage][p][lane] = xs[i];
+		}
+	};
+	auto load_taps = [&](v4f (&h)[NC][R][U], const char *base) {
+#pragma unroll
+		for (int q = 0; q < R; q++)
+#pragma unroll
+			for (int u = 0; u < U; u++)
+#pragma unroll
+				for (int k = 0; k < NC; k++)
+					h[k][q][u] = __builtin_nontemporal_load((const v4f *)(base + (size_t)k * cs_b + (size_t)q * rs_b + (size_t)voff + (size_t)(u * 64 * 16)));
+	};
+	// One trip: ask for this wave's share of the NEXT trip's spectrum tile, then for this trip's taps (the tile answers out of L2,
+	// ahead of the taps: loads return in order); read this trip's tile from LDS; store the fetched share to the other stage; multiply
+	// as the taps arrive; barrier.  The fences keep the compiler from rotating the trip (it would issue the taps after the wait for
+	// the tile share, one load latency after the other).
+	fetch(sb);
+	stash(0);
+	__syncthreads();
+	int stage = 0;
+	for (int r = 0; r < rows; r += R) {
+		const bool more = r + R < rows;
+		v4f h[NC][R][U];
+		sb += (size_t)R * r4_b;
+		if (more) fetch(sb);
+		load_taps(h, tb);
+		asm volatile("" ::: "memory");
+		v4f x[NB][R][U];
+#pragma unroll
+		for (int q = 0; q < R; q++)
+#pragma unroll
+			for (int b = 0; b < NB; b++)
+#pragma unroll
+				for (int u = 0; u < U; u++) x[b][q][u] = tile[stage][(b * R + q) * U + u][lane];
+		if (more) stash(stage ^ 1);
+		asm volatile("" ::: "memory");
+#pragma unroll
+		for (int q = 0; q < R; q++)           // rows strictly in order: the sum over a slice's rows is the same chain in every variant
+#pragma unroll
+			for (int b = 0; b < NB; b++)
+#pragma unroll
+				for (int u = 0; u < U; u++)
+#pragma unroll
+					for (int k = 0; k < NC; k++) cmac2(acc[b][k][u], h[k][q][u], x[b][q][u]);
+		__syncthreads();
+		stage ^= 1;
+		tb += (size_t)R * rs_b;
+	}
+#pragma unroll
+	for (int b = 0; b < NB; b++)
+#pragma unroll
+		for (int k = 0; k < NC; k++) {
+			v4f *po = (v4f *)partial + (size_t)b * partial_stride4 + (((size_t)(c0 + k) * slices + s) * (size_t)m >> 1) + col;
+#pragma unroll
+			for (int u = 0; u < U; u++) po[u * 64] = acc[b][k][u];
+		}
 }
 
 // Read-only streaming probe: what this board's HBM delivers to a bare kernel doing nothing but non-temporal 16-byte loads
@@ -208,31 +317,68 @@ static int fold_go(const FoldArgs &a)
 	return launches;
 }
 
+template <int U, int R, int NC, int NB, int WPW>
+static int fold_go_lds(const FoldArgs &a)
+{
+	constexpr int GC = WPW * NC;                          // channels per workgroup
+	const int cs = (a.m >> 1) / (64 * U);
+	constexpr int RU = U >= 4 ? U / 4 : 1;                  // the channels left over: single-channel workgroups of the plain kernel
+	const int groups = a.nch / GC, rest = a.nch - groups * GC;
+	int launches = 0;
+	if (groups > 0) {
+		hipExtLaunchKernelGGL((fold_kernel_lds<U, R, NC, NB, WPW>), dim3((unsigned)(groups * a.slices * cs)), dim3(64 * WPW), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
+			a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, 0);
+		launches++;
+	}
+	if (rest > 0) {
+		const int rcs = a.m / (2 * FOLD_THREADS * RU);
+		auto go = [&](auto kern, int cs_) {
+			hipExtLaunchKernelGGL(kern, dim3((unsigned)(rest * a.slices * cs_)), dim3(FOLD_THREADS), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+				a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, groups * GC);
+		};
+		switch (rcs) {          // CS is a template argument of the plain kernel
+		case 1: go(fold_kernel<RU, 1, 1, 1, NB, false>, 1); break;
+		case 2: go(fold_kernel<RU, 1, 2, 1, NB, false>, 2); break;
+		case 4: go(fold_kernel<RU, 1, 4, 1, NB, false>, 4); break;
+		case 8: go(fold_kernel<RU, 1, 8, 1, NB, false>, 8); break;
+		default: go(fold_kernel<RU, 1, 16, 1, NB, false>, 16); break;
+		}
+		launches++;
+	}
+	return launches;
+}
+
 struct FoldVariant { int u, r, cs, nc, nb, wv; int (*go)(const FoldArgs &); };
 #define FV(U, R, CS, NC, NB) { U, R, CS, NC, NB, 0, fold_go<U, R, CS, NC, NB, false> }
 #define FW(U, R, CS, NC, NB) { U, R, CS, NC, NB, 1, fold_go<U, R, CS, NC, NB, true> }
+// LDS-staged spectra: wv = 2 + waves per workgroup; `cs` is left 0 (the column split follows from M: M / (128 U) parts)
+#define FL(U, R, NC, NB, WPW) { U, R, 0, NC, NB, 2 + WPW, fold_go_lds<U, R, NC, NB, WPW> }
 // A row of M bins = U * CS * 512 (FV) or U * CS * 128 (FW: waves over channels).  Measured on cfg3 (M = 4096) with
 // profiles/fold_variants.py: profiles/r04_fold_variants.md.
 // What paid at one block per launch (profiles/r01_experiments.md): non-temporal tap loads (+7 %) and TWO channels per workgroup
 // sharing every spectrum load (+14 %: halves the L2 -> L1 spectrum traffic).  With NB blocks per launch the spectrum traffic is
 // NB / NC times the tap traffic, so the tile trades registers between the two (acc = 4 * NB * NC * U VGPRs).
 static const FoldVariant fold_variants[] = {
-	// the first entry of a block count that fits the geometry is the one used; the rest are kept for profiles/fold_variants.py
+	// The first entry of a block count that fits the geometry is the one used; the rest are kept for profiles/fold_variants.py
+	// (measured on cfg3, M = 4096: profiles/r04_fold_variants.md).
 	// one block per launch, M = 512 .. 8192: the round-1 tilings
 	FV(1, 1, 1, 2, 1), FV(1, 1, 2, 2, 1), FV(2, 1, 2, 2, 1), FV(4, 1, 2, 2, 1), FV(8, 1, 2, 2, 1),
-	FV(4, 2, 2, 2, 1), FW(4, 1, 8, 2, 1),
+	FV(4, 2, 2, 2, 1), FW(4, 1, 8, 2, 1), FL(4, 1, 4, 1, 4), FL(4, 1, 2, 1, 8),
 	// two blocks
 	FV(1, 1, 1, 2, 2), FV(1, 1, 2, 2, 2), FV(1, 1, 4, 4, 2), FV(2, 1, 4, 4, 2), FV(4, 1, 4, 2, 2),
-	FV(4, 1, 2, 2, 2), FV(2, 1, 2, 2, 2), FW(2, 1, 16, 4, 2), FV(1, 1, 8, 4, 2), FV(1, 1, 8, 8, 2),
-	// four blocks
+	FV(4, 1, 2, 2, 2), FW(2, 1, 16, 4, 2), FV(1, 1, 8, 8, 2), FL(4, 1, 2, 2, 4), FL(2, 2, 2, 2, 8),
+	// four blocks: spectra through LDS where the slices are long enough (16 channels per workgroup), register tiles otherwise
+	FL(2, 1, 4, 4, 4),
 	FV(1, 1, 1, 2, 4), FV(1, 1, 2, 4, 4), FV(1, 1, 4, 8, 4), FV(1, 1, 8, 8, 4), FV(2, 1, 8, 4, 4),
-	FV(1, 1, 2, 2, 4), FV(1, 1, 4, 4, 4), FV(2, 1, 4, 4, 4), FV(1, 1, 8, 4, 4), FW(2, 1, 16, 4, 4), FW(1, 1, 32, 4, 4), FW(1, 1, 32, 8, 4), FV(2, 1, 2, 2, 4),
+	FL(1, 1, 4, 4, 8), FL(2, 1, 2, 4, 8), FL(1, 1, 4, 4, 4), FL(2, 1, 4, 4, 8), FV(2, 1, 4, 4, 4), FW(1, 1, 32, 8, 4), FW(2, 1, 16, 4, 4),
 	// eight blocks
+	FL(1, 1, 4, 8, 4),
 	FV(1, 1, 1, 2, 8), FV(1, 1, 2, 4, 8), FV(1, 1, 4, 4, 8), FW(1, 1, 32, 4, 8), FV(1, 1, 16, 4, 8),
-	FV(1, 1, 8, 4, 8), FV(1, 1, 2, 2, 8), FV(1, 1, 4, 2, 8), FV(1, 1, 8, 2, 8), FW(1, 1, 32, 2, 8),
+	FL(1, 1, 4, 8, 8), FL(1, 1, 2, 8, 8), FL(1, 2, 4, 8, 8), FL(1, 1, 2, 8, 4), FV(1, 1, 8, 4, 8), FV(1, 1, 8, 2, 8),
 };
 #undef FV
 #undef FW
+#undef FL
 constexpr int N_FOLD_VARIANTS = (int)(sizeof(fold_variants) / sizeof(fold_variants[0]));
 
 int fold_variant_count() { return N_FOLD_VARIANTS; }
@@ -247,6 +393,9 @@ int fold_variant_describe(int v, int desc[6])
 
 static bool variant_fits(const FoldVariant &f, const Geometry &g)
 {
+	// LDS-staged spectra: any M that is a multiple of the workgroup's 128 U bins, at least one full group of channels, and slices long
+	// enough for the two-stage pipeline to matter (the small geometries' 16-row slices keep the register tiles)
+	if (f.wv >= 2) return g.m % (128 * f.u) == 0 && g.rows_per_slice % f.r == 0 && g.rows_per_slice >= 64 * f.r && g.nch >= (f.wv - 2) * f.nc;
 	return g.m == 2 * (f.wv ? 64 : FOLD_THREADS) * f.u * f.cs && g.rows_per_slice % f.r == 0;
 }
 

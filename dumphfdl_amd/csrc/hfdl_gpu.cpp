@@ -251,7 +251,9 @@ static int pick_demod_batch(const hfdl_gpu_frontend *fe)
 // or syncs after every block (live input) still gets one launch per block: a sync / poll closes the half as it is.
 static int pick_fold_batch()
 {
-	int want = 4;
+	// 8: measured on cfg3 (profiles/r04_experiments.md) -- a launch of 8 takes 3.4 ms against 2.6 for 4 and 2.5 for 1; beyond that the
+	// multiplies (4 FMAs per tap and block) cost as much as the taps' HBM time and the register tile (acc[NB][NC]) runs out
+	int want = 8;
 	if (const char *e = getenv("HFDL_GPU_FOLD_BATCH")) {        // A/B measurements; 1 = a pass over the taps per block
 		const long v = strtol(e, nullptr, 10);
 		if (v >= 1 && v <= hfdl_gpu_frontend::MAX_HALF) want = (int)v;

@@ -366,21 +366,34 @@ struct input_cfg *input_cfg_create(void)
 
 void input_cfg_destroy(struct input_cfg *cfg) { free(cfg); }
 
-static struct input_vtable const *g_vtables[INPUT_TYPE_MAX];
+/* The inputs this library knows, whatever the caller's enum calls them.  The reference's input_type numbering depends on the host
+ * program's WITH_SOAPYSDR (src/input-common.h:8-15): INPUT_TYPE_FILE is 1 without it, 2 with it.  This file is compiled without;
+ * include/hfdl_host.h binds a WITH_SOAPYSDR caller to the *_with_soapysdr entry points below. */
+enum input_kind { KIND_NONE = 0, KIND_FILE, KIND_SOAPYSDR, KIND_MAX };
+static struct input_vtable const *g_vtables[KIND_MAX];
 
-int32_t input_vtable_register(input_type type, struct input_vtable const *vtable)
+static enum input_kind kind_of(int type, bool caller_has_soapysdr)
 {
-	if (type <= INPUT_TYPE_UNDEF || type >= INPUT_TYPE_MAX || vtable == NULL) return -1;
+	if (caller_has_soapysdr) return type == 1 ? KIND_SOAPYSDR : type == 2 ? KIND_FILE : KIND_NONE;
+	return type == INPUT_TYPE_FILE ? KIND_FILE : KIND_NONE;
+}
+
+static int32_t vtable_register(enum input_kind kind, struct input_vtable const *vtable)
+{
+	if (kind == KIND_NONE || vtable == NULL) return -1;
 	if (vtable->create == NULL || vtable->init == NULL || vtable->destroy == NULL || vtable->rx_thread_routine == NULL) return -1;
-	g_vtables[type] = vtable;
+	g_vtables[kind] = vtable;
 	return 0;
 }
 
-static struct input_vtable const *input_vtable_get(input_type type)
+int32_t input_vtable_register(input_type type, struct input_vtable const *vtable) { return vtable_register(kind_of((int)type, false), vtable); }
+int32_t input_vtable_register_with_soapysdr(int type, struct input_vtable const *vtable) { return vtable_register(kind_of(type, true), vtable); }
+
+static struct input_vtable const *input_vtable_get(enum input_kind kind)
 {
-	if (type <= INPUT_TYPE_UNDEF || type >= INPUT_TYPE_MAX) return NULL;
-	if (g_vtables[type] != NULL) return g_vtables[type];
-	return type == INPUT_TYPE_FILE ? &file_vtable : NULL;          /* SoapySDR: only if the host program registered it */
+	if (kind == KIND_NONE) return NULL;
+	if (g_vtables[kind] != NULL) return g_vtables[kind];
+	return kind == KIND_FILE ? &file_vtable : NULL;                /* SoapySDR: only if the host program registered it */
 }
 
 int hfdl_file_input_raw_format(const struct block *source)
@@ -390,10 +403,9 @@ int hfdl_file_input_raw_format(const struct block *source)
 	return in->config ? (int)in->config->sfmt : SFMT_CF32;
 }
 
-struct block *input_create(struct input_cfg *cfg)
+static struct block *create_of_kind(struct input_cfg *cfg, enum input_kind kind)
 {
-	if (cfg == NULL) return NULL;
-	struct input_vtable const *vt = input_vtable_get(cfg->type);
+	struct input_vtable const *vt = input_vtable_get(kind);
 	if (vt == NULL) return NULL;
 	struct input *in = vt->create(cfg);
 	if (in == NULL) return NULL;
@@ -405,6 +417,9 @@ struct block *input_create(struct input_cfg *cfg)
 	in->block.thread_routine = vt->rx_thread_routine;
 	return &in->block;
 }
+
+struct block *input_create(struct input_cfg *cfg) { return cfg ? create_of_kind(cfg, kind_of((int)cfg->type, false)) : NULL; }
+struct block *input_create_with_soapysdr(struct input_cfg *cfg) { return cfg ? create_of_kind(cfg, kind_of((int)cfg->type, true)) : NULL; }
 
 int32_t input_init(struct block *block)
 {

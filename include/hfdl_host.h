@@ -97,9 +97,24 @@ size_t hfdl_ring_read(struct hfdl_ring *r, float complex *dst, size_t n);       
 
 /* ------------------------------------------------------------------ inputs (src/input-common.h, input-helpers.h) */
 
-/* INPUT_TYPE_SOAPYSDR is the reference's optional radio input (src/input-common.h:8-15, built WITH_SOAPYSDR): this library
- * carries no SoapySDR code, the slot is filled by the host program with input_vtable_register() */
-typedef enum { INPUT_TYPE_UNDEF, INPUT_TYPE_SOAPYSDR, INPUT_TYPE_FILE, INPUT_TYPE_MAX } input_type;
+/* The reference's enum, conditional member included (src/input-common.h:8-15): INPUT_TYPE_FILE is 1 in a default build of the
+ * host program and 2 when it is built WITH_SOAPYSDR.  This library carries no SoapySDR code: in a WITH_SOAPYSDR build the slot is
+ * filled by the host program with input_vtable_register(INPUT_TYPE_SOAPYSDR, &soapysdr_input_vtable). */
+typedef enum {
+	INPUT_TYPE_UNDEF,
+#ifdef WITH_SOAPYSDR
+	INPUT_TYPE_SOAPYSDR,
+#endif
+	INPUT_TYPE_FILE,
+	INPUT_TYPE_MAX
+} input_type;
+/* libhfdl_host.so is ONE binary for both builds of the host program.  The two entry points that interpret an input_type value bind,
+ * through these names, to the symbol that reads the caller's numbering -- a host program compiled against dumphfdl's own
+ * input-common.h (either way) and this library agree on what cfg->type means. */
+#ifdef WITH_SOAPYSDR
+#define input_create          input_create_with_soapysdr
+#define input_vtable_register input_vtable_register_with_soapysdr
+#endif
 typedef enum { SFMT_UNDEF = 0, SFMT_CU8, SFMT_CS16, SFMT_CF32, SFMT_MAX } sample_format;
 
 struct input_cfg {
@@ -130,10 +145,10 @@ struct input {
 	int32_t bytes_per_sample;
 };
 
-/* Plug an input implementation into input_create()'s switch (input_vtable_get, src/input-common.c:12-25): dumphfdl's
+/* Plug an input implementation into input_create()'s table (input_vtables[], src/input-common.c:12-18): dumphfdl's
  * soapysdr_input_vtable registers under INPUT_TYPE_SOAPYSDR unchanged -- its rx thread only needs complex_samples_produce()
- * and the block fields.  Returns 0, or -1 for a type outside the enum / a NULL or incomplete table.  Not in the reference
- * (which selects at compile time). */
+ * and the block fields.  Returns 0, or -1 for a type outside the caller's enum / a NULL or incomplete table.  Not in the reference
+ * (which fills the table at compile time). */
 int32_t input_vtable_register(input_type type, struct input_vtable const *vtable);
 
 struct input_cfg *input_cfg_create(void);

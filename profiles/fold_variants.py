@@ -32,7 +32,10 @@ for b in range(8):      # eight spectra into the half (no sync in between: they 
 fe.poll_pdus()
 rows, ref = [], {}
 for v, (u, r, cs, nc, nb, wv) in enumerate(F.fold_variants()):
-    if g.fft_inv_size != (128 if wv else 512) * u * cs:
+    if wv >= 2:                     # LDS-staged spectra, wv - 2 waves per workgroup: any M that is a multiple of 128 U
+        if g.fft_inv_size % (128 * u) or g.channels < (wv - 2) * nc:
+            continue
+    elif g.fft_inv_size != (128 if wv else 512) * u * cs:
         continue
     try:
         avg, best, chk = fe.fold_variant_probe(v, reps)

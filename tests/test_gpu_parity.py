@@ -859,8 +859,8 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
         bursts = synth.plan_traffic(freqs, dur, seed=31, dense=True, gap_s=0.12, amp=(0.02, 0.1))
     else:
         freqs = [int(cf + (i - nch // 2) * 15_000 + 4_000) for i in range(nch)]
-        dur = 2.6
-        bursts = [dict(freq=freqs[c], mode=int(rng.integers(0, 4)), octets=b"", t0=float(rng.uniform(0.1, 0.5)), amp=0.03, cfo=float(rng.uniform(-10, 10)))
+        dur = 3.7               # 19 blocks; a single-slot burst lasts 2.5 s
+        bursts = [dict(freq=freqs[c], mode=int(rng.integers(0, 4)), octets=b"", t0=float(rng.uniform(0.1, 0.7)), amp=0.03, cfo=float(rng.uniform(-10, 10)))
                   for c in (0, 3, 64, 77, 128, 129)]
         for b in bursts:
             b["octets"] = synth.make_pdu(rng, b["mode"])

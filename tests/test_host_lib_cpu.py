@@ -13,7 +13,8 @@ PKG = os.path.join(ROOT, "dumphfdl_amd")
 def host_check(tmp_path_factory):
     subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "host")])
     exe = str(tmp_path_factory.mktemp("hc") / "host_check")
-    subprocess.check_call(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "host"),
+    # built as dumphfdl is WITH_SOAPYSDR: the radio slot exists (tests/test_host_abi_cpu.py runs both numberings)
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", "-DWITH_SOAPYSDR", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "host"),
                            os.path.join(ROOT, "tests", "hostsim", "host_check.c"), "-o", exe,
                            "-L", PKG, "-lhfdl_host", "-lhfdl_gpu", "-Wl,-rpath," + PKG, "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-lm"])
     return exe
