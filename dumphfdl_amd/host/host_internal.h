@@ -34,7 +34,9 @@ size_t hfdl_frontend_block_samples(const struct block *sink);      /* input_size
 int    hfdl_file_input_raw_format(const struct block *source);     /* the file's sample_format if `source` is the file input, else SFMT_CF32 */
 
 /* the entry points a WITH_SOAPYSDR host program is bound to (include/hfdl_host.h): the caller's numbering has the radio slot at 1 */
+#ifndef WITH_SOAPYSDR       /* (a WITH_SOAPYSDR unit already sees them under their public names) */
 struct block *input_create_with_soapysdr(struct input_cfg *cfg);
 int32_t input_vtable_register_with_soapysdr(int type, struct input_vtable const *vtable);
+#endif
 
 #define container_of(ptr, type, member) ((type *)((char *)(ptr) - offsetof(type, member)))
