@@ -389,16 +389,39 @@ def host_path_leg(w, x, freqs, fmt="CF32", dev_index=0, seconds_cap=120):
             pass
 
 
-def traffic_record(workload):
+def csrc_hash():
+    """sha256 (16 hex digits) over the device sources, dumphfdl_amd/csrc/*.{hip,h,cpp} in name order: identifies the kernels a
+    measurement was made with (profiles/fold_traffic.py stamps it into the traffic record; this run compares it with its own tree)."""
+    import hashlib
+    d = os.path.join(ROOT, "dumphfdl_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_record(workload, blocks_per_launch=None):
     """HBM bytes per fold launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs, corrected as the
-    MI355X guide prescribes): a bench run cannot collect counters itself, so the line names where the figure comes from."""
+    MI355X guide prescribes): a bench run cannot collect counters itself, so the line names where the figure comes from -- and
+    whether the kernels it was measured on are the ones this run executes (csrc_matches_head) at this run's blocks per launch.
+    A record that fails either check is reported as stale and `traffic` is null."""
     tfile = os.path.join(ROOT, "profiles", "fold_traffic_%s.json" % workload)
     if not os.path.exists(tfile):
         return None, None
     try:
         t = json.load(open(tfile))
-        return t.get("hbm_bytes_per_launch"), dict(file="profiles/fold_traffic_%s.json" % workload, measured_at_commit=t.get("measured_at_commit"),
-                                                  collected_by=t.get("command"), note="replayed from that file, not observed by this run")
+        now = csrc_hash()
+        same_code = t.get("csrc_sha16") == now
+        same_shape = blocks_per_launch is None or t.get("blocks_per_launch") is None or abs(t["blocks_per_launch"] - blocks_per_launch) < 1e-9
+        src = dict(file="profiles/fold_traffic_%s.json" % workload, measured_at_commit=t.get("measured_at_commit"),
+                   csrc_sha16_at_measurement=t.get("csrc_sha16"), csrc_sha16_now=now, csrc_matches_head=bool(same_code),
+                   blocks_per_launch_at_measurement=t.get("blocks_per_launch"), kernel=t.get("kernel"),
+                   collected_by=t.get("command"), note="replayed from that file, not observed by this run")
+        if not (same_code and same_shape):
+            src["stale"] = "the record was measured on other device code or another launch shape: traffic withheld"
+            return None, src
+        return t.get("hbm_bytes_per_launch"), src
     except Exception:
         return None, None
 
@@ -616,6 +639,26 @@ def main():
     x, bursts = make_input(w, g.input_size, rank, world, args.shard)
     my_seed = shard.stream_seed(w["seed"], rank, world) if args.shard == "streams" else w["seed"]
     t_gen = time.time() - t0
+    # A rank whose set-up crawls (eight front ends designing filter taps on one host's cores, eight syntheses behind one lock) would
+    # otherwise surface as a barrier time-out minutes later: every rank learns the slowest rank's times, and the job stops with a message.
+    budget = float(os.environ.get("HFDL_BENCH_SETUP_BUDGET_S", "600"))
+    worst_create, worst_gen = (t_create, t_gen)
+    if use_dist is not None:
+        t = torch.tensor([t_create, t_gen], dtype=torch.float64, device=red_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        worst_create, worst_gen = float(t[0]), float(t[1])
+    if worst_create + worst_gen > budget:
+        if rank == 0:
+            sys.stderr.write("bench.py: set-up took %.0f s on the slowest rank (front end %.0f s + input synthesis %.0f s), over the %.0f s budget "
+                             "(HFDL_BENCH_SETUP_BUDGET_S): not starting the timed region. Fewer ranks per host, or more host cores per rank "
+                             "(HFDL_GPU_HOST_THREADS), bring it down; profiles/r04_setup_time.json has the single-rank figures.\n"
+                             % (worst_create + worst_gen, worst_create, worst_gen, budget))
+        fe.close()
+        if use_dist is not None:
+            with stdout_to_stderr():
+                dist.barrier()
+                dist.destroy_process_group()
+        raise SystemExit(3)
     nblocks = len(x) // g.input_size
     bursts_by_freq = {}
     for b in bursts:
@@ -692,7 +735,7 @@ def main():
     if rank == 0:
         samples = total_samples
         achieved = alg_bytes / (fold_avg_ms * 1e-3) / 1e9 if fold_n else None
-        traffic, traffic_src = traffic_record(args.workload)
+        traffic, traffic_src = traffic_record(args.workload, fold_nb)
         par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, geom["channels"])) if args.shard == "streams" else \
               ("ONE %d-channel stream, channels round-robin over %d GPUs (%d on rank 0), every GPU ingests the same block; no collectives"
                % (len(all_freqs), world, geom["channels"]))

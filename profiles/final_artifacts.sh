@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the measured artefacts kept under profiles/ (run through gpurun; results land in gpurun_out/final/).
 #   bash profiles/final_artifacts.sh [commit]
-C=${1:-$(cat /root/repo/profiles/scripts/commit.txt 2>/dev/null || echo unknown)}
+C=${1:-$(python -c "import json; print(json.load(open('/root/repo/profiles/scripts/stamp.json'))['commit'])" 2>/dev/null || echo unknown)}
 OUT=/root/repo/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd /root/repo

@@ -1,15 +1,32 @@
 #!/usr/bin/env python3
 """fold_traffic_<workload>.json from the rocprofv3 --pmc databases of profiles/pmc_passes.sh: HBM bytes per fold launch, with the
-gfx950 FETCH_SIZE correction calibrated on the stream-read probe kernel of the same run (it reads a known number of bytes)."""
+gfx950 FETCH_SIZE correction calibrated on the stream-read probe kernel of the same run (it reads a known number of bytes).
+
+A fold launch serves NB queued blocks with one pass over the filter taps: NB is read from the kernel's template
+arguments, the algorithmic bytes are bench.alg_bytes_per_launch(g, NB).  The record carries a hash of dumphfdl_amd/csrc as it was when
+the counters were collected: bench.py compares it with the tree it runs from (roofline.traffic_source.csrc_matches_head), and this
+script REFUSES to stamp a commit whose csrc differs from the working tree's."""
 import json
 import os
+import re
 import sqlite3
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 wl, commit, dbs = sys.argv[1], sys.argv[2], sys.argv[3:]
+csrc_now = bench.csrc_hash()
+# the commit being stamped must be the code that ran: profiles/stamp.sh (run where git is, refuses a dirty csrc) left the commit and the
+# hash of its device sources; the tree this script runs from must hash the same
+try:
+    stamp = json.load(open(os.path.join(ROOT, "profiles", "scripts", "stamp.json")))
+except Exception:
+    sys.exit("fold_traffic.py: no profiles/scripts/stamp.json -- run profiles/stamp.sh on a clean csrc before collecting")
+if stamp.get("csrc_sha16") != csrc_now or (commit not in ("", "unknown") and commit != stamp.get("commit")):
+    sys.exit("fold_traffic.py: refusing to stamp commit %s: stamped %s with csrc %s, running tree has %s" % (commit, stamp.get("commit"), stamp.get("csrc_sha16"), csrc_now))
+commit = stamp["commit"]
 vals = {}
 for db in dbs:
     cur = sqlite3.connect(db).cursor()
@@ -19,12 +36,22 @@ for db in dbs:
 w = bench.WORKLOADS[wl]
 import dumphfdl_amd as hf  # noqa: E402
 g = hf.plan_geometry(4096 if w["fs"] == 40_000_000 else 1024, 250 / w["fs"])
-nch = w["nch"]
-alg = 8 * g.input_size + nch * 8 * g.fft_size + nch * 8 * (g.post_input_size // g.post_decimation)
-fold = [k for k in vals if "fold_kernel<" in k[0] and k[1] == "FETCH_SIZE"]
+g.channels = w["nch"]
+
+
+def blocks_of(kernel):
+    """NB from the template arguments: fold_kernel<U, R, CS, NC, NB, WV>, fold_kernel_lds<U, R, NC, NB, WPW>"""
+    a = [x.strip() for x in re.search(r"<(.*)>", kernel).group(1).split(",")]
+    return int(a[3]) if "fold_kernel_lds" in kernel else int(a[4])
+
+
+fold = [(k, v) for k, v in vals.items() if re.search(r"fold_kernel(_lds)?<", k[0]) and k[1] == "FETCH_SIZE"]
 assert fold, "no fold kernel in the FETCH_SIZE pass"
-fname = fold[0][0]
-probe_bytes = min(nch * 8 * g.fft_size // (4 << 20) * (4 << 20), 16 << 30)
+# the launch shape that moved the most bytes in the run: the full batches of the timed region
+fname = max(fold, key=lambda kv: kv[1][0] * kv[1][1])[0][0]
+nb = blocks_of(fname)
+alg = bench.alg_bytes_per_launch(g, nb)
+probe_bytes = min(w["nch"] * 8 * g.fft_size // (4 << 20) * (4 << 20), 16 << 30)
 probe = [v[1] for k, v in vals.items() if "stream_read_kernel" in k[0] and k[1] == "FETCH_SIZE"]
 corr = probe_bytes / (1024.0 * (sum(probe) / len(probe))) if probe else 2.0
 fetch_kb = vals[(fname, "FETCH_SIZE")][1]
@@ -34,9 +61,11 @@ miss = vals.get((fname, "TCC_MISS_sum"), (0, 0.0))[1]
 rd, wr = fetch_kb * 1024 * corr, write_kb * 1024
 out = {
     "kernel": "hfdl::" + fname.split("hfdl::")[-1],
+    "blocks_per_launch": nb,
     "workload": "%s: %s" % (wl, w["name"]),
     "measured_at_commit": commit,
-    "command": "profiles/pmc_passes.sh %s (rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --workload %s --steps 8 --warmup 2 "
+    "csrc_sha16": csrc_now,
+    "command": "profiles/pmc_passes.sh %s (rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --workload %s --steps 32 --warmup 8 "
                "--no-cpu-baseline --no-extra-legs; second pass --pmc WRITE_SIZE; third --pmc TCC_HIT_sum TCC_MISS_sum)" % (wl, wl),
     "FETCH_SIZE_KB_raw_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
     "gfx950_fetch_correction": round(corr, 4),

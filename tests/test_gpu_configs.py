@@ -174,13 +174,13 @@ def test_poll_sequence_drain_then_snapshot(gpu):
     fe.close()
 
 
-def _run_bench(args, nproc, port, tmp_path, tag):
+def _run_bench(args, nproc, port, tmp_path, tag, backend="gloo"):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     dump = str(tmp_path / tag)
     base = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--no-cpu-baseline", "--no-extra-legs", "--dump-pdus", dump] + args
     if nproc > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-               "--master-port", str(port)] + base + ["--backend", "gloo"]
+               "--master-port", str(port)] + base + ["--backend", backend]
     else:
         cmd = [sys.executable] + base
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -206,5 +206,48 @@ def test_single_stream_channel_sharded_union_equals_unsharded(tmp_path):
     f0, f1 = {k[0] for k in k2[0]}, {k[0] for k in k2[1]}
     assert not f0 & f1                                            # channel partition
     assert sorted(k2[0] + k2[1]) == sorted(k1[0]) and len(k1[0]) >= 30
+    assert parts["pdus_in_timed_region"] == whole["pdus_in_timed_region"] == len(k1[0])
+    assert parts["pdus_matching_sent_payload"] == parts["pdus_in_timed_region"]
+
+
+def test_eight_rank_rehearsal_independent_streams(tmp_path):
+    """BASELINE.json configs[4]'s launch shape -- `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`, default backend, default
+    sharding -- rehearsed on the one GPU of the test box with the small geometry (8 front ends fit beside each other): eight ranks,
+    stream seeds 5..12 in rank order, eight per-rank rows, every rank's PDUs match what ITS stream carried, samples summed over the ranks,
+    time = the slowest rank's; RCCL is not asked for ranks that share a device (it would hang) and the line says so."""
+    import torch
+    r, keys = _run_bench(["--workload", "cfg2", "--steps", "26", "--warmup", "0"], 8, 29553, tmp_path, "s8", backend="nccl")
+    assert r["n_gpus"] == 8 and r["steps"] == 26 and r["scaling"] == "weak"
+    assert r["config"]["stream_seeds"] == [5, 6, 7, 8, 9, 10, 11, 12] and r["config"]["shard"] == "streams"
+    pr = r["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(8)) and [p["stream_seed"] for p in pr] == list(range(5, 13))
+    assert all(p["channels"] == 32 and p["pdus"] > 0 and p["pdus"] == p["pdus_matching_sent_payload"] and p["fold_avg_ms"] > 0 for p in pr)
+    assert sum(p["pdus"] for p in pr) == r["pdus_in_timed_region"] == sum(len(k) for k in keys)
+    assert max(p["ms_per_step"] for p in pr) == pytest.approx(r["ms_per_step"], rel=1e-3)
+    assert abs(r["value"] * 1e6 * r["ms_per_step"] * 26e-3 - 8 * 26 * 917504) < 240               # eight streams' samples over the slowest rank's time
+    assert len({tuple(sorted(k)) for k in keys}) == 8                                             # eight different streams
+    d = r["distributed"]
+    assert d["requested"] == "nccl" and d["world_size"] == 8
+    if torch.cuda.device_count() >= 8:
+        assert d["backend"] == "nccl" and d["fallback"] is None
+    else:
+        assert d["backend"] == "gloo" and "share a device" in d["fallback"]
+    assert all(p["frontend_create_s"] < 120 and p["input_synthesis_s"] < 120 for p in pr)
+
+
+def test_eight_rank_rehearsal_one_stream_channel_sharded(tmp_path):
+    """SURVEY.md 8(e) at the node's full width: ONE stream, its 32 channels round-robin over eight ranks (4 each), every rank ingests the
+    same blocks.  The union of the eight shards' PDUs is the unsharded run's set, no channel is decoded twice, the stream's samples
+    count once."""
+    args = ["--workload", "cfg2", "--steps", "26", "--warmup", "0", "--shard", "channels"]
+    whole, k1 = _run_bench(args, 1, 0, tmp_path, "whole8")
+    parts, k8 = _run_bench(args, 8, 29557, tmp_path, "parts8")
+    assert parts["n_gpus"] == 8 and parts["scaling"] == "strong" and parts["config"]["stream_seeds"] == [2] * 8
+    assert parts["config"]["channels"] == 32 and parts["config"]["channels_rank0"] == 4
+    assert [p["rank"] for p in parts["per_rank"]] == list(range(8)) and all(p["channels"] == 4 for p in parts["per_rank"])
+    assert abs(parts["value"] * 1e6 * parts["ms_per_step"] * 26e-3 - 26 * 917504) < 30              # ONE stream's samples
+    fsets = [{k[0] for k in ks} for ks in k8]
+    assert all(not (fsets[i] & fsets[j]) for i in range(8) for j in range(i))                      # channel partition
+    assert sorted(k for ks in k8 for k in ks) == sorted(k1[0]) and len(k1[0]) >= 30
     assert parts["pdus_in_timed_region"] == whole["pdus_in_timed_region"] == len(k1[0])
     assert parts["pdus_matching_sent_payload"] == parts["pdus_in_timed_region"]
