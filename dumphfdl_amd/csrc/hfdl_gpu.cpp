@@ -122,6 +122,9 @@ struct hfdl_gpu_frontend {
 	double demod_ms = 0;
 	int64_t demod_launches = 0, demod_timed_blocks = 0;
 	hipStream_t stream_c = nullptr;     // C: host -> device copies of block k+1 into the other staging buffer
+	hipStream_t stream_f = nullptr;     // F: forward FFTs of the half being filled, beside the fold of the half before (== stream when HFDL_GPU_FFT_STREAM=0)
+	bool fft_own_stream = false;
+	hipEvent_t ev_spec[2] = { nullptr, nullptr };    // newest forward FFT of the half in spectrum set 0 / 1 done (rides on its last pass)
 
 	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
 	hipEvent_t ev_stage_ready[2] = { nullptr, nullptr }, ev_stage_free[2] = { nullptr, nullptr };
@@ -152,7 +155,12 @@ struct hfdl_gpu_frontend {
 	int last_index = 0;                 // its index inside the half: spectrum / phasor-table slot of the newest block
 	float2 *chan_slot(int slot) const { return d_chan_all + (size_t)slot * (size_t)geo.nch * (size_t)geo.outs; }
 	int *cnt_slot(int slot) const { return d_cnt_all + (size_t)slot * (size_t)geo.nch; }
-	float2 *spec_slot(int i) const { return d_spec + (size_t)i * (size_t)geo.n; }
+	// spectra, NCO phasor tables and carried-state snapshots of a half: two sets (the forward FFTs of half k+1 fill one while the fold
+	// and inverse FFTs of half k read the other); `set` = cur_half of the half they belong to
+	int last_set = 0;                   // set of the newest channelized half: what the taps read
+	float2 *spec_slot(int set, int i) const { return d_spec + ((size_t)set * (size_t)half_blocks + (size_t)i) * (size_t)geo.n; }
+	float2 *ph_slot(int set, int i) const { return d_ph + ((size_t)set * (size_t)half_blocks + (size_t)i) * ph_stride(); }
+	NcoState *snap_slot(int set, int i) const { return d_nco_snap + ((size_t)set * (size_t)half_blocks + (size_t)i) * (size_t)geo.nch; }
 	size_t partial_stride() const { return (size_t)geo.nch * (size_t)geo.slices * (size_t)geo.m; }
 	size_t ph_stride() const { return (size_t)geo.nch * (size_t)geo.outs; }
 	ChanConst *d_cc = nullptr;
@@ -188,6 +196,8 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	if (fe->stream_b) (void)hipStreamSynchronize(fe->stream_b);
 	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamSynchronize(fe->stream_d);
 	if (fe->stream_c) (void)hipStreamSynchronize(fe->stream_c);
+	if (fe->fft_own_stream && fe->stream_f) (void)hipStreamSynchronize(fe->stream_f);
+	for (hipEvent_t e : fe->ev_spec) if (e) (void)hipEventDestroy(e);
 	for (int i = 0; i < 2; i++)
 		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_stage_ready[i], fe->ev_stage_free[i], fe->ev_copy[i], fe->ev_copy[i + 2] }) if (e) (void)hipEventDestroy(e);
 	for (auto &h : fe->ev_dm) for (hipEvent_t e : h) if (e) (void)hipEventDestroy(e);
@@ -205,6 +215,7 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamDestroy(fe->stream_d);
 	if (fe->stream_b) (void)hipStreamDestroy(fe->stream_b);
 	if (fe->stream_c) (void)hipStreamDestroy(fe->stream_c);
+	if (fe->fft_own_stream && fe->stream_f) (void)hipStreamDestroy(fe->stream_f);
 	delete fe;
 }
 
@@ -363,6 +374,19 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	}
 	FE_TRY(hipStreamCreateWithFlags(&fe->stream_c, hipStreamNonBlocking));
 	{
+		// HFDL_GPU_FFT_STREAM=1 puts the forward FFTs of the blocks being pushed on a stream of their own, beside the fold of the half
+		// before (two sets of spectra / phasor tables / state snapshots).  Measured on cfg3 at 8 blocks per fold launch
+		// (profiles/r04_experiments.md): the FFT passes then take their HBM share out of the fold (3.25 -> 4.3 ms per launch) and out of
+		// the demodulators beside it (0.41 -> 0.51 ms per block), 11.3 -> 10.4 Gsamples/s -- fold, FFT and demodulators together already
+		// keep the machine busy, so the FFTs stay in front of the fold on stream A.  Kept as a switch for other geometries / boards.
+		// (More than four busy streams also need GPU_MAX_HW_QUEUES > 4: two streams on one hardware queue run in turn.)
+		fe->fft_own_stream = false;
+		if (const char *e = getenv("HFDL_GPU_FFT_STREAM")) fe->fft_own_stream = atoi(e) != 0;
+		if (fe->fft_own_stream) FE_TRY(hipStreamCreateWithFlags(&fe->stream_f, hipStreamNonBlocking));
+		else fe->stream_f = fe->stream;
+		for (auto &e : fe->ev_spec) FE_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	}
+	{
 		// The burst decoder of block k only hands PDUs to the host; the demodulator of block k+1 does not need it.  With few
 		// channels the demodulator (a serial recurrence per channel, ~0.3 ms per block whatever the channel count) bounds the
 		// block, and a frame ending in a block puts 0.3 ms of Viterbi on the same stream: the decoder then gets its own stream
@@ -413,10 +437,10 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	fe->fold_nb = pick_fold_batch();
 	fe->half_blocks = std::min((int)hfdl_gpu_frontend::MAX_HALF, ((std::max(fe->fold_nb, fe->batch) + fe->fold_nb - 1) / fe->fold_nb) * fe->fold_nb);
 	const size_t hb = (size_t)fe->half_blocks;
-	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n * hb));
+	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n * 2 * hb));
 	FE_TRY(hipMalloc(&fe->d_partial, sizeof(float2) * fe->partial_stride() * hb));
-	FE_TRY(hipMalloc(&fe->d_ph, sizeof(float2) * fe->ph_stride() * hb));
-	FE_TRY(hipMalloc(&fe->d_nco_snap, sizeof(NcoState) * (size_t)nch * hb));
+	FE_TRY(hipMalloc(&fe->d_ph, sizeof(float2) * fe->ph_stride() * 2 * hb));
+	FE_TRY(hipMalloc(&fe->d_nco_snap, sizeof(NcoState) * (size_t)nch * 2 * hb));
 	FE_TRY(hipMalloc(&fe->d_chan_all, sizeof(float2) * 2 * hb * (size_t)nch * g.outs));
 	FE_TRY(hipMalloc(&fe->d_cnt_all, sizeof(int) * 2 * hb * (size_t)nch));
 	FE_TRY(hipMemsetAsync(fe->d_cnt_all, 0, sizeof(int) * 2 * hb * (size_t)nch, fe->stream));
@@ -494,7 +518,7 @@ extern "C" void hfdl_gpu_host_free(void *ptr)
 	(void)hipHostFree(ptr);
 }
 
-extern "C" void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe) { return fe ? (void *)fe->stream : nullptr; }
+extern "C" void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe) { return fe ? (void *)fe->stream_f : nullptr; }      // the stream that reads the input
 
 static size_t sample_bytes(int fmt) { return fmt == SFMT_CS16 ? 4 : fmt == SFMT_CU8 ? 2 : 8; }
 
@@ -504,13 +528,13 @@ static int queue_input_copy(hfdl_gpu_frontend *fe, const void *iq, size_t nsampl
 	const uint64_t j = fe->host_blocks++;
 	const int sb = (int)(j & 1);
 	if (fe->stage_cap[sb] < nsamples) {
-		HIP_TRY(hipStreamSynchronize(fe->stream));
+		HIP_TRY(hipStreamSynchronize(fe->stream_f));
 		if (fe->d_stage[sb]) (void)hipFree(fe->d_stage[sb]);
 		fe->d_stage[sb] = nullptr; fe->stage_cap[sb] = 0;
 		HIP_TRY(hipMalloc(&fe->d_stage[sb], sizeof(float2) * nsamples));
 		fe->stage_cap[sb] = nsamples;
 	}
-	HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_stage_free[sb], 0));     // stream A finished reading this buffer two blocks ago
+	HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_stage_free[sb], 0));     // the forward FFT finished reading this buffer two blocks ago
 	// (one hipMemcpyAsync per block: cutting a block in 2 or 4 pieces on as many streams was measured and is slower, profiles/r03_experiments.md)
 	HIP_TRY(hipMemcpyAsync(fe->d_stage[sb], iq, sample_bytes(fmt) * nsamples, hipMemcpyHostToDevice, fe->stream_c));
 	HIP_TRY(hipEventRecord(fe->ev_stage_ready[sb], fe->stream_c));
@@ -548,7 +572,7 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 		int rc = queue_input_copy(fe, iq, nsamples, fmt, &sb);
 		if (rc) return rc;
 	}
-	HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_stage_ready[sb], 0));
+	HIP_TRY(hipStreamWaitEvent(fe->stream_f, fe->ev_stage_ready[sb], 0));
 	*dev = fe->d_stage[sb];
 	*stage_idx = sb;
 	return 0;
@@ -605,23 +629,26 @@ static int flush_pending_demod(hfdl_gpu_frontend *fe, bool after_fft)
 static int enqueue_fft(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int stage_idx)
 {
 	const Geometry &g = fe->geo;
-	const int i = fe->batch_fill;
+	const int i = fe->batch_fill, set = fe->cur_half;
 	// The events other streams (and the bench's fold timer) wait for ride on the kernel dispatches themselves
 	// (hipExtLaunchKernelGGL start / stop events): a separate hipEventRecord is one more barrier packet in the queue, ~5 us
 	// of idle machine each (profiles/r01_experiments.md).
-	const bool pend = fe->pending_demod_buf >= 0 && i + 1 == fe->half_blocks;      // the last forward FFT of this half: held-back demodulators follow it
+	// FFT on stream A: the held-back demodulators of the half before follow the LAST forward FFT of this half (launch_demod)
+	const bool pend = !fe->fft_own_stream && fe->pending_demod_buf >= 0 && i + 1 == fe->half_blocks;
 	if (pend && !fe->ev_fft) HIP_TRY(hipEventCreateWithFlags(&fe->ev_fft, hipEventDisableTiming));
+	// FFT on its own stream: this set of spectra / phasor tables / snapshots was last read by the fold and inverse FFT two halves ago
+	if (fe->fft_own_stream && i == 0) HIP_TRY(hipStreamWaitEvent(fe->stream_f, fe->ev_chan[set], 0));
 	NcoJob job;
-	job.cc = fe->d_cc; job.chain = fe->d_nco; job.snap = fe->d_nco_snap + (size_t)i * (size_t)g.nch;
-	job.ph = fe->d_ph + (size_t)i * fe->ph_stride(); job.cont = fe->d_ph_cont;
+	job.cc = fe->d_cc; job.chain = fe->d_nco; job.snap = fe->snap_slot(set, i);
+	job.ph = fe->ph_slot(set, i); job.cont = fe->d_ph_cont;
 	job.nch = g.nch; job.outs = g.outs; job.post_input_size = g.post_input_size; job.post = g.post;
-	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->spec_slot(i), true, fe->stream,
-			FftOutLayout(), pend ? fe->ev_fft : nullptr, job);
+	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->spec_slot(set, i), true, fe->stream_f,
+			FftOutLayout(), fe->fft_own_stream ? fe->ev_spec[set] : (pend ? fe->ev_fft : nullptr), job);
 	if (pend) {
 		int rc = flush_pending_demod(fe, true);
 		if (rc) return rc;
 	}
-	if (stage_idx >= 0) HIP_TRY(hipEventRecord(fe->ev_stage_free[stage_idx], fe->stream));   // input consumed: the copy stream may refill it
+	if (stage_idx >= 0) HIP_TRY(hipEventRecord(fe->ev_stage_free[stage_idx], fe->stream_f));   // input consumed: the copy stream may refill it
 	HIP_TRY(hipGetLastError());
 	fe->blocks++;
 	fe->batch_fill++;
@@ -638,6 +665,7 @@ static int close_half(hfdl_gpu_frontend *fe, bool launch_now, bool with_demod = 
 	if (nblk == 0) return 0;
 	const Geometry &g = fe->geo;
 	const int half = fe->cur_half;
+	if (fe->fft_own_stream) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_spec[half], 0));      // the newest forward FFT of this half (stream F)
 	if (fe->timing) {
 		std::pair<hipEvent_t, hipEvent_t> e;
 		if (!fe->ev_pool.empty()) {                 // made by reset_timers(): no event creation between the timed launches
@@ -647,11 +675,11 @@ static int close_half(hfdl_gpu_frontend *fe, bool launch_now, bool with_demod = 
 			HIP_TRY(hipEventCreate(&e.first));
 			HIP_TRY(hipEventCreate(&e.second));
 		}
-		launch_fold(g, fe->d_taps, fe->d_spec, (size_t)g.n, fe->d_partial, fe->partial_stride(), nblk, fe->fold_nb, fe->stream, e.first, e.second);
+		launch_fold(g, fe->d_taps, fe->spec_slot(half, 0), (size_t)g.n, fe->d_partial, fe->partial_stride(), nblk, fe->fold_nb, fe->stream, e.first, e.second);
 		fe->ev.push_back(e);
 		fe->ev_blocks.push_back(nblk);
 	} else {
-		launch_fold(g, fe->d_taps, fe->d_spec, (size_t)g.n, fe->d_partial, fe->partial_stride(), nblk, fe->fold_nb, fe->stream);
+		launch_fold(g, fe->d_taps, fe->spec_slot(half, 0), (size_t)g.n, fe->d_partial, fe->partial_stride(), nblk, fe->fold_nb, fe->stream);
 	}
 	// this half is free once the demodulator launches that read it last (two halves ago) are done
 	if (fe->ev_dm_cur[half]) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm_cur[half], 0));
@@ -663,17 +691,19 @@ static int close_half(hfdl_gpu_frontend *fe, bool launch_now, bool with_demod = 
 		fe->frames_wait_on_a = true;
 	}
 	const int slot0 = half * fe->half_blocks;
-	launch_ifft_nco(g, fe->d_partial, fe->partial_stride(), fe->d_cc, fe->d_nco_snap, fe->d_ph, fe->ph_stride(), fe->d_tw_m,
+	launch_ifft_nco(g, fe->d_partial, fe->partial_stride(), fe->d_cc, fe->snap_slot(half, 0), fe->ph_slot(half, 0), fe->ph_stride(), fe->d_tw_m,
 			fe->chan_slot(slot0), fe->cnt_slot(slot0), nblk, fe->stream, fe->ev_chan[half]);
 	HIP_TRY(hipGetLastError());
 	fe->last_slot = slot0 + nblk - 1;
 	fe->last_index = nblk - 1;
+	fe->last_set = half;
 	fe->cur_half ^= 1;
 	fe->batch_fill = 0;
 	if (!with_demod) return 0;                   // channelize-only: the half is simply left behind
 	fe->prev_demod_buf = fe->demod_buf;          // what poll_pdus_ready(.., 1) waits for: the half before the newest one
 	fe->demod_buf = half;
-	if (launch_now) return launch_demod(fe, half, nblk, false);
+	// (forward FFTs on their own stream run beside everything anyway: there is no quiet moment to hold the demodulators back for)
+	if (launch_now || fe->fft_own_stream) return launch_demod(fe, half, nblk, false);
 	fe->pending_demod_buf = half;
 	fe->pending_demod_nblk = nblk;
 	return 0;
@@ -756,6 +786,7 @@ extern "C" int hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe)
 	{ int rc = flush_pending_demod(fe, false); if (rc) return rc; }
 	{ int rc = close_half(fe, true); if (rc) return rc; }           // blocks waiting for their half to fill: folded and demodulated now
 	HIP_TRY(hipStreamSynchronize(fe->stream_c));
+	if (fe->fft_own_stream) HIP_TRY(hipStreamSynchronize(fe->stream_f));
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipStreamSynchronize(fe->stream_b));
 	if (fe->own_decode_stream) HIP_TRY(hipStreamSynchronize(fe->stream_d));
@@ -911,7 +942,7 @@ extern "C" int hfdl_gpu_frontend_fold_variant_probe(hfdl_gpu_frontend *fe, int v
 	HIP_TRY(hipEventCreate(&e1));
 	double sum = 0, best = 1e30;
 	for (int i = 0; i < reps + 1; i++) {
-		if (launch_fold_variant(variant, g, fe->d_taps, fe->d_spec, (size_t)g.n, fe->d_partial, fe->partial_stride(), fe->stream, e0, e1) < 0) {
+		if (launch_fold_variant(variant, g, fe->d_taps, fe->spec_slot(fe->last_set, 0), (size_t)g.n, fe->d_partial, fe->partial_stride(), fe->stream, e0, e1) < 0) {
 			(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 			return fail(HFDL_GPU_ERANGE, "fold variant %d does not fit this geometry (M = %d)", variant, g.m);
 		}
@@ -1049,7 +1080,7 @@ extern "C" int hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what,
 	const void *src = nullptr;
 	size_t nf = 0;
 	switch (what) {
-	case HFDL_GPU_TAP_SPECTRUM: src = fe->spec_slot(index); nf = 2 * (size_t)g.n; break;
+	case HFDL_GPU_TAP_SPECTRUM: src = fe->spec_slot(fe->last_set, index); nf = 2 * (size_t)g.n; break;
 	case HFDL_GPU_TAP_FILTER: {
 		// rows of M bins, tap_row_stride apart: gather them into the caller's contiguous cf32[N]
 		if (2 * (size_t)g.n > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", 2 * (size_t)g.n, cap);
@@ -1066,7 +1097,7 @@ extern "C" int hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what,
 		HIP_TRY(hipMemcpy(&cnt, fe->cnt_slot(slot) + channel, sizeof(cnt), hipMemcpyDeviceToHost));
 		if (2 * (size_t)cnt > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", 2 * (size_t)cnt, cap);
 		// column `channel` of the [outs][nch] table
-		if (cnt) HIP_TRY(hipMemcpy2D(dst, sizeof(float2), fe->d_ph + (size_t)index * fe->ph_stride() + channel, sizeof(float2) * (size_t)g.nch, sizeof(float2), (size_t)cnt, hipMemcpyDeviceToHost));
+		if (cnt) HIP_TRY(hipMemcpy2D(dst, sizeof(float2), fe->ph_slot(fe->last_set, index) + channel, sizeof(float2) * (size_t)g.nch, sizeof(float2), (size_t)cnt, hipMemcpyDeviceToHost));
 		*n_floats = 2 * (size_t)cnt;
 		return 0; }
 	case HFDL_GPU_TAP_PHASE_CYCLES: src = fe->demod.d_tap_lvl + (size_t)channel * fe->demod.cap + fe->demod.cap - 4; nf = 4; break;
