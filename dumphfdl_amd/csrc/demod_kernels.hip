@@ -13,7 +13,19 @@
 #include <utility>
 #include <vector>
 #include <cstring>
+#ifdef HFDL_DM_STRICT
+// TEST-ONLY BUILD (csrc/build_strict.sh, never the shipped library; same standing as HFDL_DM_LIBM_TRIG): the demodulator runs the
+// one-lane serial loop of tests/hostsim/serial_demod.h with the fixed-sequence elementary functions of tests/hostsim/shared_math.h --
+// the arithmetic the oracle runs under orc_variant.shared_math -- so that device and oracle can be compared BIT FOR BIT, and the
+// pipeline's fast forms can be switched back on one at a time (HFDL_DM_STRICT_FAST).  profiles/strict_study.py, DESIGN.md section 5.
+#define SM_FN __host__ __device__ static inline
+#include "../../tests/hostsim/shared_math.h"
+#define HFDL_ATAN2F sm_atan2f
+#endif
 #include "demod_core.h"
+#ifdef HFDL_DM_STRICT
+#include "../../tests/hostsim/serial_demod.h"
+#endif
 #include "demod_tables.h"
 #include "demod.h"
 
@@ -152,7 +164,15 @@ __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, Demod
 	sh.mbox = (int *)(lds + L.mbox);
 	sh.sink = (float *)(lds + L.sink);
 	sh.stage = (cf *)(lds + L.stage);
+#ifdef HFDL_DM_STRICT
+	if (tid == 0) {
+		DemodConst Ks = K;
+		Ks.ss_mf = T.c.ss_mf; Ks.ss_dmf = T.c.ss_dmf;      // the serial loop reads the filter banks where they lie
+		demod_block_serial(*S, *A, Ks, io, l_in, n_block);
+	}
+#else
 	demod_block<TAPS>(*A, K, io, sh, l_in, n_block);
+#endif
 	__syncthreads();
 	{
 		uint32_t *dst = (uint32_t *)&gs->a;

@@ -12,6 +12,9 @@
 
 #define HFDL_FN __device__ inline
 #define HFDL_HD __host__ __device__ inline
+#ifndef HFDL_ATAN2F                 // the test-only build -DHFDL_DM_STRICT substitutes a fixed fp32 sequence shared with the oracle (demod_kernels.hip)
+#define HFDL_ATAN2F atan2f
+#endif
 
 namespace hfdl {
 
@@ -153,7 +156,7 @@ HFDL_FN uint32_t psk_slice(int arity, cf x, float *phase_error, const Pts &pts)
 	} else {
 		const uint32_t M = 1u << arity;
 		const float alpha = (float)M_PI / (float)M;
-		float theta = atan2f(x.y, x.x);
+		float theta = HFDL_ATAN2F(x.y, x.x);
 		theta -= (float)M_PI * (1.0f - 1.0f / (float)M);
 		if (theta < -(float)M_PI) theta += 2 * (float)M_PI;
 		uint32_t s = 0;

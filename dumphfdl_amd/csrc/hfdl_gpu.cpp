@@ -721,6 +721,28 @@ extern "C" int hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const f
 	return close_half(fe, false, false);                    // this block is never demodulated
 }
 
+// The demodulator / burst-decoder stage alone: one block of channelizer OUTPUT from the host (what fastddc_inv_cc hands to
+// hfdl_decoder_thread's loop body, src/hfdl.c:676) goes through K4 + K5 with the channel state carried as usual.  Stage parity:
+// fed with the oracle's own channelizer output, the device demodulator is compared with the oracle's without the two channelizers'
+// different fp32 roundings in between (tests/test_gpu_parity.py, profiles/strict_study.py).
+extern "C" int hfdl_gpu_frontend_push_baseband(hfdl_gpu_frontend *fe, const float *chan_out, const int32_t *counts)
+{
+	if (!fe || !chan_out || !counts) return fail(HFDL_GPU_EINVAL, "null argument");
+	const Geometry &g = fe->geo;
+	for (int c = 0; c < g.nch; c++)
+		if (counts[c] < 0 || counts[c] > g.outs) return fail(HFDL_GPU_ERANGE, "channel %d: %d samples, a block holds at most %d", c, counts[c], g.outs);
+	int rc = hfdl_gpu_frontend_sync(fe);                    // a stage-test entry point: everything pushed before is finished first
+	if (rc) return rc;
+	const int half = fe->cur_half, slot0 = half * fe->half_blocks;
+	HIP_TRY(hipMemcpy(fe->chan_slot(slot0), chan_out, sizeof(float2) * (size_t)g.nch * (size_t)g.outs, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(fe->cnt_slot(slot0), counts, sizeof(int32_t) * (size_t)g.nch, hipMemcpyHostToDevice));
+	fe->last_slot = slot0;
+	fe->cur_half ^= 1;
+	fe->prev_demod_buf = fe->demod_buf;
+	fe->demod_buf = half;
+	return launch_demod(fe, half, 1, false);
+}
+
 static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int fmt, int on_device)
 {
 	const void *fresh = nullptr;

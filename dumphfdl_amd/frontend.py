@@ -62,7 +62,7 @@ EXPORTS = [
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_input_done_upto", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_demod_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
-    "hfdl_gpu_frontend_fold_blocks", "hfdl_gpu_frontend_read_tap_block", "hfdl_gpu_fold_variant_count", "hfdl_gpu_fold_variant_describe", "hfdl_gpu_frontend_fold_variant_probe",
+    "hfdl_gpu_frontend_fold_blocks", "hfdl_gpu_frontend_read_tap_block", "hfdl_gpu_frontend_push_baseband", "hfdl_gpu_fold_variant_count", "hfdl_gpu_fold_variant_describe", "hfdl_gpu_frontend_fold_variant_probe",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk", "hfdl_gpu_frontend_prefetch_block_raw", "hfdl_gpu_frontend_prefetch_cancel", "hfdl_gpu_psk_slice",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
@@ -104,6 +104,7 @@ def load():
     L.hfdl_gpu_frontend_push_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.hfdl_gpu_frontend_channelize_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.hfdl_gpu_frontend_push_block_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    L.hfdl_gpu_frontend_push_baseband.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.hfdl_gpu_frontend_sync.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_input_done.argtypes = [C.c_void_p]
     L.hfdl_gpu_frontend_input_done_upto.argtypes = [C.c_void_p, C.c_uint64]
@@ -212,6 +213,20 @@ class Frontend:
         else:
             s = np.ascontiguousarray(samples, dtype=np.complex64)
             _check(L.hfdl_gpu_frontend_channelize_block(self._h, _p(s), len(s), 0))
+
+    def push_baseband(self, per_channel):
+        """per_channel: one complex64 array of channelizer OUTPUT per channel (<= max_outputs_per_block + 1 samples each): the demodulator
+        and burst decoder stage alone, fed from the host (stage parity)."""
+        g = self.geometry
+        row = g.max_outputs_per_block + 1
+        assert len(per_channel) == g.channels
+        buf = np.zeros((g.channels, row), np.complex64)
+        cnt = np.zeros(g.channels, np.int32)
+        for c, x in enumerate(per_channel):
+            x = np.asarray(x, np.complex64)
+            buf[c, :len(x)] = x
+            cnt[c] = len(x)
+        _check(load().hfdl_gpu_frontend_push_baseband(self._h, _p(buf), _p(cnt)))
 
     def push_host_ptr(self, ptr, sample_format=SFMT_CF32):
         """ptr: address of a (page-locked) host buffer holding one block; valid until input_done() / sync()."""

@@ -155,6 +155,11 @@ int  hfdl_gpu_frontend_prefetch_cancel(hfdl_gpu_frontend *fe);
 #define HFDL_GPU_SFMT_CS16 1
 #define HFDL_GPU_SFMT_CU8  2
 int  hfdl_gpu_frontend_push_block_raw(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int sample_format, int on_device);
+/* the demodulator + burst decoder stage alone (for stage parity): one block of channelizer OUTPUT from host memory -- chan_out[channels]
+ * [max_outputs_per_block + 1] complex samples (interleaved re, im; rows of that length whatever counts[] says), counts[c] of them valid
+ * for channel c -- through the same kernels and carried channel state as a pushed block's (hfdl_decoder_thread's loop body after
+ * fastddc_inv_cc, src/hfdl.c:676-892).  Syncs first; collect with hfdl_gpu_frontend_poll_pdus(). */
+int  hfdl_gpu_frontend_push_baseband(hfdl_gpu_frontend *fe, const float *chan_out, const int32_t *counts);
 /* run only the channelizer part of a block (forward FFT + fold + inverse FFT + NCO); for stage parity/bench */
 int  hfdl_gpu_frontend_channelize_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
 int  hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe);

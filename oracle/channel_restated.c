@@ -16,6 +16,7 @@
 
 /* ======================= variant switches (hfdl_oracle.h) ======================= */
 
+#include "../tests/hostsim/shared_math.h"     /* orc_variant.shared_math: libm replaced by fixed fp32 sequences (test infrastructure, like this file) */
 orc_variant orc_v = { .soft_dmin_init = 4.0f };
 void orc_variant_default(orc_variant *v) { memset(v, 0, sizeof(*v)); v->soft_dmin_init = 4.0f; }
 void orc_variant_set(const orc_variant *v) { orc_v = *v; }
@@ -238,7 +239,7 @@ static orc_cf agc_step(agc_t *a, orc_cf x)
 	float e = y.re * y.re + y.im * y.im;
 	if (orc_v.agc_double) a->y2 = (float)((1.0 - a->alpha) * a->y2 + a->alpha * e);      /* liquid writes (1.0 - alpha): a double expression */
 	else a->y2 = (1.0f - a->alpha) * a->y2 + a->alpha * e;
-	if (a->y2 > 1e-6f) a->g *= expf(-0.5f * a->alpha * logf(a->y2));
+	if (a->y2 > 1e-6f) a->g *= orc_v.shared_math ? sm_expf(-0.5f * a->alpha * sm_logf(a->y2)) : expf(-0.5f * a->alpha * logf(a->y2));
 	if (a->g > 1e6f) a->g = 1e6f;
 	return y;
 }
@@ -797,7 +798,9 @@ static void process_resampled(orc_channel *c, orc_pdu_sink sink, void *ctx)
 			c->loop.phi += c->loop.dphi;
 			if (c->loop.phi > (float)M_PI) c->loop.phi -= (float)(2.0 * M_PI);
 			else if (c->loop.phi < -(float)M_PI) c->loop.phi += (float)(2.0 * M_PI);
-			float cp = cosf(c->loop.phi), sp = sinf(c->loop.phi);
+			float cp, sp;
+			if (orc_v.shared_math) sm_sincosf(c->loop.phi, &sp, &cp);
+			else { cp = cosf(c->loop.phi); sp = sinf(c->loop.phi); }
 			r.re = sym[i].re * cp + sym[i].im * sp;
 			r.im = sym[i].im * cp - sym[i].re * sp;
 			if (fabsf(c->loop.dphi) > 0.25f && c->fr_state == FR_A1) {

@@ -12,6 +12,7 @@
 #include "hfdl_oracle.h"
 
 extern orc_variant orc_v;       /* channel_restated.c */
+#include "../tests/hostsim/shared_math.h"
 
 static inline int parity32(uint32_t x)
 {
@@ -304,7 +305,7 @@ uint32_t orc_modem_demod_hard(int arity, orc_cf x, float *phase_error)
 	} else {
 		uint32_t M = 1u << arity;
 		float alpha = (float)M_PI / (float)M;
-		float theta = atan2f(x.im, x.re);
+		float theta = orc_v.shared_math ? sm_atan2f(x.im, x.re) : atan2f(x.im, x.re);
 		theta -= (float)M_PI * (1.0f - 1.0f / (float)M);
 		if (theta < -(float)M_PI) theta += 2 * (float)M_PI;
 		/* successive-approximation slicer on ref[k] = 2^k * alpha */

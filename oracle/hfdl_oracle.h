@@ -138,6 +138,10 @@ typedef struct {
 	float   soft_gamma_scale;    /* 8-PSK soft de-mapper gamma = this * 1.2 M (0 -> 1.0) */
 	int32_t soft_floor;          /* soft bit conversion: 0 = C cast of (llr * 16 + 127) (truncation, default), 1 = floor */
 	float   agc_y2_init;         /* AGC energy estimate at create (0 -> 1.0) */
+	int32_t shared_math;         /* 1: expf / logf (AGC), sinf / cosf (carrier NCO) and atan2f (PSK slicer) come from tests/hostsim/shared_math.h
+	                                -- fixed sequences of fp32 operations -- instead of glibc's libm: the arithmetic the device's test-only
+	                                build -DHFDL_DM_STRICT runs, so that the two can be compared bit for bit (tests/test_strict_cpu.py,
+	                                profiles/strict_study.py).  Rounding-level change only: ~1 ulp functions either way */
 } orc_variant;
 void orc_variant_default(orc_variant *v);
 void orc_variant_set(const orc_variant *v);

@@ -47,7 +47,7 @@ class Variant(C.Structure):
                 ("lfsr_kind", C.c_int32), ("eqlms_norm", C.c_int32), ("agc_double", C.c_int32), ("design_float", C.c_int32),
                 ("perr_kind", C.c_int32), ("dot_order", C.c_int32), ("symsync_bank_floor", C.c_int32),
                 ("symsync_dmf_scale", C.c_float), ("symsync_lf_b", C.c_float), ("soft_gamma_scale", C.c_float), ("soft_floor", C.c_int32),
-                ("agc_y2_init", C.c_float)]
+                ("agc_y2_init", C.c_float), ("shared_math", C.c_int32)]
 
 
 SINK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Pdu))

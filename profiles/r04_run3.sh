@@ -1,9 +1,6 @@
 #!/bin/bash
-OUT=/root/repo/gpurun_out/r4f
+OUT=/root/repo/gpurun_out/r4l
 mkdir -p $OUT
 cd /root/repo
-nproc > $OUT/nproc.txt
-timeout 1500 python -m pytest tests/test_gpu_configs.py -m gpu -x -q -k "eight_rank or two_rank" > $OUT/pytest_8rank.log 2>&1; echo "rc=$?" >> $OUT/pytest_8rank.log
-tail -15 $OUT/pytest_8rank.log
-timeout 900 python profiles/setup_time.py > $OUT/setup_time.json 2> $OUT/setup_time.err
-cat $OUT/setup_time.json
+timeout 900 python -m pytest tests/test_gpu_strict.py tests/test_gpu_parity.py -m gpu -x -q -k "strict or demodulator_stage or fold_batching" > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log
+tail -25 $OUT/pytest.log

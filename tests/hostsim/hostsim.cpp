@@ -14,6 +14,11 @@ static const struct { unsigned x; } threadIdx = { 0 };
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+#ifdef HFDL_DM_STRICT              // the arithmetic of the device's test-only strict build, on the host: fixed-sequence elementary functions
+#define SM_FN static inline
+#include "shared_math.h"
+#define HFDL_ATAN2F sm_atan2f
+#endif
 #include "serial_demod.h"
 #include "../../dumphfdl_amd/csrc/demod_tables.h"
 #include "../../dumphfdl_amd/csrc/planner.h"

@@ -6,11 +6,60 @@
 #pragma once
 #include "../../dumphfdl_amd/csrc/demod_logic.h"
 
+// The second user (round 4): the device's test-only build -DHFDL_DM_STRICT runs THIS loop, one lane per channel, in place of the
+// three-wave pipeline (dumphfdl_amd/csrc/demod_kernels.hip), with the elementary functions of tests/hostsim/shared_math.h on both
+// sides (the oracle through orc_variant.shared_math): device and oracle then run the same chain of fp32 operations and must agree
+// bit for bit.  HFDL_DM_STRICT_FAST re-enables, one bit at a time, the forms in which the shipped pipeline differs from this loop --
+// each emulated here in the exact operation order of demod_core.h -- so that the frames that differ from the oracle at low SNR can be
+// charged to the form that causes them (profiles/strict_study.py); with all bits set this loop reproduces the shipped kernel.
+//   1  SUM     the timing loop's and the equaliser's dot products summed as the DPP row scan sums them (a balanced pairwise tree
+//              over the 16 lanes of a row; taps t and t + 16 of the 18-tap windows share lane t) instead of tap after tap
+//   2  AGC     gain update exp2(-alpha/2 log2 y2) on the hardware v_log_f32 / v_exp_f32, level 1/g by v_rcp_f32
+//   4  TRIG    carrier NCO on the hardware v_sin_f32 / v_cos_f32 (argument in revolutions)
+//   8  SLICER  the carrier loop's nearest-point slicer (largest Re x conj p) instead of arg() + reference ladder
+#ifndef HFDL_DM_STRICT_FAST
+#define HFDL_DM_STRICT_FAST 0
+#endif
+#ifdef HFDL_DM_STRICT
+#define SD_EXPF sm_expf
+#define SD_LOGF sm_logf
+#define SD_SINCOS(x, s, c) sm_sincosf((x), (s), (c))
+#else
+#define SD_EXPF expf
+#define SD_LOGF logf
+#define SD_SINCOS(x, s, c) (*(c) = cosf(x), *(s) = sinf(x))
+#endif
+
 namespace hfdl {
 
-// sum_t h[t] * win[(head - t) mod 18] : polyphase branch output, newest sample first
-static inline cf bank_dot(const float *h, const cf *win, int head)
+// row_scan_sum's order of additions (demod_core.h): lane 15 of a row ends up with ((v15+v14)+(v13+v12)) + ... -- at every level the
+// higher-lane partial sum is the left operand
+HFDL_FN float tree16(const float *v)
 {
+	float t[16];
+	for (int i = 0; i < 16; i++) t[i] = v[i];
+	for (int n = 16; n > 1; n >>= 1)
+		for (int j = 0; j < n / 2; j++) t[j] = t[2 * j + 1] + t[2 * j];
+	return t[0];
+}
+
+// sum_t h[t] * win[(head - t) mod 18] : polyphase branch output, newest sample first
+HFDL_FN cf bank_dot(const float *h, const cf *win, int head)
+{
+	if (HFDL_DM_STRICT_FAST & 1) {
+		// the device: lane t holds h[t] * w[t] + h[t + 16] * w[t + 16] (the second product only for t < 2; elsewhere the tap is 0), rows
+		// reduced by the scan
+		float vr[16], vi[16];
+		for (int t = 0; t < 16; t++) {
+			int i0 = head - t; if (i0 < 0) i0 += D_SS_TAPS;
+			int i1 = head - t - 16; while (i1 < 0) i1 += D_SS_TAPS;
+			const float h1 = t + 16 < D_SS_TAPS ? h[t + 16] : 0.f;
+			vr[t] = h[t] * win[i0].x + h1 * win[i1].x;
+			vi[t] = h[t] * win[i0].y + h1 * win[i1].y;
+		}
+		cf y; y.x = tree16(vr); y.y = tree16(vi);
+		return y;
+	}
 	float ar = 0, ai = 0;
 	int idx = head;
 	for (int t = 0; t < D_SS_TAPS; t++) {
@@ -22,8 +71,40 @@ static inline cf bank_dot(const float *h, const cf *win, int head)
 	return y;
 }
 
+// the carrier wave's slicer (demod_core.h LaneSlicer) as a loop over the table: the point with the largest Re(x conj p), the lowest
+// index among equals, the first point if none compares equal
+struct NearestSlicer {
+	const float *p;
+	HFDL_FN uint32_t operator()(int arity, cf x, float *phase_error) const
+	{
+		uint32_t sym;
+		cf xh;
+		if (arity == 1) {
+			sym = (x.x > 0) ? 0 : 1;
+			xh.x = sym ? -1.0f : 1.0f; xh.y = 0.0f;
+		} else {
+			const int M = 1 << arity, base = M - 2;
+			float best = -1.0f;
+			for (int i = 0; i < M; i++) {
+				const float d = x.x * p[2 * (base + i)] + x.y * p[2 * (base + i) + 1];
+				best = d > best ? d : best;
+			}
+			int win = base;
+			for (int i = M - 1; i >= 0; i--) {
+				const float d = x.x * p[2 * (base + i)] + x.y * p[2 * (base + i) + 1];
+				if (d == best) win = base + i;
+			}
+			const uint32_t lin = (uint32_t)(win - base);
+			sym = lin ^ (lin >> 1);
+			xh.x = p[2 * win]; xh.y = p[2 * win + 1];
+		}
+		if (phase_error) *phase_error = x.y * xh.x - x.x * xh.y;
+		return sym;
+	}
+};
+
 // returns the number of 5400-sps samples produced
-static inline int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, const cf *in, int n_in)
+HFDL_FN int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodConst &T, const BlockIo &io, const cf *in, int n_in)
 {
 	// ---- R: arbitrary resampler, 24-bit fixed-point phase (msresamp_crcf_execute, src/hfdl.c:676)
 	const uint64_t total = (uint64_t)n_in << 24;
@@ -61,10 +142,17 @@ static inline int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodC
 			cf y; y.x = x.x * g; y.y = x.y * g;
 			const float e = y.x * y.x + y.y * y.y;
 			y2 = (1.0f - alpha) * y2 + alpha * e;
-			if (y2 > 1e-6f) g *= expf(-0.5f * alpha * logf(y2));
+#if (HFDL_DM_STRICT_FAST & 2) && defined(__HIP_DEVICE_COMPILE__)
+			if (y2 > 1e-6f) g *= __builtin_amdgcn_exp2f(-0.5f * alpha * __builtin_amdgcn_logf(y2));
+			if (g > 1e6f) g = 1e6f;
+			io.agc[k] = y;
+			io.lvl[k] = __builtin_amdgcn_rcpf(g);
+#else
+			if (y2 > 1e-6f) g *= SD_EXPF(-0.5f * alpha * SD_LOGF(y2));
 			if (g > 1e6f) g = 1e6f;
 			io.agc[k] = y;
 			io.lvl[k] = 1.0f / g;
+#endif
 		}
 		s.agc_g = g; s.agc_y2 = y2;
 	}
@@ -138,7 +226,12 @@ static inline int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodC
 			s.phi += s.dphi;
 			if (s.phi > (float)M_PI) s.phi -= (float)(2.0 * M_PI);
 			else if (s.phi < -(float)M_PI) s.phi += (float)(2.0 * M_PI);
-			const float cp = cosf(s.phi), sp = sinf(s.phi);
+			float cp, sp;
+#if (HFDL_DM_STRICT_FAST & 4) && defined(__HIP_DEVICE_COMPILE__)
+			{ const float rev = s.phi * 0.15915494309189535f; sp = __builtin_amdgcn_sinf(rev); cp = __builtin_amdgcn_cosf(rev); }
+#else
+			SD_SINCOS(s.phi, &sp, &cp);
+#endif
 			cf r;
 			r.x = out[i].x * cp + out[i].y * sp;
 			r.y = out[i].y * cp - out[i].x * sp;
@@ -158,7 +251,19 @@ static inline int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodC
 			if (!(s.symsync_out_idx & 1u)) continue;
 			// eqlms_cccf_execute: sum conj(w_i) x_i, x_0 oldest
 			cf y; y.x = 0.f; y.y = 0.f;
-			{
+			if (HFDL_DM_STRICT_FAST & 1) {
+				// the device: tap t in lane t + 1 of a row (lane 0 holds 0), row 0 the real part, row 1 the imaginary part
+				float vr[16], vi[16];
+				vr[0] = 0.f; vi[0] = 0.f;
+				int idx = s.eq_head;
+				for (int t = 0; t < D_EQ; t++) {
+					const cf w = a.eq_w[t], x = a.eq_buf[idx];
+					vr[t + 1] = w.x * x.x + w.y * x.y;
+					vi[t + 1] = w.x * x.y + w.y * (-x.x);
+					idx = idx + 1 == D_EQ ? 0 : idx + 1;
+				}
+				y.x = tree16(vr); y.y = tree16(vi);
+			} else {
 				int idx = s.eq_head;
 				for (int t = 0; t < D_EQ; t++) {
 					const cf w = a.eq_w[t], x = a.eq_buf[idx];
@@ -187,7 +292,8 @@ static inline int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodC
 			}
 			if (io.tap_symbols) io.tap_symbols[nsym] = y;
 			nsym++;
-			on_symbol(s, s, a, T, io, y, level, TableSlicer{T.psk_pts});
+			if (HFDL_DM_STRICT_FAST & 8) on_symbol(s, s, a, T, io, y, level, NearestSlicer{T.psk_pts});
+			else on_symbol(s, s, a, T, io, y, level, TableSlicer{T.psk_pts});
 		}
 	}
 	if (io.tap_counts) io.tap_counts[1] = nsym;

@@ -842,6 +842,43 @@ def test_demodulator_batching_changes_nothing(gpu, oracle, monkeypatch):
                 assert have[k + "_corr_avg"] == pytest.approx(want[k + "_corr_total"] / want[cnt], rel=1e-5)
 
 
+def test_demodulator_stage_fed_with_the_oracles_channelizer_output(gpu, oracle):
+    """hfdl_gpu_frontend_push_baseband: the device's demodulator + burst decoder alone, fed block by block with the ORACLE's channelizer
+    output (the two channelizers round differently -- other FFT factorisation -- so only this feed compares the demodulators on the same
+    input).  Every PDU field and channel counter is the oracle's; the shipped pipeline's symbols stay within 1e-4 of the oracle's in the
+    typical block (what is left is the AGC's hardware log / exp and the scan-order sums: profiles/r04/strict_study.md) -- between
+    bursts the loops random-walk on noise and the two drift apart in the last bits, which is why the gate is the median block and
+    the bit-for-bit comparison is the strict build's (tests/test_gpu_strict.py: 0 of 80519 symbols differ)."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000]
+    dur = 14.0
+    bursts = synth.plan_traffic(freqs, dur, seed=53, dense=True, gap_s=0.12, amp=(0.02, 0.1))
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.012, seed=53)
+    fe = gpu.Frontend(fs, cf, freqs)
+    ora = oracle.Frontend(fs, cf, freqs)
+    n, got, errs, nsym = fe.input_size, [], [], 0
+    for b in range(len(x) // n):
+        ora.push_block(x[b * n:(b + 1) * n])
+        fe.push_baseband([ora.channel_view(c)["chan_out"] for c in range(len(freqs))])
+        got += fe.poll_pdus()
+        for c in range(len(freqs)):
+            a, w = fe.read_tap(F.TAP_SYMBOLS, c), ora.channel_view(c)["symbols"]
+            assert len(a) == len(w), (b, c)
+            if len(w):
+                errs.append(rel_rms(a, w))
+                nsym += len(w)
+    key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"], p["train_bits_bad"], p["train_bits_total"])
+    assert sorted(map(key, got)) == sorted(map(key, ora.pdus)) and len(got) >= len(bursts) - 2
+    assert nsym > 80_000 and float(np.median(errs)) < 1e-4, (float(np.median(errs)), max(errs))
+    for c in range(len(freqs)):
+        want, have = ora.channel_summary(c), fe.channel_stats(c)
+        assert (have["a1_found"], have["a2_found"], have["m1_found"], have["m1_not_found"]) == (want["a1_found"], want["a2_found"], want["m1_found"], want["m1_not_found"])
+    with pytest.raises(gpu.GpuError):
+        fe.push_baseband([np.zeros(fe.geometry.max_outputs_per_block + 2, np.complex64)] * len(freqs))       # more than a block holds
+    fe.close()
+    ora.close()
+
+
 @pytest.mark.parametrize("fs,nch", [(250000, 5), (2_400_000, 130)])
 def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
     """One fold launch multiplies the spectra of up to geometry.fold_batch queued blocks against ONE pass over the filter taps

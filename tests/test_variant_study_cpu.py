@@ -29,7 +29,7 @@ def test_default_variant_is_the_plain_oracle(oracle, bb20):
     data, sent = bb20
     assert oracle.get_variant() == dict(symsync_reset_both=0, resamp_kind=0, kaiser_arg=0, soft_dmin_init=4.0, lfsr_kind=0, eqlms_norm=0,
                                         agc_double=0, design_float=0, perr_kind=0, dot_order=0, symsync_bank_floor=0,
-                                        symsync_dmf_scale=0.0, symsync_lf_b=0.0, soft_gamma_scale=0.0, soft_floor=0, agc_y2_init=0.0)
+                                        symsync_dmf_scale=0.0, symsync_lf_b=0.0, soft_gamma_scale=0.0, soft_floor=0, agc_y2_init=0.0, shared_math=0)
     base, summ = decode({}, data)
     assert vs.score(base, sent) == len(base) >= 46 and summ["a2_found"] == 48
     # a channel that never saw set_variant() gives the same PDUs: the switches default to the restatement the parity tests use
