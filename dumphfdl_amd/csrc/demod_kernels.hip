@@ -589,7 +589,10 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 	batch = batch_want < 1 ? 1 : batch_want;
 	for (;; batch--) {
 		cap = (int)((double)outs * (double)batch * (double)resamp_rate + 8);
-		if (batch == 1 || (demod_lds_bytes(cap) <= 160 * 1024 && 2 * cap <= 65535)) break;      // cum[] counts outputs in 16 bits
+		// ... and less than one second of signal per launch WHATEVER asked for the batch (cap samples at 5400 sps): a channel then finishes
+		// at most one frame per launch -- the frame queue has one entry per channel and the frame buffers two slots (hfdl_gpu.cpp
+		// pick_demod_batch states the same bound; an override or a larger LDS must not get past it)
+		if (batch == 1 || (demod_lds_bytes(cap) <= 160 * 1024 && 2 * cap <= 65535 && (double)cap / 5400.0 < 1.0)) break;      // cum[] counts outputs in 16 bits
 	}
 	auto *pv = new DemodPriv();
 	build_demod_tables(pv->h, resamp_rate);
@@ -724,7 +727,8 @@ int Demod::collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st)
 int Demod::collect_snapshot(int buf, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st)
 {
 	const volatile int *snap = h_snap + 4 * (buf & 1);
-	dropped = (uint32_t)snap[2];
+	const uint32_t d = (uint32_t)snap[2];
+	if ((int32_t)(d - dropped) > 0) dropped = d;       // monotone: an older snapshot never takes the count back
 	return take((unsigned)snap[1], out, max, n, st);
 }
 

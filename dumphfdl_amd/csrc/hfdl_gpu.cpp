@@ -1036,7 +1036,11 @@ extern "C" int hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu
 	if (buf < 0) return 0;                              // fewer than two launches: nothing is known to be done
 	HIP_TRY(hipSetDevice(fe->device));
 	HIP_TRY(hipEventSynchronize(fe->ev_dm_cur[buf] ? fe->ev_dm_cur[buf] : fe->ev_demod[buf]));
-	int rc = fe->demod.collect_snapshot(buf, out, max, n, fe->stream_d);
+	// The snapshot slot of that half is written by its burst decoders' 16-byte copies: read it only once the last of them is known to be
+	// done (ev_demod is recorded behind it); until then the OTHER slot is the stable one -- it was written two halves ago, and the
+	// newest half's decoders, which write it next, sit behind this half's on their stream.
+	const bool decoded = hipEventQuery(fe->ev_demod[buf]) == hipSuccess;
+	int rc = fe->demod.collect_snapshot(decoded ? buf : buf ^ 1, out, max, n, fe->stream_d);
 	if (rc) return fail(rc, "pdu collection failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;
 }

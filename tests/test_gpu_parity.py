@@ -167,9 +167,12 @@ def test_end_to_end_small_matches_oracle(gpu, oracle):
     x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.01, seed=1)
     got, want, worst = _run_both(gpu, oracle, fs, cf, freqs, x, check_stages=True)
     assert worst["resampled"] < RMS_TOL and worst["mf_out"] < RMS_TOL, worst
-    # Equalised symbols come out of three nested feedback loops; on noise-only stretches the loops wander and a 1-ulp
-    # difference in sinf/atan2f grows, so gate the typical block tightly and the worst one loosely.  The decoded
-    # octets below are the real gate.
+    # Equalised symbols come out of three nested feedback loops; on noise-only stretches the loops wander and a 1-ulp difference at
+    # their INPUT grows: the strict build, whose demodulator arithmetic is the oracle's to the bit (0 of 80519 symbols differ when both
+    # are fed the same channelizer output), shows symbol differences of up to 0.07 on such stretches once the device's own channelizer
+    # (another FFT factorisation, ~1e-6 relative) is in front of it (profiles/r04/strict_study.md).  So a worst-block bound below
+    # that would gate the channelizer's last bits, not the demodulator: the typical block is gated tightly, the worst one loosely, the
+    # decoded octets below exactly -- and the demodulator alone in tests/test_gpu_strict.py and the oracle-fed stage test below.
     assert np.median(worst["symbols"]) < 2e-3 and max(worst["symbols"]) < 0.3, (np.median(worst["symbols"]), max(worst["symbols"]))
     key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
     assert sorted(map(key, got)) == sorted(map(key, want))
@@ -543,9 +546,8 @@ def test_full_size_cfg3_geometry(gpu, oracle):
     # 256 bursts sent; the oracle, run over ALL 256 channels of this very traffic (profiles/variant_study.py, committed table), loses
     # nine of them to the reference's own M1 search (A2_found + M1_not_found): the GPU must lose exactly those nine and no other
     import json
-    rep = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_variant_sensitivity.json")))
-    row = rep["sets"]["cfg3"]["rows"]["default"]
-    lost = {freqs[b["stream"]] for b in rep["sets"]["cfg3"]["default_m1_not_found_bursts"]}
+    row = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_oracle_lost_bursts.json")))
+    lost = {freqs[i] for i in row["lost_burst_streams"]}
     assert len(lost) == row["m1_not_found"] == 256 - row["pdus"]
     assert {f for f in freqs if not any(p["freq"] == f for p in pdus)} == lost and len(pdus) == row["pdus"] == row["recovered"]
     for p in pdus:
