@@ -498,6 +498,9 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 			}
 			if (TAPS && lane == 0) io.tap_symbols[nsym] = y;
 			nsym++;
+			// (The two straight-line copies of on_symbol()'s commonest paths below are guarded against drifting from it: the test-only strict
+			// build runs EVERY symbol through on_symbol() in a serial loop with this pipeline's arithmetic forms emulated, and its PDUs must
+			// equal this kernel's in every SNR bin -- tests/test_gpu_strict.py, strict_15 == shipped.)
 			// The searching framer's symbol -- by far the commonest: a BPSK decision into the 127-bit window, the carrier loop's update, the
 			// correlation against the A sequence, and nothing found.  Decided BEFORE anything is changed: such a symbol is finished here in
 			// straight-line code; every other one (a detection, a frame in progress, the 13-frame re-centring) goes through on_symbol().

@@ -1040,6 +1040,7 @@ extern "C" int hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu
 	// done (ev_demod is recorded behind it); until then the OTHER slot is the stable one -- it was written two halves ago, and the
 	// newest half's decoders, which write it next, sit behind this half's on their stream.
 	const bool decoded = hipEventQuery(fe->ev_demod[buf]) == hipSuccess;
+	if (!decoded) (void)hipGetLastError();            // "not ready" is an answer, not an error to be found by a later check
 	int rc = fe->demod.collect_snapshot(decoded ? buf : buf ^ 1, out, max, n, fe->stream_d);
 	if (rc) return fail(rc, "pdu collection failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;

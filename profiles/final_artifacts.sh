@@ -1,21 +1,26 @@
 #!/bin/bash
 # Regenerates the measured artefacts kept under profiles/ (run through gpurun; results land in gpurun_out/final/).
-#   bash profiles/final_artifacts.sh [commit]
-C=${1:-$(python -c "import json; print(json.load(open('/root/repo/profiles/scripts/stamp.json'))['commit'])" 2>/dev/null || echo unknown)}
+#   profiles/stamp.sh                      (here, where git is: names the commit + csrc hash the artefacts are stamped with)
+#   gpurun -- 'bash profiles/final_artifacts.sh'
+#   profiles/collect_final.sh r04          (copies gpurun_out/final/* into profiles/)
+C=$(python -c "import json; print(json.load(open('/root/repo/profiles/scripts/stamp.json'))['commit'])" 2>/dev/null || echo unknown)
 OUT=/root/repo/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd /root/repo
+echo "commit $C" > $OUT/README.txt
 timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "rc=$?" >> $OUT/pytest_gpu.log
 tail -3 $OUT/pytest_gpu.log
 cp gpurun_out/low_snr_sweep.json $OUT/low_snr_sweep.json 2>/dev/null
 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench.err
 python bench.py --workload cfg2 > $OUT/bench_cfg2.json 2>> $OUT/bench.err
 python bench.py --workload cfg4 > $OUT/bench_cfg4.json 2>> $OUT/bench.err
-python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/bench_cfg3_20steps.json 2>> $OUT/bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_cfg3_driver_line.json 2>> $OUT/bench.err
+for nb in 1 4; do
+	HFDL_GPU_FOLD_BATCH=$nb python bench.py --no-cpu-baseline --no-extra-legs > $OUT/bench_cfg3_fold_batch_$nb.json 2>> $OUT/bench.err
+done
 python bench.py --host-input --sample-format cs16 --no-cpu-baseline --no-extra-legs > $OUT/bench_cfg3_host_cs16.json 2>> $OUT/bench.err
-HFDL_GPU_DEMOD_BATCH=1 python bench.py --workload cfg2 --no-cpu-baseline --no-extra-legs > $OUT/bench_cfg2_one_block_per_launch.json 2>> $OUT/bench.err
 # the N > 1 launch path through RCCL at world size 1, exactly as the driver starts it
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --steps 64 --warmup 4 --no-cpu-baseline --no-extra-legs 2>> $OUT/bench.err | grep "^{" > $OUT/bench_cfg3_rccl_world1.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --steps 64 --warmup 8 --no-cpu-baseline --no-extra-legs 2>> $OUT/bench.err | grep "^{" > $OUT/bench_cfg3_rccl_world1.json
 # the C host path on cf32 and cs16 files (raw samples over PCIe, converted on the device)
 python - > $OUT/host_path.json 2>> $OUT/bench.err <<'PY'
 import json, sys
@@ -30,29 +35,16 @@ for name in ("cfg3", "cfg2"):
     out[name] = {fmt: [bench.host_path_leg(w, x, bench.channel_plan(w), fmt) for _ in range(2)] for fmt in ("CS16", "CF32")}
 print(json.dumps(out))
 PY
-python profiles/phase_probe.py cfg2 > $OUT/phase_cycles_cfg2.txt 2>> $OUT/bench.err
+timeout 300 python profiles/fold_variants.py cfg3 3 > $OUT/fold_variants_cfg3.md 2>> $OUT/bench.err
+timeout 900 python profiles/strict_study.py --bins=-8:2:2 > $OUT/strict_study.json 2> $OUT/strict_study.md
+timeout 300 python profiles/setup_time.py > $OUT/setup_time.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg3 cfg2 cfg4; do
 	rm -rf /tmp/kt_$wl
 	rocprofv3 --kernel-trace --stats -d /tmp/kt_$wl -- python /root/repo/bench.py --workload $wl --no-cpu-baseline --no-extra-legs > $OUT/bench_${wl}_under_rocprof.json 2>/dev/null
 	DB=$(find /tmp/kt_$wl -name "*.db" | head -1)
-	python /root/repo/profiles/summarize_rocpd.py $DB "$wl -- rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --no-cpu-baseline --no-extra-legs (256 timed blocks + 8 warm-up; fft_pass* also run once per channel at create for the filter taps; commit $C)" > $OUT/${wl}_kernel_stats.md
-	python /root/repo/profiles/timeline_rocpd.py $DB 2 > $OUT/${wl}_timeline.md
+	python /root/repo/profiles/summarize_rocpd.py $DB "$wl -- rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --no-cpu-baseline --no-extra-legs (256 timed blocks + 8 warm-up, 8 blocks per fold launch; fft_pass* also run once per channel at create for the filter taps; commit $C)" > $OUT/${wl}_kernel_stats.md
+	python /root/repo/profiles/timeline_rocpd.py $DB 1 > $OUT/${wl}_timeline.md
 	bash /root/repo/profiles/pmc_passes.sh $wl $OUT $C > /dev/null 2>&1
 done
-# the C host program on cfg2 under a kernel + copy trace: demodulator gaps over the whole run
-python - <<'PY'
-import sys
-sys.path.insert(0, "/root/repo")
-import numpy as np, bench
-import dumphfdl_amd as hf
-w = bench.WORKLOADS["cfg2"]
-g = hf.plan_geometry(1024, 250 / w["fs"])
-x, _ = bench.make_input(w, g.input_size, 0, 1)
-x.view(np.float32).tofile("/tmp/cfg2.cf32")
-open("/tmp/cfg2.freqs", "w").write(" ".join("%.3f" % (f / 1e3) for f in bench.channel_plan(w)))
-PY
-rm -rf /tmp/tr
-rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/tr -- /root/repo/dumphfdl_amd/hfdl_replay --bench --loop 60 --iq-file /tmp/cfg2.cf32 --sample-rate 8000000 --sample-format CF32 --centerfreq 10000.000 $(cat /tmp/cfg2.freqs) > $OUT/replay_cfg2_traced.json 2>/dev/null
-python /root/repo/profiles/demod_gaps.py $(find /tmp/tr -name "*.db" | head -1) > $OUT/replay_cfg2_demod_gaps.txt
 ls -la $OUT
