@@ -141,10 +141,23 @@ __global__ __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(fold_w
 	__shared__ v4f tile[2][PIECES][64];
 	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row of the spectrum
 	const int cs = row4 / (64 * U);                           // column parts per row
-	const int cpart = blockIdx.x % cs;
-	const int bs = blockIdx.x / cs;
+	// blockIdx -> (tile = column part x slice, channel group).  The workgroups that share a spectrum tile must sit on ONE XCD (the
+	// dispatcher puts block b on XCD b mod 8) and be resident TOGETHER, so that the tile comes out of HBM once and out of that XCD's
+	// L2 for every other group: per XCD the channel groups vary fastest.  (Column part fastest -- the first layout -- kept only 4 of
+	// the 16 groups of a tile resident at a time and the spectra crossed the fabric four times: 1.11 x the algorithmic bytes.)
+	const int ntile = cs * slices, groups = (int)gridDim.x / ntile;
+	int tile_id, grp;
+	if ((ntile & 7) == 0) {
+		const int xcd = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+		grp = i % groups;
+		tile_id = (i / groups) * 8 + xcd;
+	} else {
+		tile_id = (int)blockIdx.x % ntile;
+		grp = (int)blockIdx.x / ntile;
+	}
+	const int cpart = tile_id % cs;
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
-	const int s = bs % slices, c0 = c_base + ((bs / slices) * WPW + wave) * NC;
+	const int s = tile_id / cs, c0 = c_base + (grp * WPW + wave) * NC;
 	const size_t col = (size_t)cpart * U * 64 + lane;
 	const unsigned voff = (unsigned)lane * 16u;
 	const char *tb = (const char *)(taps + (size_t)c0 * chan_stride4 + (size_t)s * rows * row_stride4 + (size_t)cpart * U * 64);

@@ -875,8 +875,11 @@ def test_demodulator_stage_fed_with_the_oracles_channelizer_output(gpu, oracle):
     for c in range(len(freqs)):
         want, have = ora.channel_summary(c), fe.channel_stats(c)
         assert (have["a1_found"], have["a2_found"], have["m1_found"], have["m1_not_found"]) == (want["a1_found"], want["a2_found"], want["m1_found"], want["m1_not_found"])
-    with pytest.raises(gpu.GpuError):
-        fe.push_baseband([np.zeros(fe.geometry.max_outputs_per_block + 2, np.complex64)] * len(freqs))       # more than a block holds
+    import ctypes as C                                   # a count beyond what a block holds is refused (HFDL_GPU_ERANGE), nothing is queued
+    row = fe.geometry.max_outputs_per_block + 1
+    buf, cnt = np.zeros((len(freqs), row), np.complex64), np.full(len(freqs), row + 1, np.int32)
+    assert F.load().hfdl_gpu_frontend_push_baseband(fe._h, buf.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)) == -5
+    assert fe.poll_pdus() == []
     fe.close()
     ora.close()
 
