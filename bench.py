@@ -401,11 +401,25 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def traffic_record(workload, blocks_per_launch=None):
+def fold_launch_shapes(steps, fold_batch):
+    """Blocks per fold launch of a timed region of `steps` blocks that starts on an empty half and is closed by one draining poll
+    (timed_blocks): full halves, then the rest split 8 / 4 / 2 / 1 (hfdl_gpu.cpp close_half, fold_kernels.hip launch_fold)."""
+    half = fold_batch
+    shapes = [half] * (steps // half)
+    rest = steps % half
+    for t in (8, 4, 2, 1):
+        while t <= half and rest >= t:
+            shapes.append(t)
+            rest -= t
+    return shapes
+
+
+def traffic_record(workload, shapes=None, launches=None):
     """HBM bytes per fold launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs, corrected as the
     MI355X guide prescribes): a bench run cannot collect counters itself, so the line names where the figure comes from -- and
-    whether the kernels it was measured on are the ones this run executes (csrc_matches_head) at this run's blocks per launch.
-    A record that fails either check is reported as stale and `traffic` is null."""
+    whether the kernels it was measured on are the ones this run executes (csrc_matches_head).  `shapes` = this run's launches by
+    blocks per launch: the figure is the average over them of the record's per-shape measurements (a launch of 4 blocks moves
+    other bytes than one of 8).  A record that fails a check is reported as stale and `traffic` is null."""
     tfile = os.path.join(ROOT, "profiles", "fold_traffic_%s.json" % workload)
     if not os.path.exists(tfile):
         return None, None
@@ -413,15 +427,20 @@ def traffic_record(workload, blocks_per_launch=None):
         t = json.load(open(tfile))
         now = csrc_hash()
         same_code = t.get("csrc_sha16") == now
-        same_shape = blocks_per_launch is None or t.get("blocks_per_launch") is None or abs(t["blocks_per_launch"] - blocks_per_launch) < 1e-9
+        per = t.get("per_shape") or ({str(t["blocks_per_launch"]): t} if t.get("blocks_per_launch") else {})
         src = dict(file="profiles/fold_traffic_%s.json" % workload, measured_at_commit=t.get("measured_at_commit"),
                    csrc_sha16_at_measurement=t.get("csrc_sha16"), csrc_sha16_now=now, csrc_matches_head=bool(same_code),
-                   blocks_per_launch_at_measurement=t.get("blocks_per_launch"), kernel=t.get("kernel"),
+                   shapes_measured=sorted(int(k) for k in per), kernel=t.get("kernel"),
                    collected_by=t.get("command"), note="replayed from that file, not observed by this run")
-        if not (same_code and same_shape):
-            src["stale"] = "the record was measured on other device code or another launch shape: traffic withheld"
+        if shapes is None:
+            shapes = [t.get("blocks_per_launch")]
+        src["launch_shapes_of_this_run"] = {str(nb): shapes.count(nb) for nb in sorted(set(shapes))}
+        ok = same_code and all(str(nb) in per for nb in shapes) and (launches is None or launches == len(shapes))
+        if not ok:
+            src["stale"] = "measured on other device code, or this run launched shapes the record does not hold: traffic withheld"
             return None, src
-        return t.get("hbm_bytes_per_launch"), src
+        src["traffic_over_algorithmic"] = {str(nb): per[str(nb)]["traffic_over_algorithmic"] for nb in sorted(set(shapes))}
+        return sum(per[str(nb)]["hbm_bytes_per_launch"] for nb in shapes) / len(shapes), src
     except Exception:
         return None, None
 
@@ -735,7 +754,7 @@ def main():
     if rank == 0:
         samples = total_samples
         achieved = alg_bytes / (fold_avg_ms * 1e-3) / 1e9 if fold_n else None
-        traffic, traffic_src = traffic_record(args.workload, fold_nb)
+        traffic, traffic_src = traffic_record(args.workload, fold_launch_shapes(args.steps, fold_batch), fold_n)
         par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, geom["channels"])) if args.shard == "streams" else \
               ("ONE %d-channel stream, channels round-robin over %d GPUs (%d on rank 0), every GPU ingests the same block; no collectives"
                % (len(all_freqs), world, geom["channels"]))

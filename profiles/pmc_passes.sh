@@ -10,11 +10,11 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_${WL}_*
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
 	d=/tmp/pmc_${WL}_$(echo $c | tr ' ' '_' | cut -c1-40)
-	rocprofv3 --pmc $c --kernel-trace -d $d -- python /root/repo/bench.py --workload $WL --steps 32 --warmup 8 --no-cpu-baseline --no-extra-legs > $d.log 2>&1
+	rocprofv3 --pmc $c --kernel-trace -d $d -- python /root/repo/bench.py --workload $WL --steps 39 --warmup 8 --no-cpu-baseline --no-extra-legs > $d.log 2>&1
 done
 DBS=$(find /tmp/pmc_${WL}_* -name "*.db" | sort)
 {
-	echo "# r04 $WL PMC passes (profiles/pmc_passes.sh $WL: rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --workload $WL --steps 32 --warmup 8 --no-cpu-baseline --no-extra-legs, one pass per counter set; commit $COMMIT)"
+	echo "# r04 $WL PMC passes (profiles/pmc_passes.sh $WL: rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --workload $WL --steps 39 --warmup 8 --no-cpu-baseline --no-extra-legs, one pass per counter set; commit $COMMIT)"
 	echo
 	echo "Per-dispatch averages. FETCH_SIZE / WRITE_SIZE in KB; on gfx950 reads = 2 x FETCH_SIZE for wide coalesced streaming reads (calibrated in the same run on stream_read_kernel, which reads a known byte count). SQ_* count quad-cycles summed over the dispatch's waves."
 	echo
