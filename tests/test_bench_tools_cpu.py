@@ -1,0 +1,56 @@
+"""bench.py's roofline bookkeeping (no GPU): the per-launch byte model, the launch shapes of a timed region, and the guard that keeps
+a traffic record measured on other device code -- or on other launch shapes -- out of the line."""
+import json
+import os
+
+import pytest
+
+import bench
+
+
+class G:          # the cfg3 geometry (hfdl_gpu_geometry fields the model reads)
+    input_size, channels, fft_size, post_input_size, post_decimation = 7340032, 256, 8388608, 3584, 2
+
+
+def test_algorithmic_bytes_per_launch_restates_the_per_block_model():
+    assert bench.alg_bytes_per_launch(G, 1) == bench.alg_bytes_per_block(G) == 17_242_259_456          # 2349.1 B/sample
+    b8 = bench.alg_bytes_per_launch(G, 8)
+    assert b8 == 8 * 8 * G.input_size + 256 * 8 * G.fft_size + 256 * 8 * 8 * 1792 == 17_678_991_360   # the taps ONCE for 8 blocks
+    assert b8 < 8 * bench.alg_bytes_per_block(G) / 7.7
+
+
+def test_launch_shapes_of_a_timed_region():
+    assert bench.fold_launch_shapes(20, 8) == [8, 8, 4]              # the driver's --steps 20
+    assert bench.fold_launch_shapes(256, 8) == [8] * 32
+    assert bench.fold_launch_shapes(39, 8) == [8, 8, 8, 8, 4, 2, 1]  # the PMC pass: every shape once
+    assert bench.fold_launch_shapes(7, 4) == [4, 2, 1] and bench.fold_launch_shapes(3, 1) == [1, 1, 1]
+
+
+def test_stale_traffic_is_withheld(tmp_path, monkeypatch):
+    rec = dict(kernel="k", blocks_per_launch=8, measured_at_commit="abc", csrc_sha16="1111", hbm_bytes_per_launch=100,
+               per_shape={"8": dict(hbm_bytes_per_launch=100, traffic_over_algorithmic=1.02), "4": dict(hbm_bytes_per_launch=60, traffic_over_algorithmic=1.01)})
+    os.makedirs(tmp_path / "profiles")
+    json.dump(rec, open(tmp_path / "profiles" / "fold_traffic_cfgX.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_hash", lambda: "1111")
+    t, src = bench.traffic_record("cfgX", [8, 8, 4], 3)
+    assert t == pytest.approx((100 + 100 + 60) / 3) and src["csrc_matches_head"] and "stale" not in src
+    t, src = bench.traffic_record("cfgX", [8, 2], 2)                  # a shape the record does not hold
+    assert t is None and "stale" in src
+    t, src = bench.traffic_record("cfgX", [8, 8, 4], 4)               # the run launched something else than reconstructed
+    assert t is None and "stale" in src
+    monkeypatch.setattr(bench, "csrc_hash", lambda: "2222")           # other kernels than the ones measured
+    t, src = bench.traffic_record("cfgX", [8, 8, 4], 3)
+    assert t is None and src["csrc_matches_head"] is False and "stale" in src
+
+
+def test_committed_traffic_records_match_the_committed_kernels():
+    """The records under profiles/ were measured on THIS tree's dumphfdl_amd/csrc: a kernel edit without a new PMC pass fails here."""
+    for wl in ("cfg3", "cfg2", "cfg4"):
+        rec = json.load(open(os.path.join(bench.ROOT, "profiles", "fold_traffic_%s.json" % wl)))
+        assert rec["csrc_sha16"] == bench.csrc_hash(), \
+            "%s: dumphfdl_amd/csrc changed since profiles/fold_traffic_%s.json was measured -- commit, run profiles/stamp.sh, then " \
+            "`gpurun -- bash profiles/pmc_passes.sh %s gpurun_out/final <commit>` and copy the record into profiles/" % (wl, wl, wl)
+        assert set(rec["per_shape"]) >= {"8", "4"}
+    r3 = json.load(open(os.path.join(bench.ROOT, "profiles", "fold_traffic_cfg3.json")))
+    assert r3["per_shape"]["8"]["traffic_over_algorithmic"] <= 1.05           # no wasted re-reads on the roofline kernel
