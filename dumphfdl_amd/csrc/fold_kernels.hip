@@ -62,10 +62,22 @@ __global__ __launch_bounds__(FOLD_THREADS) __attribute__((amdgpu_waves_per_eu(fo
 		int m, int slices, int rows, int c_base)
 {
 	constexpr int LANES = WV ? 64 : FOLD_THREADS;             // threads side by side along a row
-	const int cpart = blockIdx.x % CS;
-	const int bs = blockIdx.x / CS;
+	// blockIdx -> (tile = column part x slice, channel group), XCD-aware: block b runs on XCD b mod 8; a tile's workgroups all land on
+	// one XCD and, there, the channel groups vary fastest, so the groups that share a tile of the spectra are resident together and the
+	// tile crosses the fabric once (see fold_kernel_lds; with 8 tiles -- cfg3 at one block per launch -- this is the round-1 layout)
+	const int ntile = CS * slices, groups = (int)gridDim.x / ntile;
+	int tile_id, grp;
+	if ((ntile & 7) == 0) {
+		const int xcd = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+		grp = i % groups;
+		tile_id = (i / groups) * 8 + xcd;
+	} else {
+		tile_id = (int)blockIdx.x % ntile;
+		grp = (int)blockIdx.x / ntile;
+	}
+	const int cpart = tile_id % CS;
 	const int wave = WV ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, lane = WV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-	const int s = bs % slices, c0 = c_base + ((bs / slices) * (WV ? 4 : 1) + wave) * NC;
+	const int s = tile_id / CS, c0 = c_base + (grp * (WV ? 4 : 1) + wave) * NC;
 	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row of the spectrum
 	const size_t col = (size_t)cpart * U * LANES + lane;
 	// Addresses = a wave-uniform base per stream (scalar registers, stepped by scalar adds) + ONE 32-bit byte offset per thread + an

@@ -944,6 +944,45 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
         assert stats == ref_stats, (fold_env, cuts)
 
 
+def test_fft_stream_switch_changes_nothing(gpu, monkeypatch):
+    """HFDL_GPU_FFT_STREAM=1 (forward FFTs of the half being filled on a stream of their own, beside the fold of the half before: two
+    sets of spectra, phasor tables and state snapshots chained by events) is an A/B switch that is off by default (measured slower on
+    cfg3): it must give the same channelizer output, bit for bit, and the same PDUs -- full halves, ragged cuts,
+    lagging collections and channelizer-only blocks in between."""
+    fs, cf = 250000, 10_000_000
+    freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000, 10_101_000]
+    dur = 10.0
+    bursts = synth.plan_traffic(freqs, dur, seed=61, dense=True, gap_s=0.12, amp=(0.02, 0.1))
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.012, seed=61)
+
+    def run(own_stream):
+        monkeypatch.setenv("HFDL_GPU_FFT_STREAM", "1" if own_stream else "0")
+        fe = gpu.Frontend(fs, cf, freqs)
+        n, got, outs = fe.input_size, [], []
+        for b in range(len(x) // n):
+            blk = x[b * n:(b + 1) * n]
+            if b == 20:
+                fe.channelize_block(blk)               # never demodulated, in both runs
+                outs.append(fe.read_tap(F.TAP_CHAN_OUT, 3).view(np.uint32).copy())
+                continue
+            fe.push_block(blk)
+            if b % 11 == 4:
+                got += fe.poll_pdus()                  # a draining poll: a ragged half
+                outs.append(fe.read_tap(F.TAP_CHAN_OUT, 1).view(np.uint32).copy())
+            elif b % 5 == 0:
+                got += fe.poll_pdus(max_in_flight=1)
+        got += fe.poll_pdus()
+        outs.append(fe.read_tap(F.TAP_CHAN_OUT, 4).view(np.uint32).copy())
+        stats = fe.all_channel_stats()
+        fe.close()
+        return sorted(got, key=lambda p: (p["freq"], p["sample_index"])), outs, stats
+
+    ref, ref_outs, ref_stats = run(False)
+    got, outs, stats = run(True)
+    assert len(ref) >= len(bursts) - 3 and got == ref and stats == ref_stats
+    assert len(outs) == len(ref_outs) and all(np.array_equal(a, b) for a, b in zip(outs, ref_outs))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_random_call_sequences_equal_a_launch_per_block(gpu, monkeypatch, seed):
     """The batching state machine under random use: after every pushed block one of {nothing, lagging collection, draining poll, sync,
