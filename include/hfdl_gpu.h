@@ -166,12 +166,13 @@ int  hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe);
 /* Collect PDUs produced by all blocks enqueued so far (implies a sync). Returns count in *n.  `out` must hold `max`
  * entries; out == NULL with max > 0 is HFDL_GPU_EINVAL (nothing is discarded), max == 0 just syncs. */
 int  hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n);
-/* Same without draining the pipeline: with max_in_flight = 1 the newest demodulator launch (one block, or geometry.demod_batch
- * blocks on the small geometries) keeps running; the call waits only for the demodulator of the launch before it and returns the PDUs
- * known to be complete at that moment -- those of that launch if its burst decoder has finished too, otherwise they come with the next
- * call (nothing until two launches were made).  max_in_flight = 0 is hfdl_gpu_frontend_poll_pdus().  A file replay pushes block k+1,
- * then collects this way, so copies, channelizer, demodulator and burst decoder of consecutive blocks overlap; a live receiver that has
- * no further input queued uses 0 and gets its PDUs at once. */
+/* Same without draining the pipeline: with max_in_flight = 1 whatever was pushed since the last half filled keeps filling, the newest
+ * CLOSED half (geometry.fold_batch blocks, or max(fold_batch, demod_batch)) keeps running; the call waits only for the demodulators of the
+ * half before it and returns the PDUs known to be complete at that moment -- those of that half if its burst decoders have finished too,
+ * otherwise they come with the next call (nothing until two halves were closed).  max_in_flight = 0 is hfdl_gpu_frontend_poll_pdus().
+ * A file replay pushes block k+1, then collects this way, so copies, channelizer, demodulator and burst decoder of consecutive halves
+ * overlap and the fold shares its pass over the filter taps between the blocks of a half; a live receiver that has no further input
+ * queued uses 0 and gets its PDUs at once. */
 int  hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32_t max, int32_t *n, int32_t max_in_flight);
 /* PDUs wait in a device ring of pdu_ring_capacity entries; one that finds the ring full is dropped and counted
  * (the reference's GAsyncQueue is unbounded, src/pdu.c:37-43: poll at least once per few seconds of signal).
