@@ -260,13 +260,11 @@ static int pick_demod_batch(const hfdl_gpu_frontend *fe)
 // catching up, the bench) the spectra of up to `fold_nb` consecutive blocks are folded in ONE pass over the taps
 // (fold_kernels.hip, NB).  Every block's sums are bit-identical to a launch of its own (fixed FMA chain per bin); a caller that polls
 // or syncs after every block (live input) still gets one launch per block: a sync / poll closes the half as it is.
-static int pick_fold_batch(const hfdl_gpu_frontend *fe)
+static int pick_fold_batch()
 {
-	// 8: measured on cfg3 (profiles/r04_experiments.md) -- a launch of 8 takes 3.0 ms against 2.5 for 4 and 2.5 for 1; beyond that the
-	// multiplies (4 FMAs per tap and block) cost as much as the taps' HBM time and the register tile (acc[NB][NC]) runs out.
-	// Where the demodulator bounds the step (few channels: the decoder has its own stream) the fold is a few per cent of a block and a
-	// half longer than one demodulator launch only lengthens the pipeline's fill and drain: the half is one demodulator launch.
-	int want = fe->own_decode_stream ? std::max(1, std::min(8, fe->batch)) : 8;
+	// 8: measured on cfg3 (profiles/r04_experiments.md) -- a launch of 8 takes 3.4 ms against 2.6 for 4 and 2.5 for 1; beyond that the
+	// multiplies (4 FMAs per tap and block) cost as much as the taps' HBM time and the register tile (acc[NB][NC]) runs out
+	int want = 8;
 	if (const char *e = getenv("HFDL_GPU_FOLD_BATCH")) {        // A/B measurements; 1 = a pass over the taps per block
 		const long v = strtol(e, nullptr, 10);
 		if (v >= 1 && v <= hfdl_gpu_frontend::MAX_HALF) want = (int)v;
@@ -436,7 +434,7 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	float resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)fe->decimation);
 	if ((rc = fe->demod.init(nch, g.outs, resamp_rate, fe->freqs.data(), fe->stream, pick_demod_batch(fe)))) { frontend_free(fe); return rc; }
 	fe->batch = fe->demod.batch;        // what fits the demodulator's LDS
-	fe->fold_nb = pick_fold_batch(fe);
+	fe->fold_nb = pick_fold_batch();
 	fe->half_blocks = std::min((int)hfdl_gpu_frontend::MAX_HALF, ((std::max(fe->fold_nb, fe->batch) + fe->fold_nb - 1) / fe->fold_nb) * fe->fold_nb);
 	const size_t hb = (size_t)fe->half_blocks;
 	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n * 2 * hb));

@@ -77,7 +77,7 @@ typedef struct {
 	                                    they are pushed faster than they are collected (src/fastddc.c:123-150 run for that many blocks; the taps are
 	                                    > 99 % of a block's bytes on the 256-channel geometries).  Every block's result is bit-identical to a launch
 	                                    of its own; a poll / sync always folds what has been pushed.  HFDL_GPU_FOLD_BATCH=1..8 overrides the default
-	                                    at create time (8; demod_batch on the small geometries the demodulator bounds).  0 from hfdl_gpu_plan_geometry() */
+	                                    of 8 at create time.  0 from hfdl_gpu_plan_geometry() */
 } hfdl_gpu_geometry;
 
 /* one decoded PDU: what dispatch_pdu() hands to pdu_decoder_queue_push (src/hfdl.c:1058-1080,

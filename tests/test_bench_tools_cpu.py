@@ -51,6 +51,6 @@ def test_committed_traffic_records_match_the_committed_kernels():
         assert rec["csrc_sha16"] == bench.csrc_hash(), \
             "%s: dumphfdl_amd/csrc changed since profiles/fold_traffic_%s.json was measured -- commit, run profiles/stamp.sh, then " \
             "`gpurun -- bash profiles/pmc_passes.sh %s gpurun_out/final <commit>` and copy the record into profiles/" % (wl, wl, wl)
-        assert set(rec["per_shape"]) >= ({"4"} if wl == "cfg2" else {"8", "4"})        # cfg2 (demodulator-bound) folds one demodulator launch = 4 blocks at a time
+        assert set(rec["per_shape"]) >= {"8", "4"}
     r3 = json.load(open(os.path.join(bench.ROOT, "profiles", "fold_traffic_cfg3.json")))
     assert r3["per_shape"]["8"]["traffic_over_algorithmic"] <= 1.05           # no wasted re-reads on the roofline kernel
