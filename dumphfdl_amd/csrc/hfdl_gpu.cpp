@@ -737,6 +737,7 @@ extern "C" int hfdl_gpu_frontend_push_baseband(hfdl_gpu_frontend *fe, const floa
 	HIP_TRY(hipMemcpy(fe->chan_slot(slot0), chan_out, sizeof(float2) * (size_t)g.nch * (size_t)g.outs, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(fe->cnt_slot(slot0), counts, sizeof(int32_t) * (size_t)g.nch, hipMemcpyHostToDevice));
 	fe->last_slot = slot0;
+	fe->last_index = 0;                                     // one block in this half: nothing further back to read (read_tap_block)
 	fe->cur_half ^= 1;
 	fe->prev_demod_buf = fe->demod_buf;
 	fe->demod_buf = half;
