@@ -54,3 +54,28 @@ def test_committed_traffic_records_match_the_committed_kernels():
         assert set(rec["per_shape"]) >= {"8", "4"}
     r3 = json.load(open(os.path.join(bench.ROOT, "profiles", "fold_traffic_cfg3.json")))
     assert r3["per_shape"]["8"]["traffic_over_algorithmic"] <= 1.05           # no wasted re-reads on the roofline kernel
+
+
+def test_xcd_aware_tile_placement_is_a_bijection():
+    """fold_kernels.hip maps blockIdx -> (tile, channel group) so that a tile's workgroups land on one XCD (block b runs on XCD b mod 8)
+    with the groups varying fastest there; the same arithmetic here: every (tile, group) exactly once, a tile on one XCD, and the
+    workgroups of one tile consecutive in that XCD's dispatch order."""
+    def place(b, ntile, groups):
+        if ntile % 8 == 0:
+            xcd, i = b & 7, b >> 3
+            return (i // groups) * 8 + xcd, i % groups
+        return b % ntile, b // ntile
+
+    for ntile, groups in ((8, 128), (128, 16), (64, 8), (128, 8), (32, 3), (12, 5), (1, 4)):
+        seen, xcd_of = set(), {}
+        for b in range(ntile * groups):
+            t, g = place(b, ntile, groups)
+            assert 0 <= t < ntile and 0 <= g < groups and (t, g) not in seen
+            seen.add((t, g))
+            if ntile % 8 == 0:
+                assert xcd_of.setdefault(t, b & 7) == (b & 7)
+        assert len(seen) == ntile * groups
+        if ntile % 8 == 0:
+            for x in range(8):
+                order = [place(b, ntile, groups)[0] for b in range(x, ntile * groups, 8)]         # this XCD's blocks in dispatch order
+                assert order == sorted(order) and all(order[i:i + groups] == [order[i]] * groups for i in range(0, len(order), groups))
