@@ -401,25 +401,28 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def fold_launch_shapes(steps, fold_batch):
-    """Blocks per fold launch of a timed region of `steps` blocks that starts on an empty half and is closed by one draining poll
-    (timed_blocks): full halves, then the rest split 8 / 4 / 2 / 1 (hfdl_gpu.cpp close_half, fold_kernels.hip launch_fold)."""
-    half = fold_batch
-    shapes = [half] * (steps // half)
-    rest = steps % half
-    for t in (8, 4, 2, 1):
-        while t <= half and rest >= t:
-            shapes.append(t)
-            rest -= t
-    return shapes
+def stream_read_leg(w, freqs, dev_index):
+    """What the board's HBM delivers to a bare read-only kernel over the same 16 GiB of filter taps: a probe of the LABORATORY build
+    (libhfdl_gpu_lab.so, include/hfdl_gpu_lab.h) on a front end of its own -- the product library carries no probes."""
+    try:
+        from dumphfdl_amd import frontend as F
+        fe = F.Frontend(w["fs"], w["centerfreq"], freqs, device=dev_index, lib=F.load_lab())
+        try:
+            return fe.stream_read_probe()
+        finally:
+            fe.close()
+    except Exception as e:                      # noqa: BLE001 -- the probe is an extra: the line says why it is missing
+        sys.stderr.write("bench.py: stream-read probe unavailable: %s\n" % e)
+        return None
 
 
 def traffic_record(workload, shapes=None, launches=None):
     """HBM bytes per fold launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs, corrected as the
     MI355X guide prescribes): a bench run cannot collect counters itself, so the line names where the figure comes from -- and
-    whether the kernels it was measured on are the ones this run executes (csrc_matches_head).  `shapes` = this run's launches by
-    blocks per launch: the figure is the average over them of the record's per-shape measurements (a launch of 4 blocks moves
-    other bytes than one of 8).  A record that fails a check is reported as stale and `traffic` is null."""
+    whether the kernels it was measured on are the ones this run executes (csrc_matches_head).  `shapes` = this run's timed launches
+    by blocks per launch, AS THE LIBRARY COUNTED THEM (hfdl_gpu_frontend_fold_launch_shapes): the figure is the average over them of
+    the record's per-shape measurements (a launch of 4 blocks moves other bytes than one of 16).  A record that fails a check is
+    reported as stale and `traffic` is null."""
     tfile = os.path.join(ROOT, "profiles", "fold_traffic_%s.json" % workload)
     if not os.path.exists(tfile):
         return None, None
@@ -711,6 +714,7 @@ def main():
     fold_blk = fe.fold_blocks()
     dm_ms, dm_n, dm_blk = fe.demod_time_ms()
     period_ms = fe.step_period_ms()
+    shapes = fe.fold_launch_shapes()                       # {blocks per launch: timed launches}
     barrier()
     fe.reset_timers(False)
     good = sum(1 for p in pdus if matches_sent(p, bursts_by_freq))
@@ -735,7 +739,6 @@ def main():
     solo = world == 1 and rank == 0
     if solo and not args.no_extra_legs and not args.host_input:
         hbuf, extra["host_ram_input"] = host_ram_leg(torch, hf, F, fe, x, g, nblocks, args.steps)
-    stream_gbs = fe.stream_read_probe() if rank == 0 else None       # after the timed regions: the board's own read ceiling
     if solo and not args.no_extra_legs:
         extra["fec"] = fec_capacity(hf, dev_index)
     geom = dict(channels=g.channels, fft_size=g.fft_size, fft_inv_size=g.fft_inv_size, input_size=g.input_size)
@@ -750,11 +753,12 @@ def main():
     del dev
     if hbuf:
         hf.host_free(hbuf)
+    stream_gbs = stream_read_leg(w, freqs, dev_index) if rank == 0 else None       # after the timed regions: the board's own read ceiling
 
     if rank == 0:
         samples = total_samples
         achieved = alg_bytes / (fold_avg_ms * 1e-3) / 1e9 if fold_n else None
-        traffic, traffic_src = traffic_record(args.workload, fold_launch_shapes(args.steps, fold_batch), fold_n)
+        traffic, traffic_src = traffic_record(args.workload, [nb for nb, cnt in sorted(shapes.items()) for _ in range(cnt)], fold_n)
         par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, geom["channels"])) if args.shard == "streams" else \
               ("ONE %d-channel stream, channels round-robin over %d GPUs (%d on rank 0), every GPU ingests the same block; no collectives"
                % (len(all_freqs), world, geom["channels"]))

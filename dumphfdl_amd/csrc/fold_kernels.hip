@@ -3,13 +3,13 @@
 // Replaces fastddc_inv_cc (reference src/fastddc.c:152-215): multiply_and_shift (:123-150), fft_swap_sides,
 // the M-point backward FFT + normalisation (:190-197) and decimating_shift_addition_cc (src/libcsdr_gpl.c:41-74).
 //
-// fold_kernel is THE roofline kernel: per channel it streams N cf32 filter taps (distinct per channel, read once,
-// 8*N bytes) against the shared N-bin spectrum and accumulates the N/M alias rows onto M bins:
+// The fold is THE roofline kernel: per channel it streams N cf32 filter taps (distinct per channel, 8*N bytes) against the shared
+// N-bin spectrum and accumulates the N/M alias rows onto M bins:
 //      Y_c[(h0 + j) mod M] = sum_a  H_c[a*M + j] * X[a*M + j]
-// Workgroup = (channel pair, slice of alias rows, half of the M columns); a row is M contiguous cf32, so every wave
-// issues 1 KiB dwordx4 runs; each spectrum value is loaded once and multiplied into both channels' tap streams.
-// blockIdx -> (column half, slice, pair): the dispatcher puts block b on XCD b mod 8, so every XCD's L2 only ever
-// sees 1/8 of the spectrum (two slices x one column half), shared by all channels.
+// The taps are the same for every block, so one launch multiplies them into the spectra of up to 16 queued blocks -- and with more
+// than one block the fold IS a small dense contraction per bin j:  Y[j] (channels x blocks) = H[j] (channels x alias rows) . X[j]
+// (alias rows x blocks).  It runs on the fp32 matrix pipe (v_mfma_f32_4x4x1_16B_f32: sixteen independent 4x4 outer products per
+// instruction = sixteen bins), which takes the multiply-accumulates off the vector ALUs the demodulator kernel next door lives on.
 #include <hip/hip_ext.h>
 #include "kernels.h"
 #include "fft_core.h"
@@ -19,145 +19,110 @@ namespace hfdl {
 constexpr int FOLD_THREADS = 256;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-// streamed-once filter taps: non-temporal 16-byte load, so they do not evict the shared spectrum from L2
-__device__ __forceinline__ float4 load_stream(const float4 *p)
+// ---- tap layout -------------------------------------------------------------------------------------------------------------
+// Plain (M not a multiple of 64): element (channel c, alias row r, bin j) at r * tap_row_stride + c * M + j, cf32.
+// Pair-interleaved (every other geometry), in floats: row r, channel pair q = c / 2, group g = j / 64 of 64 bins:
+//      r * 2 * tap_row_stride + q * 4 M + g * 256 + lane * 4 + v,      lane = 4 * (j % 16) + i,   v = (j / 16) % 4,
+//      i = 0: Re H_c0   1: Im H_c0   2: Re H_c1   3: Im H_c1        (c0 = 2 q, c1 = 2 q + 1)
+// i.e. one 1 KiB wave load (16 bytes per lane) of a pair's group yields, in register v of lane 4 b + i, operand A of the 4x4x1
+// instruction that handles bins 64 g + 16 v + b (b = 0..15, one per block of the instruction): rows (Re c0, Im c0, Re c1, Im c1).
+// Alias row r of ALL channels is still one nch * M run, so the workgroups of all channels, which walk the rows together, stream
+// through a few moving windows of HBM.
+
+__device__ __forceinline__ float2 tap_at(const float *taps, size_t row_stride_f, int m, int pair_layout, int c, int row, int j)
 {
-	v4f v = __builtin_nontemporal_load((const v4f *)p);
-	return make_float4(v.x, v.y, v.z, v.w);
+	if (!pair_layout) return ((const float2 *)taps)[(size_t)row * (row_stride_f >> 1) + (size_t)c * m + j];
+	const int g = j >> 6, v = (j >> 4) & 3, b = j & 15, i0 = (c & 1) * 2;
+	const float *p = taps + (size_t)row * row_stride_f + (size_t)(c >> 1) * 4 * m + (size_t)g * 256 + v;
+	return make_float2(p[(4 * b + i0) * 4], p[(4 * b + i0 + 1) * 4]);
 }
 
-// One complex multiply-accumulate per bin, spelled out as FMAs in a FIXED order so that every instantiation below -- any
-// (U, CS, NC, NB) -- rounds a (block, channel, bin) sum exactly alike: a block folded alone and the same block folded beside three
-// others give the same 32 bits (tests/test_gpu_parity.py::test_fold_batching_changes_nothing).
-__device__ __forceinline__ void cmac2(v4f &a, const v4f h, const v4f x)
+// plain -> pair-interleaved, in place, one workgroup per (alias row, channel pair): the pair's 2 M taps go through LDS
+__global__ __launch_bounds__(FOLD_THREADS) void tap_interleave_kernel(float *taps, size_t row_stride_f, int m, int npairs)
 {
-	a.x = __builtin_fmaf(h.x, x.x, a.x); a.x = __builtin_fmaf(-h.y, x.y, a.x);
-	a.y = __builtin_fmaf(h.x, x.y, a.y); a.y = __builtin_fmaf(h.y, x.x, a.y);
-	a.z = __builtin_fmaf(h.z, x.z, a.z); a.z = __builtin_fmaf(-h.w, x.w, a.z);
-	a.w = __builtin_fmaf(h.z, x.w, a.w); a.w = __builtin_fmaf(h.w, x.z, a.w);
+	extern __shared__ float sm_t[];         // 4 M floats
+	const int pr = blockIdx.x % npairs, row = blockIdx.x / npairs;
+	float *base = taps + (size_t)row * row_stride_f + (size_t)pr * 4 * m;
+	for (int e = threadIdx.x; e < 4 * m; e += FOLD_THREADS) sm_t[e] = base[e];
+	__syncthreads();
+	for (int e = threadIdx.x; e < 4 * m; e += FOLD_THREADS) {
+		const int v = e & 3, lane = (e >> 2) & 63, g = e >> 8;
+		const int i = lane & 3, b = lane >> 2, j = g * 64 + v * 16 + b;
+		base[e] = sm_t[(i >> 1) * 2 * m + 2 * j + (i & 1)];
+	}
 }
 
-// U float4 (= 2U bins) per thread per alias row; R = alias rows per loop trip; CS = column split: a workgroup covers 1/CS of a
-// row; NC = channels per thread sharing every spectrum load; NB = BLOCKS per launch sharing every tap load: the spectra of NB
-// consecutive blocks (`spec_stride4` apart) are folded against ONE pass over the taps -- the taps are 99.9 % of a block's bytes and
-// identical from block to block, so when blocks are queued (replay, catch-up, the bench) a launch serves NB of them for the HBM
-// traffic of one (src/fastddc.c:123-150 run NB times).  Register tile: acc[NB][NC][U], an NB x NC outer product per column.
-// WV = waves over channels: the workgroup's four wavefronts cover the SAME 64 * U columns and four different groups of NC channels,
-// so one wave's spectrum loads fill the CU's L1 and the other three hit it: with NB blocks per launch the spectrum traffic out of
-// L2 is NB / NC times the tap traffic (measured: what bounds the launch, profiles/r04_fold_variants.md), NB / (4 NC) this way.
-// waves per SIMD the register tile allows (512 VGPRs per lane and SIMD).  Told to the compiler: with a bare __launch_bounds__(256) it
-// aims at 8 waves per SIMD, squeezes the kernel into 64 VGPRs and gets there by issuing a load or two, waiting, multiplying, loading
-// again -- one or two kilobytes in flight per wave where the trip has eight or more to ask for at once.
-constexpr int fold_waves(int u, int r, int nc, int nb, bool lds = false)
+// One complex multiply-accumulate per bin as a FIXED chain of four fused multiply-adds -- the order the matrix instructions below
+// apply them in (real part of X first, then the imaginary part), so that the plain-VALU reference and every MFMA tiling round a
+// (block, channel, bin) sum exactly alike: a block folded alone and the same block folded beside fifteen others give the same 32 bits
+// (tests/test_gpu_parity.py::test_fold_batching_changes_nothing, ::test_fold_mfma_equals_fma_chain).
+__device__ __forceinline__ void cmac_chain(float2 &a, const float2 h, const float2 x)
 {
-	const int regs = 4 * (nb * nc * u + nc * r * u + nb * r * u) + (lds ? 16 : 24);
+	a.x = __builtin_fmaf(h.x, x.x, a.x); a.y = __builtin_fmaf(h.y, x.x, a.y);
+	a.x = __builtin_fmaf(-h.y, x.y, a.x); a.y = __builtin_fmaf(h.x, x.y, a.y);
+}
+
+// reference / fallback: one thread per (channel, slice, bin), either tap layout, any geometry, `nb` blocks one after the other
+__global__ __launch_bounds__(FOLD_THREADS) void fold_ref_kernel(const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
+		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int pair_layout, int nb)
+{
+	const int s = blockIdx.x % slices, c = blockIdx.x / slices;
+	for (int b0 = 0; b0 < nb; b0 += 4)              // four blocks per pass over the taps
+		for (int j = threadIdx.x; j < m; j += FOLD_THREADS) {
+			const float2 *sp = spec + (size_t)b0 * spec_stride + (size_t)s * rows * (size_t)m + j;
+			float2 acc[4] = { make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f) };
+			for (int r = 0; r < rows; r++) {
+				const float2 h = tap_at(taps, row_stride_f, m, pair_layout, c, s * rows + r, j);
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					if (b0 + k < nb) cmac_chain(acc[k], h, sp[(size_t)k * spec_stride + (size_t)r * m]);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				if (b0 + k < nb) partial[(size_t)(b0 + k) * partial_stride + ((size_t)c * slices + s) * (size_t)m + j] = acc[k];
+		}
+}
+
+// lanes 4 b + i: i <-> i ^ 1 inside every quad, then the sign of the even lanes flipped: (Re c0, Im c0, Re c1, Im c1) -> (-Im c0, Re c0, -Im c1, Re c1)
+__device__ __forceinline__ float rot90(float a, int sign_mask)
+{
+	const int v = __builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+	return __int_as_float(v ^ sign_mask);
+}
+
+// registers the tile asks for -> waves per SIMD told to the compiler (512 per lane and SIMD): left to itself it aims at 8 waves,
+// squeezes the loop into 64 registers and gets there by loading, waiting, multiplying, loading again
+constexpr int fold_mfma_waves(int p, int q, int w, int d)
+{
+	const int mine = (2 * q + w - 1) / w;
+	const int regs = 16 * p * q + 4 * p * d + 4 * mine * d + 8 * q + 4 * p + 28;
 	return regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
 }
 
-template <int U, int R, int CS, int NC, int NB, bool WV>
-__global__ __launch_bounds__(FOLD_THREADS) __attribute__((amdgpu_waves_per_eu(fold_waves(U, R, NC, NB), fold_waves(U, R, NC, NB)))) void fold_kernel(
-		const float4 *__restrict__ taps, const float4 *__restrict__ spec,
-		float4 *__restrict__ partial, size_t chan_stride4, size_t row_stride4, size_t spec_stride4, size_t partial_stride4,
-		int m, int slices, int rows, int c_base)
+// P channel PAIRS per wave, Q groups of four blocks (a launch folds nb <= 4 Q blocks), W waves per workgroup, D row trips of loads in
+// flight.  A workgroup = one group of 64 bins x one slice of alias rows x 2 P W channels; its W waves cover the SAME bins and
+// different channels, so each alias row's spectrum tile (4 Q blocks x 64 bins) is fetched ONCE per workgroup -- every wave loads
+// 1 / W of it, already in operand-B order (lane 4 b + n = bin b of block n) -- written to LDS and read from there by all of them.
+// Per alias row and wave: P tap loads of 1 KiB (non-temporal), 2 Q LDS reads, 4 P vector instructions (the rotated operand), and
+// 8 P Q matrix instructions of 256 multiply-accumulates: first every accumulator's Re(X) product, then every Im(X) product, so two
+// instructions on the same accumulator are 4 P Q instructions apart.  Loads run D rows ahead of the multiplies (registers are
+// cheap here: the accumulators are the only large tile), the spectrum tile one row ahead through two LDS stages, one barrier per row.
+template <int P, int Q, int W, int D>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold_mfma_waves(P, Q, W, D), fold_mfma_waves(P, Q, W, D)))) void fold_mfma_kernel(
+		const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
+		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int pair_base, int nch, int nb)
 {
-	constexpr int LANES = WV ? 64 : FOLD_THREADS;             // threads side by side along a row
-	// blockIdx -> (tile = column part x slice, channel group), XCD-aware: block b runs on XCD b mod 8; a tile's workgroups all land on
-	// one XCD and, there, the channel groups vary fastest, so the groups that share a tile of the spectra are resident together and the
-	// tile crosses the fabric once (see fold_kernel_lds; with 8 tiles -- cfg3 at one block per launch -- this is the round-1 layout)
-	const int ntile = CS * slices, groups = (int)gridDim.x / ntile;
-	int tile_id, grp;
-	if ((ntile & 7) == 0) {
-		const int xcd = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
-		grp = i % groups;
-		tile_id = (i / groups) * 8 + xcd;
-	} else {
-		tile_id = (int)blockIdx.x % ntile;
-		grp = (int)blockIdx.x / ntile;
-	}
-	const int cpart = tile_id % CS;
-	const int wave = WV ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, lane = WV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-	const int s = tile_id / CS, c0 = c_base + (grp * (WV ? 4 : 1) + wave) * NC;
-	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row of the spectrum
-	const size_t col = (size_t)cpart * U * LANES + lane;
-	// Addresses = a wave-uniform base per stream (scalar registers, stepped by scalar adds) + ONE 32-bit byte offset per thread + an
-	// immediate: a load costs no vector arithmetic, and the whole trip's loads go out back to back.
-	const unsigned voff = (unsigned)lane * 16u;
-	const char *tb = (const char *)(taps + (size_t)c0 * chan_stride4 + (size_t)s * rows * row_stride4 + (size_t)cpart * U * LANES);
-	const char *sb = (const char *)(spec + (((size_t)s * rows * (size_t)m) >> 1) + (size_t)cpart * U * LANES);
-	const size_t cs_b = chan_stride4 * 16, rs_b = row_stride4 * 16, ss_b = spec_stride4 * 16, r4_b = (size_t)row4 * 16;
-	v4f acc[NB][NC][U];
-#pragma unroll
-	for (int b = 0; b < NB; b++)
-#pragma unroll
-		for (int k = 0; k < NC; k++)
-#pragma unroll
-			for (int u = 0; u < U; u++) acc[b][k][u] = (v4f)(0.f);
-	const bool live = WV || (U * CS > 1) || ((int)threadIdx.x < row4);
-	if (live) {
-		for (int r = 0; r < rows; r += R) {
-			v4f h[NC][R][U], x[NB][R][U];
-#pragma unroll
-			for (int q = 0; q < R; q++) {
-#pragma unroll
-				for (int u = 0; u < U; u++) {
-#pragma unroll
-					for (int k = 0; k < NC; k++)
-						h[k][q][u] = __builtin_nontemporal_load((const v4f *)(tb + (size_t)k * cs_b + (size_t)q * rs_b + (size_t)voff + (size_t)(u * LANES * 16)));
-#pragma unroll
-					for (int b = 0; b < NB; b++)
-						x[b][q][u] = *(const v4f *)(sb + (size_t)b * ss_b + (size_t)q * r4_b + (size_t)voff + (size_t)(u * LANES * 16));
-				}
-			}
-#pragma unroll
-			for (int q = 0; q < R; q++)       // rows strictly in order: the sum over a slice's rows is the same chain in every variant
-#pragma unroll
-				for (int b = 0; b < NB; b++)
-#pragma unroll
-					for (int k = 0; k < NC; k++)
-#pragma unroll
-						for (int u = 0; u < U; u++) cmac2(acc[b][k][u], h[k][q][u], x[b][q][u]);
-			// the trip as the scheduler is to lay it out: every load first, then the multiplies as their operands arrive
-			__builtin_amdgcn_sched_group_barrier(0x020, (NC + NB) * R * U, 0);
-			__builtin_amdgcn_sched_group_barrier(0x002, NB * NC * U * R * 8, 0);
-			tb += (size_t)R * rs_b;
-			sb += (size_t)R * r4_b;
-		}
-#pragma unroll
-		for (int b = 0; b < NB; b++)
-#pragma unroll
-			for (int k = 0; k < NC; k++) {
-				v4f *po = (v4f *)partial + (size_t)b * partial_stride4 + (((size_t)(c0 + k) * slices + s) * (size_t)m >> 1) + col;
-#pragma unroll
-				for (int u = 0; u < U; u++) po[u * LANES] = acc[b][k][u];
-			}
-	}
-}
-
-// The same fold with the block spectra staged through LDS.  With NB blocks per launch every tap byte out of HBM wants NB / NC
-// spectrum bytes out of L2, and the vector memory path (one 64-byte lane group per clock and CU, whatever level answers) is what
-// bounds the launch from NB / NC = 1 up (profiles/r04_fold_variants.md: 2.5 ms at 0.5, 3.1 at 1, 4.3 at 2, 6 at 4).  Here the WPW
-// wavefronts of a workgroup cover the SAME 64 * U columns and WPW different groups of NC channels: each alias row's spectrum tile
-// (NB blocks x 64 * U columns) is fetched ONCE per workgroup -- every wave loads 1 / WPW of it -- written to LDS and read from
-// there by all of them (ds_read_b128: 256 B per clock and CU, four times the vector memory path), so the spectrum costs
-// NB / (WPW * NC) of the tap traffic.  Two LDS stages: the tile of trip t + 1 is fetched into registers while trip t is multiplied,
-// stored to the other stage at the end of the trip, one workgroup barrier per trip.  Same FMA chain per bin as fold_kernel.
-template <int U, int R, int NC, int NB, int WPW>
-__global__ __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(fold_waves(U, R, NC, NB, true), fold_waves(U, R, NC, NB, true)))) void fold_kernel_lds(
-		const float4 *__restrict__ taps, const float4 *__restrict__ spec,
-		float4 *__restrict__ partial, size_t chan_stride4, size_t row_stride4, size_t spec_stride4, size_t partial_stride4,
-		int m, int slices, int rows, int c_base)
-{
-	constexpr int PIECES = NB * R * U;                         // 1 KiB wave-loads per spectrum tile
-	constexpr int MINE = (PIECES + WPW - 1) / WPW;              // ... and this wave's share
-	__shared__ v4f tile[2][PIECES][64];
-	const int row4 = m >> 1;                                  // float4 (= 2 bins) per alias row of the spectrum
-	const int cs = row4 / (64 * U);                           // column parts per row
-	// blockIdx -> (tile = column part x slice, channel group).  The workgroups that share a spectrum tile must sit on ONE XCD (the
+	static_assert(D == 2 || D == 4, "the LDS stage of a trip is a compile-time constant for even D");
+	constexpr int COMBOS = 2 * Q;                             // (block group, bin-set pair) pieces of a row's spectrum tile
+	constexpr int MINE = (COMBOS + W - 1) / W;                // ... and this wave's share
+	__shared__ v4f xt[2][Q][2][64];                           // [stage][block group][bin-set pair][lane] = (Re, Im) of bin-sets 2 vp, 2 vp + 1
+	const int ngrp = m >> 6;
+	// blockIdx -> (tile = bin group x slice, channel group).  The workgroups that share a spectrum tile must sit on ONE XCD (the
 	// dispatcher puts block b on XCD b mod 8) and be resident TOGETHER, so that the tile comes out of HBM once and out of that XCD's
-	// L2 for every other group: per XCD the channel groups vary fastest.  (Column part fastest -- the first layout -- kept only 4 of
-	// the 16 groups of a tile resident at a time and the spectra crossed the fabric four times: 1.11 x the algorithmic bytes.)
-	const int ntile = cs * slices, groups = (int)gridDim.x / ntile;
+	// L2 for every other group: per XCD the channel groups vary fastest.
+	const int ntile = ngrp * slices, groups = (int)gridDim.x / ntile;
 	int tile_id, grp;
 	if ((ntile & 7) == 0) {
 		const int xcd = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
@@ -167,99 +132,125 @@ __global__ __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(fold_w
 		tile_id = (int)blockIdx.x % ntile;
 		grp = (int)blockIdx.x / ntile;
 	}
-	const int cpart = tile_id % cs;
+	const int g = tile_id % ngrp, s = tile_id / ngrp;
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
-	const int s = tile_id / cs, c0 = c_base + (grp * WPW + wave) * NC;
-	const size_t col = (size_t)cpart * U * 64 + lane;
-	const unsigned voff = (unsigned)lane * 16u;
-	const char *tb = (const char *)(taps + (size_t)c0 * chan_stride4 + (size_t)s * rows * row_stride4 + (size_t)cpart * U * 64);
-	const char *sb = (const char *)(spec + (((size_t)s * rows * (size_t)m) >> 1) + (size_t)cpart * U * 64);
-	const size_t cs_b = chan_stride4 * 16, rs_b = row_stride4 * 16, ss_b = spec_stride4 * 16, r4_b = (size_t)row4 * 16;
-	v4f acc[NB][NC][U];
+	const int b = lane >> 2, n = lane & 3;
+	const int pair0 = pair_base + (grp * W + wave) * P;
+	const int sign_mask = (lane & 1) ? 0 : (int)0x80000000;
+	// wave-uniform bases stepped by scalar adds + one byte offset per lane
+	const char *tb = (const char *)(taps + (size_t)s * rows * row_stride_f + (size_t)pair0 * 4 * m + (size_t)g * 256) + lane * 16;
+	const size_t rs_b = row_stride_f * 4, ps_b = (size_t)m * 16, xrow_b = (size_t)m * 8;
+	const char *xp[MINE];
 #pragma unroll
-	for (int b = 0; b < NB; b++)
+	for (int i = 0; i < MINE; i++) {
+		const int k = wave + i * W, q = k >> 1, vp = k & 1;
+		int blk = 4 * q + n;
+		blk = blk < nb ? blk : nb - 1;                        // columns past the last block repeat it; they are never stored
+		xp[i] = (const char *)(spec + (size_t)blk * spec_stride + (size_t)s * rows * (size_t)m + g * 64 + 32 * vp + b);
+	}
+	v4f acc[P][4][Q];
 #pragma unroll
-		for (int k = 0; k < NC; k++)
+	for (int p = 0; p < P; p++)
 #pragma unroll
-			for (int u = 0; u < U; u++) acc[b][k][u] = (v4f)(0.f);
-	// piece p = (b, q, u) of a trip's tile; this wave fetches pieces wave, wave + WPW, ...
-	v4f xs[MINE];
-	auto fetch = [&](const char *base) {
+		for (int v = 0; v < 4; v++)
 #pragma unroll
-		for (int i = 0; i < MINE; i++) {
-			const int p = wave + i * WPW;
-			if (PIECES % WPW == 0 || p < PIECES) {
-				const int b = p / (R * U), q = (p / U) % R, u = p % U;
-				xs[i] = *(const v4f *)(base + (size_t)b * ss_b + (size_t)q * r4_b + (size_t)voff + (size_t)(u * 64 * 16));
+			for (int q = 0; q < Q; q++) acc[p][v][q] = (v4f)(0.f);
+	v4f h[D][P], xs[D][MINE];
+	auto issue = [&](int slot) {               // the loads of the next row not yet asked for: spectrum share first, then the taps
+#pragma unroll
+		for (int i = 0; i < MINE; i++)
+			if (COMBOS % W == 0 || wave + i * W < COMBOS) {
+				const v2f lo = *(const v2f *)xp[i], hi = *(const v2f *)(xp[i] + 128);
+				xs[slot][i] = v4f{ lo.x, lo.y, hi.x, hi.y };
+				xp[i] += xrow_b;
 			}
-		}
+#pragma unroll
+		for (int p = 0; p < P; p++) h[slot][p] = __builtin_nontemporal_load((const v4f *)(tb + (size_t)p * ps_b));
+		tb += rs_b;
 	};
-	auto stash = [&](int stage) {
+	auto stash = [&](int slot, int stage) {
 #pragma unroll
-		for (int i = 0; i < MINE; i++) {
-			const int p = wave + i * WPW;
-			if (PIECES % WPW == 0 || p < PIECES) tile[stage][p][lane] = xs[i];
-		}
+		for (int i = 0; i < MINE; i++)
+			if (COMBOS % W == 0 || wave + i * W < COMBOS) {
+				const int k = wave + i * W;
+				xt[stage][k >> 1][k & 1][lane] = xs[slot][i];
+			}
 	};
-	auto load_taps = [&](v4f (&h)[NC][R][U], const char *base) {
+	auto multiply = [&](int slot, int stage) {
+		v4f x[Q][2];
 #pragma unroll
-		for (int q = 0; q < R; q++)
+		for (int q = 0; q < Q; q++)
 #pragma unroll
-			for (int u = 0; u < U; u++)
+			for (int vp = 0; vp < 2; vp++) x[q][vp] = xt[stage][q][vp][lane];
 #pragma unroll
-				for (int k = 0; k < NC; k++)
-					h[k][q][u] = __builtin_nontemporal_load((const v4f *)(base + (size_t)k * cs_b + (size_t)q * rs_b + (size_t)voff + (size_t)(u * 64 * 16)));
+		for (int p = 0; p < P; p++)
+#pragma unroll
+			for (int v = 0; v < 4; v++)
+#pragma unroll
+				for (int q = 0; q < Q; q++)
+					acc[p][v][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(h[slot][p][v], x[q][v >> 1][(v & 1) * 2], acc[p][v][q], 0, 0, 0);
+#pragma unroll
+		for (int p = 0; p < P; p++)
+#pragma unroll
+			for (int v = 0; v < 4; v++) {
+				const float hr = rot90(h[slot][p][v], sign_mask);
+#pragma unroll
+				for (int q = 0; q < Q; q++)
+					acc[p][v][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(hr, x[q][v >> 1][(v & 1) * 2 + 1], acc[p][v][q], 0, 0, 0);
+			}
 	};
-	// One trip: ask for this wave's share of the NEXT trip's spectrum tile, then for this trip's taps (the tile answers out of L2,
-	// ahead of the taps: loads return in order); read this trip's tile from LDS; store the fetched share to the other stage; multiply
-	// as the taps arrive; barrier.  The fences keep the compiler from rotating the trip (it would issue the taps after the wait for
-	// the tile share, one load latency after the other).
-	fetch(sb);
-	stash(0);
+	// The scheduler must not reorder the loads of different rows: s_waitcnt counts loads in ISSUE order, and the count it is given at
+	// the loop header is the smaller of what the prologue and the back edge allow -- a prologue that asks for row 0's taps last makes
+	// every iteration wait for all but the last three loads, and the rows in flight are gone (measured: time = memory + multiplies).
+#pragma unroll
+	for (int d = 0; d < D; d++) {                      // rows 0 .. D-1 (rows is a multiple of D)
+		issue(d);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	stash(0, 0);
 	__syncthreads();
-	int stage = 0;
-	for (int r = 0; r < rows; r += R) {
-		const bool more = r + R < rows;
-		v4f h[NC][R][U];
-		sb += (size_t)R * r4_b;
-		if (more) fetch(sb);
-		load_taps(h, tb);
-		asm volatile("" ::: "memory");
-		v4f x[NB][R][U];
+	for (int r = 0; r < rows - D; r += D) {
 #pragma unroll
-		for (int q = 0; q < R; q++)
-#pragma unroll
-			for (int b = 0; b < NB; b++)
-#pragma unroll
-				for (int u = 0; u < U; u++) x[b][q][u] = tile[stage][(b * R + q) * U + u][lane];
-		if (more) stash(stage ^ 1);
-		asm volatile("" ::: "memory");
-#pragma unroll
-		for (int q = 0; q < R; q++)           // rows strictly in order: the sum over a slice's rows is the same chain in every variant
-#pragma unroll
-			for (int b = 0; b < NB; b++)
-#pragma unroll
-				for (int u = 0; u < U; u++)
-#pragma unroll
-					for (int k = 0; k < NC; k++) cmac2(acc[b][k][u], h[k][q][u], x[b][q][u]);
-		__syncthreads();
-		stage ^= 1;
-		tb += (size_t)R * rs_b;
+		for (int d = 0; d < D; d++) {
+			multiply(d, d & 1);
+			issue(d);                                  // row r + d + D into the registers row r + d has just left
+			stash((d + 1) % D, (d + 1) & 1);           // row r + d + 1 (asked for D - 1 trips ago) into the other stage
+			__builtin_amdgcn_sched_barrier(0);
+			__syncthreads();
+		}
 	}
 #pragma unroll
-	for (int b = 0; b < NB; b++)
-#pragma unroll
-		for (int k = 0; k < NC; k++) {
-			v4f *po = (v4f *)partial + (size_t)b * partial_stride4 + (((size_t)(c0 + k) * slices + s) * (size_t)m >> 1) + col;
-#pragma unroll
-			for (int u = 0; u < U; u++) po[u * 64] = acc[b][k][u];
+	for (int d = 0; d < D; d++) {                      // the last D rows: nothing left to ask for
+		multiply(d, d & 1);
+		if (d + 1 < D) {
+			stash(d + 1, (d + 1) & 1);
+			__builtin_amdgcn_sched_barrier(0);
+			__syncthreads();
 		}
+	}
+#pragma unroll
+	for (int p = 0; p < P; p++) {
+		const int c0 = 2 * (pair0 + p);
+#pragma unroll
+		for (int q = 0; q < Q; q++) {
+			const int blk = 4 * q + n;
+			if (blk >= nb) continue;
+#pragma unroll
+			for (int v = 0; v < 4; v++) {
+				float2 *po = partial + (size_t)blk * partial_stride + ((size_t)c0 * slices + s) * (size_t)m + g * 64 + 16 * v + b;
+				const v4f a = acc[p][v][q];
+				if (c0 < nch) *po = make_float2(a.x, a.y);
+				if (c0 + 1 < nch) po[(size_t)slices * m] = make_float2(a.z, a.w);
+			}
+		}
+	}
 }
 
+#ifdef HFDL_LAB
 // Read-only streaming probe: what this board's HBM delivers to a bare kernel doing nothing but non-temporal 16-byte loads
 // (1 KiB per wave instruction).  L loads in flight per thread; SPAN: every workgroup walks its own contiguous 4 MiB span,
-// otherwise the whole grid sweeps one moving window (workgroup b reads chunks b, b + grid, ...).  The front end reports the
-// best of the variants: SURVEY.md 8(d) asks for it next to the spec peak; bench.py prints it as roofline.stream_read_GBs.
+// otherwise the whole grid sweeps one moving window (workgroup b reads chunks b, b + grid, ...).  bench.py prints the best of the
+// variants as roofline.stream_read_GBs (SURVEY.md 8(d) asks for it next to the spec peak).  Laboratory build only.
 template <int L, bool SPAN>
 __global__ __launch_bounds__(FOLD_THREADS) void stream_read_kernel(const float4 *__restrict__ src, size_t chunks, float *__restrict__ sink)
 {
@@ -268,10 +259,10 @@ __global__ __launch_bounds__(FOLD_THREADS) void stream_read_kernel(const float4 
 	const size_t first = SPAN ? (size_t)blockIdx.x * per_block : blockIdx.x, step = SPAN ? 1 : gridDim.x;
 	const size_t last = SPAN ? first + per_block : chunks;
 	for (size_t ch = first; ch < last; ch += step) {
-		const float4 *p = src + ch * (L * FOLD_THREADS) + threadIdx.x;
-		float4 v[L];
+		const v4f *p = (const v4f *)src + ch * (L * FOLD_THREADS) + threadIdx.x;
+		v4f v[L];
 #pragma unroll
-		for (int i = 0; i < L; i++) v[i] = load_stream(p + i * FOLD_THREADS);
+		for (int i = 0; i < L; i++) v[i] = __builtin_nontemporal_load(p + i * FOLD_THREADS);
 #pragma unroll
 		for (int i = 0; i < L; i++) acc += v[i].x + v[i].w;
 	}
@@ -290,120 +281,54 @@ void launch_stream_read(int variant, const float2 *src, size_t bytes, float *sin
 	default: hipLaunchKernelGGL((stream_read_kernel<8, true>), dim3((unsigned)(bytes >> 22)), block, 0, st, (const float4 *)src, bytes / (128 * FOLD_THREADS), sink); break;
 	}
 }
+#endif
 
-// generic fallback for row sizes that are not 512*2^k bins (same FMA chain per bin; one block per launch)
-__global__ __launch_bounds__(FOLD_THREADS) void fold_kernel_generic(const float2 *__restrict__ taps, const float2 *__restrict__ spec,
-		float2 *__restrict__ partial, size_t chan_stride, size_t row_stride, int m, int slices, int rows)
-{
-	const int s = blockIdx.x % slices, c = blockIdx.x / slices;
-	for (int j = threadIdx.x; j < m; j += FOLD_THREADS) {
-		const float2 *tp = taps + (size_t)c * chan_stride + (size_t)s * rows * row_stride + j;
-		const float2 *sp = spec + (size_t)s * rows * (size_t)m + j;
-		float2 acc = make_float2(0.f, 0.f);
-		for (int r = 0; r < rows; r++) {
-			float2 h = tp[(size_t)r * row_stride], x = sp[(size_t)r * m];
-			acc.x = __builtin_fmaf(h.x, x.x, acc.x); acc.x = __builtin_fmaf(-h.y, x.y, acc.x);
-			acc.y = __builtin_fmaf(h.x, x.y, acc.y); acc.y = __builtin_fmaf(h.y, x.x, acc.y);
-		}
-		partial[((size_t)c * slices + s) * (size_t)m + j] = acc;
-	}
-}
-
-// ---- the compiled register tilings ----
+// ---- the compiled tilings ----
 struct FoldArgs {
-	const float4 *taps, *spec;
-	float4 *partial;
-	size_t cs4, rs4, ss4, ps4;
-	int m, slices, rows, nch;
+	const float *taps;
+	const float2 *spec;
+	float2 *partial;
+	size_t rs_f, ss, ps;
+	int m, slices, rows, nch, npairs, nb;
 	hipStream_t st;
 	hipEvent_t start, stop;
 };
 
-// channel groups first (NC channels, or 4 * NC with the waves over channels); the channels left over get single-channel workgroups
-// (one column range per workgroup) in a launch of their own
-template <int U, int R, int CS, int NC, int NB, bool WV>
+// channel groups of 2 P W channels first; the pairs left over get single-wave workgroups in a launch of their own
+template <int P, int Q, int W, int D>
 static int fold_go(const FoldArgs &a)
 {
-	const dim3 block(FOLD_THREADS);
-	constexpr int GC = WV ? 4 * NC : NC;                  // channels per workgroup
-	constexpr int RU = WV ? (U >= 4 ? U / 4 : 1) : U, RCS = WV ? (U >= 4 ? CS : CS * U / 4) : CS;      // the same row as RU * RCS * 256 columns
-	const int groups = a.nch / GC, rest = a.nch - groups * GC;
+	const int ntile = (a.m >> 6) * a.slices;
+	const int groups = a.npairs / (P * W), rest = a.npairs - groups * P * W;
 	int launches = 0;
 	if (groups > 0) {
-		hipExtLaunchKernelGGL((fold_kernel<U, R, CS, NC, NB, WV>), dim3((unsigned)(groups * a.slices * CS)), block, 0, a.st, a.start, rest ? nullptr : a.stop, 0,
-			a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, 0);
+		hipExtLaunchKernelGGL((fold_mfma_kernel<P, Q, W, D>), dim3((unsigned)(groups * ntile)), dim3(64 * W), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, 0, a.nch, a.nb);
 		launches++;
 	}
 	if (rest > 0) {
-		hipExtLaunchKernelGGL((fold_kernel<RU, 1, RCS, 1, NB, false>), dim3((unsigned)(rest * a.slices * RCS)), block, 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
-			a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, groups * GC);
+		hipExtLaunchKernelGGL((fold_mfma_kernel<1, Q, 1, D>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, groups * P * W, a.nch, a.nb);
 		launches++;
 	}
 	return launches;
 }
 
-template <int U, int R, int NC, int NB, int WPW>
-static int fold_go_lds(const FoldArgs &a)
-{
-	constexpr int GC = WPW * NC;                          // channels per workgroup
-	const int cs = (a.m >> 1) / (64 * U);
-	constexpr int RU = U >= 4 ? U / 4 : 1;                  // the channels left over: single-channel workgroups of the plain kernel
-	const int groups = a.nch / GC, rest = a.nch - groups * GC;
-	int launches = 0;
-	if (groups > 0) {
-		hipExtLaunchKernelGGL((fold_kernel_lds<U, R, NC, NB, WPW>), dim3((unsigned)(groups * a.slices * cs)), dim3(64 * WPW), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
-			a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, 0);
-		launches++;
-	}
-	if (rest > 0) {
-		const int rcs = a.m / (2 * FOLD_THREADS * RU);
-		auto go = [&](auto kern, int cs_) {
-			hipExtLaunchKernelGGL(kern, dim3((unsigned)(rest * a.slices * cs_)), dim3(FOLD_THREADS), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
-				a.taps, a.spec, a.partial, a.cs4, a.rs4, a.ss4, a.ps4, a.m, a.slices, a.rows, groups * GC);
-		};
-		switch (rcs) {          // CS is a template argument of the plain kernel
-		case 1: go(fold_kernel<RU, 1, 1, 1, NB, false>, 1); break;
-		case 2: go(fold_kernel<RU, 1, 2, 1, NB, false>, 2); break;
-		case 4: go(fold_kernel<RU, 1, 4, 1, NB, false>, 4); break;
-		case 8: go(fold_kernel<RU, 1, 8, 1, NB, false>, 8); break;
-		default: go(fold_kernel<RU, 1, 16, 1, NB, false>, 16); break;
-		}
-		launches++;
-	}
-	return launches;
-}
-
-struct FoldVariant { int u, r, cs, nc, nb, wv; int (*go)(const FoldArgs &); };
-#define FV(U, R, CS, NC, NB) { U, R, CS, NC, NB, 0, fold_go<U, R, CS, NC, NB, false> }
-#define FW(U, R, CS, NC, NB) { U, R, CS, NC, NB, 1, fold_go<U, R, CS, NC, NB, true> }
-// LDS-staged spectra: wv = 2 + waves per workgroup; `cs` is left 0 (the column split follows from M: M / (128 U) parts)
-#define FL(U, R, NC, NB, WPW) { U, R, 0, NC, NB, 2 + WPW, fold_go_lds<U, R, NC, NB, WPW> }
-// A row of M bins = U * CS * 512 (FV) or U * CS * 128 (FW: waves over channels).  Measured on cfg3 (M = 4096) with
-// profiles/fold_variants.py: profiles/r04_fold_variants.md.
-// What paid at one block per launch (profiles/r01_experiments.md): non-temporal tap loads (+7 %) and TWO channels per workgroup
-// sharing every spectrum load (+14 %: halves the L2 -> L1 spectrum traffic).  With NB blocks per launch the spectrum traffic is
-// NB / NC times the tap traffic, so the tile trades registers between the two (acc = 4 * NB * NC * U VGPRs).
+struct FoldVariant { int p, q, w, d; int (*go)(const FoldArgs &); };
+#define FM(P, Q, W, D) { P, Q, W, D, fold_go<P, Q, W, D> }
+// The first entry of a block-group count Q whose row look-ahead D divides the slice is the one used (nb <= 4 Q blocks per launch).
+// Measured on cfg3 (M = 4096, 512 rows per slice) with profiles/fold_variants.py: profiles/r05/fold_variants_cfg3.md.
 static const FoldVariant fold_variants[] = {
-	// The first entry of a block count that fits the geometry is the one used; the rest are kept for profiles/fold_variants.py
-	// (measured on cfg3, M = 4096: profiles/r04_fold_variants.md).
-	// one block per launch, M = 512 .. 8192: the round-1 tilings
-	FV(1, 1, 1, 2, 1), FV(1, 1, 2, 2, 1), FV(2, 1, 2, 2, 1), FV(4, 1, 2, 2, 1), FV(8, 1, 2, 2, 1),
-	FV(4, 2, 2, 2, 1), FW(4, 1, 8, 2, 1), FL(4, 1, 4, 1, 4), FL(4, 1, 2, 1, 8),
-	// two blocks
-	FV(1, 1, 1, 2, 2), FV(1, 1, 2, 2, 2), FV(1, 1, 4, 4, 2), FV(2, 1, 4, 4, 2), FV(4, 1, 4, 2, 2),
-	FV(4, 1, 2, 2, 2), FW(2, 1, 16, 4, 2), FV(1, 1, 8, 8, 2), FL(4, 1, 2, 2, 4), FL(2, 2, 2, 2, 8),
-	// four blocks: spectra through LDS where the slices are long enough (16 channels per workgroup), register tiles otherwise
-	FL(2, 1, 4, 4, 4),
-	FV(1, 1, 1, 2, 4), FV(1, 1, 2, 4, 4), FV(1, 1, 4, 8, 4), FV(1, 1, 8, 8, 4), FV(2, 1, 8, 4, 4),
-	FL(1, 1, 4, 4, 8), FL(2, 1, 2, 4, 8), FL(1, 1, 4, 4, 4), FL(2, 1, 4, 4, 8), FV(2, 1, 4, 4, 4), FW(1, 1, 32, 8, 4), FW(2, 1, 16, 4, 4),
-	// eight blocks
-	FL(1, 1, 4, 8, 4),
-	FV(1, 1, 1, 2, 8), FV(1, 1, 2, 4, 8), FV(1, 1, 4, 4, 8), FW(1, 1, 32, 4, 8), FV(1, 1, 16, 4, 8),
-	FL(1, 1, 4, 8, 8), FL(1, 1, 2, 8, 8), FL(1, 2, 4, 8, 8), FL(1, 1, 2, 8, 4), FV(1, 1, 8, 4, 8), FV(1, 1, 8, 2, 8),
+	FM(2, 1, 4, 4), FM(2, 1, 4, 2),
+	FM(2, 2, 4, 4), FM(2, 2, 4, 2),
+	FM(2, 4, 4, 2), FM(2, 4, 4, 4),
+#ifdef HFDL_LAB
+	// the sweep: more pairs per wave, eight waves per workgroup
+	FM(4, 1, 4, 4), FM(4, 2, 4, 4), FM(4, 2, 4, 2), FM(1, 2, 4, 4), FM(2, 2, 8, 4), FM(2, 2, 8, 2), FM(1, 2, 8, 4),
+	FM(2, 4, 8, 2), FM(2, 4, 8, 4), FM(1, 4, 8, 4), FM(1, 4, 4, 4), FM(4, 4, 4, 2),
+#endif
 };
-#undef FV
-#undef FW
-#undef FL
+#undef FM
 constexpr int N_FOLD_VARIANTS = (int)(sizeof(fold_variants) / sizeof(fold_variants[0]));
 
 int fold_variant_count() { return N_FOLD_VARIANTS; }
@@ -412,78 +337,92 @@ int fold_variant_describe(int v, int desc[6])
 {
 	if (v < 0 || v >= N_FOLD_VARIANTS) return -1;
 	const FoldVariant &f = fold_variants[v];
-	desc[0] = f.u; desc[1] = f.r; desc[2] = f.cs; desc[3] = f.nc; desc[4] = f.nb; desc[5] = f.wv;
+	desc[0] = f.p; desc[1] = f.q; desc[2] = f.w; desc[3] = f.d; desc[4] = 4 * f.q; desc[5] = 0;
 	return 0;
 }
 
 static bool variant_fits(const FoldVariant &f, const Geometry &g)
 {
-	// LDS-staged spectra: any M that is a multiple of the workgroup's 128 U bins, at least one full group of channels, and slices long
-	// enough for the two-stage pipeline to matter (the small geometries' 16-row slices keep the register tiles)
-	if (f.wv >= 2) return g.m % (128 * f.u) == 0 && g.rows_per_slice % f.r == 0 && g.rows_per_slice >= 64 * f.r && g.nch >= (f.wv - 2) * f.nc;
-	return g.m == 2 * (f.wv ? 64 : FOLD_THREADS) * f.u * f.cs && g.rows_per_slice % f.r == 0;
+	return g.pair_layout && g.rows_per_slice % f.d == 0;
 }
 
-// the tiling used for `nb` blocks of this geometry: the first entry of the preference list that fits (HFDL_GPU_FOLD_TILE =
-// "U,R,CS,NC[,W]" overrides it for A/B measurements when such a variant is compiled)
+// the tiling used for `nb` blocks of this geometry: the first entry of the list that fits
 static const FoldVariant *pick_variant(const Geometry &g, int nb)
 {
-	static int want[5] = { 0, 0, 0, 0, 0 };
-	static bool parsed = false;
-	if (!parsed) {
-		parsed = true;
-		if (const char *e = getenv("HFDL_GPU_FOLD_TILE"))
-			if (sscanf(e, "%d,%d,%d,%d,%d", &want[0], &want[1], &want[2], &want[3], &want[4]) < 4) want[0] = 0;
-	}
-	if (want[0])
-		for (const FoldVariant &f : fold_variants)
-			if (f.nb == nb && f.u == want[0] && f.r == want[1] && f.cs == want[2] && f.nc == want[3] && f.wv == want[4] && variant_fits(f, g)) return &f;
+	const int q = nb <= 4 ? 1 : nb <= 8 ? 2 : 4;
 	for (const FoldVariant &f : fold_variants)
-		if (f.nb == nb && variant_fits(f, g)) return &f;
+		if (f.q == q && variant_fits(f, g)) return &f;
 	return nullptr;
 }
 
 static FoldArgs fold_args(const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial, size_t partial_stride,
-		hipStream_t st, hipEvent_t start, hipEvent_t stop)
+		int nb, hipStream_t st, hipEvent_t start, hipEvent_t stop)
 {
 	FoldArgs a;
-	a.taps = (const float4 *)taps; a.spec = (const float4 *)spectrum; a.partial = (float4 *)partial;
-	a.cs4 = (size_t)g.tap_chan_stride >> 1; a.rs4 = (size_t)g.tap_row_stride >> 1; a.ss4 = spec_stride >> 1; a.ps4 = partial_stride >> 1;
-	a.m = g.m; a.slices = g.slices; a.rows = g.rows_per_slice; a.nch = g.nch;
+	a.taps = (const float *)taps; a.spec = spectrum; a.partial = partial;
+	a.rs_f = (size_t)g.tap_row_stride * 2; a.ss = spec_stride; a.ps = partial_stride;
+	a.m = g.m; a.slices = g.slices; a.rows = g.rows_per_slice; a.nch = g.nch; a.npairs = g.nch_pad / 2; a.nb = nb;
 	a.st = st; a.start = start; a.stop = stop;
 	return a;
 }
 
-int launch_fold_variant(int v, const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial,
-		size_t partial_stride, hipStream_t st, hipEvent_t start, hipEvent_t stop)
+static void launch_fold_ref(const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial, size_t partial_stride,
+		int nb, hipStream_t st, hipEvent_t start, hipEvent_t stop)
 {
-	if (v < 0 || v >= N_FOLD_VARIANTS || !variant_fits(fold_variants[v], g)) return -1;
-	return fold_variants[v].go(fold_args(g, taps, spectrum, spec_stride, partial, partial_stride, st, start, stop));
+	hipExtLaunchKernelGGL(fold_ref_kernel, dim3((unsigned)(g.nch * g.slices)), dim3(FOLD_THREADS), 0, st, start, stop, 0,
+		(const float *)taps, spectrum, partial, (size_t)g.tap_row_stride * 2, spec_stride, partial_stride, g.m, g.slices, g.rows_per_slice, g.pair_layout, nb);
+}
+
+int launch_fold_variant(int v, const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial,
+		size_t partial_stride, int nb, hipStream_t st, hipEvent_t start, hipEvent_t stop)
+{
+	if (v == -1) { launch_fold_ref(g, taps, spectrum, spec_stride, partial, partial_stride, nb, st, start, stop); return 1; }    // the FMA-chain reference
+	if (v < 0 || v >= N_FOLD_VARIANTS || !variant_fits(fold_variants[v], g) || nb < 1 || nb > 4 * fold_variants[v].q) return -1;
+	return fold_variants[v].go(fold_args(g, taps, spectrum, spec_stride, partial, partial_stride, nb, st, start, stop));
 }
 
 int launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial, size_t partial_stride,
 		int nb, int nb_max, hipStream_t st, hipEvent_t start, hipEvent_t stop)
 {
 	int launches = 0;
-	// greedy split into launches of 8 / 4 / 2 / 1 blocks (a ragged batch of 3 = 2 + 1): every block's sums are the same whatever its company
+	if (nb_max > FOLD_MAX_BLOCKS) nb_max = FOLD_MAX_BLOCKS;
+	// one launch per nb_max blocks: a launch takes ANY block count up to 4 Q (columns past the last block are computed and dropped)
 	for (int done = 0; done < nb;) {
-		int take = 1;
-		const FoldVariant *f = nullptr;
-		for (int t = 8; t >= 1; t >>= 1)
-			if (t <= nb - done && t <= nb_max && (f = pick_variant(g, t)) != nullptr) { take = t; break; }
+		const int take = nb - done < nb_max ? nb - done : nb_max;
 		const bool first = done == 0, last = done + take >= nb;
 		const float2 *sp = spectrum + (size_t)done * spec_stride;
 		float2 *pp = partial + (size_t)done * partial_stride;
-		if (f) {
-			launches += f->go(fold_args(g, taps, sp, spec_stride, pp, partial_stride, st, first ? start : nullptr, last ? stop : nullptr));
-		} else {
-			hipExtLaunchKernelGGL(fold_kernel_generic, dim3((unsigned)(g.nch * g.slices)), dim3(FOLD_THREADS), 0, st, first ? start : nullptr, last ? stop : nullptr, 0,
-				taps, sp, pp, (size_t)g.tap_chan_stride, (size_t)g.tap_row_stride, g.m, g.slices, g.rows_per_slice);
-			launches++;
-		}
+		const FoldVariant *f = pick_variant(g, take);
+		if (f) launches += f->go(fold_args(g, taps, sp, spec_stride, pp, partial_stride, take, st, first ? start : nullptr, last ? stop : nullptr));
+		else { launch_fold_ref(g, taps, sp, spec_stride, pp, partial_stride, take, st, first ? start : nullptr, last ? stop : nullptr); launches++; }
 		done += take;
 	}
 	return launches;
+}
+
+hipError_t launch_tap_interleave(float2 *taps, const Geometry &g, hipStream_t st)
+{
+	if (!g.pair_layout) return hipSuccess;
+	const size_t lds = sizeof(float) * 4 * (size_t)g.m;
+	if (lds > 64 * 1024) {
+		hipError_t e = hipFuncSetAttribute((const void *)tap_interleave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL(tap_interleave_kernel, dim3((unsigned)(g.pre * (g.nch_pad / 2))), dim3(FOLD_THREADS), lds, st, (float *)taps, (size_t)g.tap_row_stride * 2, g.m, g.nch_pad / 2);
+	return hipGetLastError();
+}
+
+// filter taps of one channel back in plain order (HFDL_GPU_TAP_FILTER): dst[N] cf32
+__global__ __launch_bounds__(FOLD_THREADS) void tap_extract_kernel(const float *__restrict__ taps, float2 *__restrict__ dst, size_t row_stride_f, int m, int pre, int pair_layout, int c)
+{
+	const size_t n = (size_t)m * pre;
+	for (size_t e = (size_t)blockIdx.x * FOLD_THREADS + threadIdx.x; e < n; e += (size_t)gridDim.x * FOLD_THREADS)
+		dst[e] = tap_at(taps, row_stride_f, m, pair_layout, c, (int)(e / m), (int)(e % m));
+}
+
+void launch_tap_extract(const float2 *taps, const Geometry &g, int channel, float2 *dst, hipStream_t st)
+{
+	hipLaunchKernelGGL(tap_extract_kernel, dim3(1024), dim3(FOLD_THREADS), 0, st, (const float *)taps, dst, (size_t)g.tap_row_stride * 2, g.m, g.pre, g.pair_layout, channel);
 }
 
 // ---- inverse FFT + scrap + NCO/decimate : one workgroup per channel, M bins in LDS ----

@@ -115,7 +115,8 @@ struct hfdl_gpu_frontend {
 	hipStream_t stream_b = nullptr;     // B: demodulator (+ burst decoder, unless it has its own stream) of block k-1, concurrent with the fold of block k
 	hipStream_t stream_d = nullptr;     // D: burst decoder + PDU snapshot when the demodulator bounds the block (few channels); else == stream_b
 	bool own_decode_stream = false;
-	static constexpr int MAX_HALF = 8;  // blocks per half at most
+	static constexpr int MAX_HALF = FOLD_MAX_BLOCKS;      // blocks per half at most: what one fold launch can take (16)
+	static constexpr int MAX_STAGE = MAX_HALF + 2;        // staging buffers for host input at most
 	hipEvent_t ev_dm[2][MAX_HALF] = {};              // demodulator launch j of the half in buffer 0 / 1 done (the decoder may start)
 	hipEvent_t ev_dm_cur[2] = { nullptr, nullptr };  // LAST demodulator launch of that half done (chan_out free): an ev_dm, or (timing on) the stop event of a timed pair
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_dmt;      // timed demodulator launches not yet read
@@ -127,11 +128,17 @@ struct hfdl_gpu_frontend {
 	hipEvent_t ev_spec[2] = { nullptr, nullptr };    // newest forward FFT of the half in spectrum set 0 / 1 done (rides on its last pass)
 
 	hipEvent_t ev_chan[2] = { nullptr, nullptr }, ev_demod[2] = { nullptr, nullptr };
-	hipEvent_t ev_stage_ready[2] = { nullptr, nullptr }, ev_stage_free[2] = { nullptr, nullptr };
-	uint64_t host_blocks = 0;
-	hipEvent_t ev_copy[4] = { nullptr, nullptr, nullptr, nullptr };   // copy of host block j done (j & 3): what input_done_upto() waits for
-	const void *prefetched = nullptr;   // host pointer whose copy hfdl_gpu_frontend_prefetch_block_raw() already queued ...
-	int prefetched_sb = -1, prefetched_fmt = 0;      // ... into this staging buffer, from this sample format
+	// Host input goes through a RING of n_stage = half_blocks + 2 staging buffers in HBM: host block j is copied (stream C) into buffer
+	// j % n_stage, which the forward FFT's first pass of block j - n_stage has finished reading -- that pass runs BEFORE the fold of its
+	// half, so uploads run a whole half ahead and never sit behind the 3 ms fold (with two buffers, upload k+2 waited for FFT k, which
+	// waited for the fold of the half before: the link idled a third of the time).
+	int n_stage = 0;
+	hipEvent_t ev_stage_ready[MAX_STAGE] = {};  // copy of the host block in this buffer done: what its forward FFT and input_done_upto() wait for
+	hipEvent_t ev_stage_free[MAX_STAGE] = {};   // pass 1 of the forward FFT that read this buffer done (rides on that dispatch): the copy stream may refill it
+	uint64_t host_blocks = 0;           // host blocks whose copy has been queued (pushed or prefetched)
+	uint64_t host_pushed = 0;           // ... of which this many have been pushed (or cancelled): the rest wait in the prefetch queue, oldest first
+	const void *pf_ptr[MAX_STAGE] = {}; // prefetch queue entry of host block j at [j % n_stage]: the host pointer ...
+	int pf_fmt[MAX_STAGE] = {};         // ... and its sample format
 	int32_t sample_rate = 0, centerfreq = 0, decimation = 0;
 	float tbw = 0;
 	Plan plan{};                       // shift = 0 geometry (src/fft.c:70-86)
@@ -140,7 +147,7 @@ struct hfdl_gpu_frontend {
 	std::vector<int32_t> freqs;
 	std::vector<ChanConst> cc;
 	float2 *d_hist[2] = { nullptr, nullptr }, *d_work = nullptr, *d_spec = nullptr, *d_taps = nullptr, *d_partial = nullptr;
-	float2 *d_tw_m = nullptr, *d_stage[2] = { nullptr, nullptr };
+	float2 *d_tw_m = nullptr, *d_stage[MAX_STAGE] = {};
 	// Channelizer output, double-buffered between stream A and stream B in two HALVES of `half_blocks` blocks each:
 	// [2][half_blocks][nch][outs].  The forward FFT of a block is queued when it is pushed; the fold and the inverse FFTs run when a
 	// half is closed (full, or a sync / poll found it part-filled): ONE pass over the filter taps serves up to `fold_nb` blocks.
@@ -167,7 +174,8 @@ struct hfdl_gpu_frontend {
 	NcoState *d_nco = nullptr;          // [nch] carried NCO state, owned by the forward FFT's rider workgroups (kernels.h NcoJob)
 	NcoState *d_nco_snap = nullptr;     // [half_blocks][nch] the state each block of the half starts from
 	float2 *d_ph = nullptr, *d_ph_cont = nullptr;      // [half_blocks] NCO phasor tables [outs][nch] and the riders' segment hand-over [nch]
-	size_t stage_cap[2] = { 0, 0 };
+	size_t stage_cap[MAX_STAGE] = {};
+	bool fold_bound = false;            // many channels: the fold bounds the block and the demodulator launches of a half are placed under the NEXT half's fold
 	Demod demod;
 	// fold timing
 	bool timing = false;
@@ -176,6 +184,7 @@ struct hfdl_gpu_frontend {
 	std::vector<int> ev_blocks;         // blocks folded between each pair of `ev`
 	double fold_ms = 0;
 	int64_t fold_launches = 0, fold_timed_blocks = 0, fold_last_blocks = 0;
+	int64_t fold_shapes[FOLD_MAX_BLOCKS + 1] = {};   // timed fold launches by block count
 	hipEvent_t ev_first_fold = nullptr;  // start of the first timed fold since reset_timers: anchor of the steady-state step period
 	double span_ms = 0;                 // first timed fold start -> last timed fold start
 	uint64_t blocks = 0;
@@ -199,7 +208,9 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	if (fe->fft_own_stream && fe->stream_f) (void)hipStreamSynchronize(fe->stream_f);
 	for (hipEvent_t e : fe->ev_spec) if (e) (void)hipEventDestroy(e);
 	for (int i = 0; i < 2; i++)
-		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i], fe->ev_stage_ready[i], fe->ev_stage_free[i], fe->ev_copy[i], fe->ev_copy[i + 2] }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { fe->ev_chan[i], fe->ev_demod[i] }) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : fe->ev_stage_ready) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : fe->ev_stage_free) if (e) (void)hipEventDestroy(e);
 	for (auto &h : fe->ev_dm) for (hipEvent_t e : h) if (e) (void)hipEventDestroy(e);
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	for (auto &e : fe->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -209,8 +220,9 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	fe->demod.release();
 	fe->fft.release();
 	void *ptrs[] = { fe->d_hist[0], fe->d_hist[1], fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_all, fe->d_tw_m,
-		fe->d_stage[0], fe->d_stage[1], fe->d_cc, fe->d_nco, fe->d_nco_snap, fe->d_ph, fe->d_ph_cont, fe->d_cnt_all };
+		fe->d_cc, fe->d_nco, fe->d_nco_snap, fe->d_ph, fe->d_ph_cont, fe->d_cnt_all };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
+	for (float2 *p : fe->d_stage) if (p) (void)hipFree(p);
 	if (fe->stream) (void)hipStreamDestroy(fe->stream);
 	if (fe->own_decode_stream && fe->stream_d) (void)hipStreamDestroy(fe->stream_d);
 	if (fe->stream_b) (void)hipStreamDestroy(fe->stream_b);
@@ -231,45 +243,42 @@ static int pick_slices(int nch, int rows)
 	return s;
 }
 
-// Blocks per demodulator launch.  Where the demodulator bounds the block (few channels: a serial recurrence per channel on a handful of
-// SIMDs, ~0.35 us per 5400-sps sample whatever the channel count) every launch pays for itself a second time in fixed costs: the
-// barrier packet in front of it (~11 us), ~25 KiB of tables and state staged into LDS and written back, and two chunks of pipeline
-// fill and drain -- ~40 us against ~210 us of recurrence per cfg2 block.  When blocks arrive faster than they are demodulated (file
-// replay, catching up) consecutive blocks are therefore handed to ONE launch, which treats them as one longer stretch of samples --
-// the per-channel state is carried sample by sample, so the result is that of block-by-block processing.  A caller that waits
-// for its PDUs after every block (live input: poll / sync) still gets a launch per block: a partial batch is launched by any call
-// that needs the results.  Bounds: the LDS (Demod::init keeps what fits), and one second of signal -- less than half the shortest
-// frame (2.34 s), so that a channel finishes at most one frame per launch (frame queue: one entry per channel; two data slots).
+// Create-time configuration from the environment (include/hfdl_gpu.h documents every name).  Read at every create and never cached:
+// there is no function-local static to race on when front ends are created from several threads.  The A/B switches of the
+// measurement scripts exist in the laboratory build only (-DHFDL_LAB, libhfdl_gpu_lab.so).
+static long env_long(const char *name, long lo, long hi, long otherwise)
+{
+	const char *e = getenv(name);
+	if (!e || !*e) return otherwise;
+	char *end = nullptr;
+	const long v = strtol(e, &end, 10);
+	return (end != e && v >= lo && v <= hi) ? v : otherwise;
+}
+
+// Blocks per demodulator launch.  Every launch pays fixed costs: the barrier packet in front of it (~11 us), ~25 KiB of tables and
+// state staged into LDS and written back, and two chunks of pipeline fill and drain -- ~40 us against ~210 us of recurrence per
+// cfg2 block.  When blocks arrive faster than they are demodulated (file replay, catching up) consecutive blocks are therefore handed
+// to ONE launch, which treats them as one longer stretch of samples -- the per-channel state is carried sample by sample, so the
+// result is that of block-by-block processing.  A caller that waits for its PDUs after every block (live input: poll / sync) still
+// gets a launch per block: a partial batch is launched by any call that needs the results.  Bounds: the LDS (Demod::init keeps what
+// fits: 46 B per sample, two cfg3 blocks), and one second of signal -- less than half the shortest frame (2.34 s), so that a channel
+// finishes at most one frame per launch (frame queue: one entry per channel; two data slots).
 static int pick_demod_batch(const hfdl_gpu_frontend *fe)
 {
-	int want = 1;
-	if (fe->own_decode_stream) {
-		const double block_s = (double)fe->plan.input_size / (double)fe->sample_rate;
-		want = (int)std::floor(1.0 / block_s);
-		want = std::max(1, std::min(8, want));
-	}
-	if (const char *e = getenv("HFDL_GPU_DEMOD_BATCH")) {       // A/B measurements; 1 = a launch per block
-		const long v = strtol(e, nullptr, 10);
-		if (v >= 1 && v <= 8) want = (int)v;
-	}
-	return want;
+	const double block_s = (double)fe->plan.input_size / (double)fe->sample_rate;
+	int want = (int)std::floor(1.0 / block_s);
+	want = std::max(1, std::min(8, want));
+	return (int)env_long("HFDL_GPU_DEMOD_BATCH", 1, 8, want);       // 1 = a launch per block
 }
 
 // Blocks per fold launch.  The filter taps are 99.9 % of a block's bytes on the fold-bound geometries (cfg3: 16 GiB of taps against
 // a 64 MiB spectrum) and they are the same for every block: when blocks are pushed faster than they are collected (file replay,
-// catching up, the bench) the spectra of up to `fold_nb` consecutive blocks are folded in ONE pass over the taps
-// (fold_kernels.hip, NB).  Every block's sums are bit-identical to a launch of its own (fixed FMA chain per bin); a caller that polls
+// catching up, the bench) the spectra of up to `fold_nb` consecutive blocks are folded in ONE pass over the taps on the matrix pipe
+// (fold_kernels.hip).  Every block's sums are bit-identical to a launch of its own (fixed FMA chain per bin); a caller that polls
 // or syncs after every block (live input) still gets one launch per block: a sync / poll closes the half as it is.
 static int pick_fold_batch()
 {
-	// 8: measured on cfg3 (profiles/r04_experiments.md) -- a launch of 8 takes 3.4 ms against 2.6 for 4 and 2.5 for 1; beyond that the
-	// multiplies (4 FMAs per tap and block) cost as much as the taps' HBM time and the register tile (acc[NB][NC]) runs out
-	int want = 8;
-	if (const char *e = getenv("HFDL_GPU_FOLD_BATCH")) {        // A/B measurements; 1 = a pass over the taps per block
-		const long v = strtol(e, nullptr, 10);
-		if (v >= 1 && v <= hfdl_gpu_frontend::MAX_HALF) want = (int)v;
-	}
-	return want;
+	return (int)env_long("HFDL_GPU_FOLD_BATCH", 1, hfdl_gpu_frontend::MAX_HALF, 16);       // 1 = a pass over the taps per block
 }
 
 static int build_taps(hfdl_gpu_frontend *fe)
@@ -281,10 +290,8 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	std::vector<std::complex<float>> host((size_t)nch * (size_t)pl.taps_length);
 	fe->cc.resize((size_t)nch);
 	unsigned nthreads = std::max(1u, std::min((unsigned)nch, std::thread::hardware_concurrency()));
-	if (const char *e = getenv("HFDL_GPU_HOST_THREADS")) {      // several front ends created at once on one host (one process per GPU): share the cores
-		const long v = strtol(e, nullptr, 10);
-		if (v >= 1) nthreads = std::min(nthreads, (unsigned)v);
-	}
+	// several front ends created at once on one host (one process per GPU): share the cores
+	nthreads = std::min(nthreads, (unsigned)env_long("HFDL_GPU_HOST_THREADS", 1, 1 << 16, (long)nthreads));
 	std::atomic<int> next{0};
 	std::atomic<int> bad{0};
 	auto work = [&]() {
@@ -317,11 +324,15 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	HIP_TRY(pad.alloc(sizeof(float2) * n));
 	float2 *d_pad = pad.as<float2>();
 	HIP_TRY(hipMemsetAsync(d_pad, 0, sizeof(float2) * n, fe->stream));
+	if (fe->geo.nch_pad > nch)          // the odd channel's partner in the pair-interleaved layout: all-zero taps
+		HIP_TRY(hipMemset2DAsync(fe->d_taps + (size_t)nch * (size_t)fe->geo.tap_chan_stride, sizeof(float2) * (size_t)fe->geo.tap_row_stride, 0,
+				sizeof(float2) * (size_t)pl.m, (size_t)pl.pre, fe->stream));
 	for (int c = 0; c < nch; c++) {
 		HIP_TRY(hipMemcpyAsync(d_pad, host.data() + (size_t)c * pl.taps_length, sizeof(float2) * (size_t)pl.taps_length,
 				hipMemcpyHostToDevice, fe->stream));
 		launch_fft_forward(fe->fft.p, nullptr, d_pad, SFMT_CF32, 0, nullptr, fe->d_work, fe->d_taps + (size_t)c * (size_t)fe->geo.tap_chan_stride, true, fe->stream, fe->tap_layout);
 	}
+	HIP_TRY(launch_tap_interleave(fe->d_taps, fe->geo, fe->stream));      // rows of channel pairs into matrix-operand order (fold_kernels.hip)
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -357,7 +368,9 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	// Filter taps row-major over channels: alias row r of every channel sits in one nch*M run, so the workgroups of all
 	// channels, which walk the rows together, stream through a few moving windows of HBM instead of nch windows 8N bytes
 	// apart (fold kernel 2.58 -> 2.48 ms on cfg3 and a tighter run-to-run spread, profiles/r01_experiments.md)
-	g.tap_chan_stride = pl.m; g.tap_row_stride = (int64_t)nch * pl.m;
+	g.pair_layout = (pl.m % 64) == 0 ? 1 : 0;
+	g.nch_pad = g.pair_layout ? (nch + 1) & ~1 : nch;
+	g.tap_chan_stride = pl.m; g.tap_row_stride = (int64_t)g.nch_pad * pl.m;
 	fe->tap_layout.row_log = ilog2(pl.m); fe->tap_layout.row_stride = g.tap_row_stride;
 	g.slices = pick_slices(nch, pl.pre);
 	g.rows_per_slice = pl.pre / g.slices;
@@ -374,35 +387,34 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	}
 	FE_TRY(hipStreamCreateWithFlags(&fe->stream_c, hipStreamNonBlocking));
 	{
-		// HFDL_GPU_FFT_STREAM=1 puts the forward FFTs of the blocks being pushed on a stream of their own, beside the fold of the half
-		// before (two sets of spectra / phasor tables / state snapshots).  Measured on cfg3 at 8 blocks per fold launch
-		// (profiles/r04_experiments.md): the FFT passes then take their HBM share out of the fold (3.25 -> 4.3 ms per launch) and out of
-		// the demodulators beside it (0.41 -> 0.51 ms per block), 11.3 -> 10.4 Gsamples/s -- fold, FFT and demodulators together already
-		// keep the machine busy, so the FFTs stay in front of the fold on stream A.  Kept as a switch for other geometries / boards.
-		// (More than four busy streams also need GPU_MAX_HW_QUEUES > 4: two streams on one hardware queue run in turn.)
+		// Forward FFTs of the half being filled on a stream of their own, beside the fold of the half before (two sets of spectra / phasor
+		// tables / state snapshots): measured on cfg3 in round 4 (profiles/r04_experiments.md) the passes then take their HBM share out of
+		// the fold and the demodulators and the step gets slower, so the FFTs stay in front of the fold on stream A.  The switch lives in the
+		// laboratory build.  (More than four busy streams also need GPU_MAX_HW_QUEUES > 4: two streams on one hardware queue run in turn.)
 		fe->fft_own_stream = false;
-		if (const char *e = getenv("HFDL_GPU_FFT_STREAM")) fe->fft_own_stream = atoi(e) != 0;
+#ifdef HFDL_LAB
+		fe->fft_own_stream = env_long("HFDL_GPU_FFT_STREAM", 0, 1, 0) != 0;
+#endif
 		if (fe->fft_own_stream) FE_TRY(hipStreamCreateWithFlags(&fe->stream_f, hipStreamNonBlocking));
 		else fe->stream_f = fe->stream;
 		for (auto &e : fe->ev_spec) FE_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	}
 	{
-		// The burst decoder of block k only hands PDUs to the host; the demodulator of block k+1 does not need it.  With few
-		// channels the demodulator (a serial recurrence per channel, ~0.3 ms per block whatever the channel count) bounds the
-		// block, and a frame ending in a block puts 0.3 ms of Viterbi on the same stream: the decoder then gets its own stream
-		// (cfg2: +25 %).  With many channels the fold bounds the block, stream B has slack, and one more busy hardware queue
-		// costs the fold more than it saves (profiles/r01_experiments.md): the decoder stays on stream B.
-		fe->own_decode_stream = nch < 128;
-		if (const char *e = getenv("HFDL_GPU_DECODE_STREAM")) fe->own_decode_stream = atoi(e) != 0;      // A/B measurements
+		// The burst decoder of launch k only hands PDUs to the host; the demodulator of launch k+1 does not need it, and a long frame
+		// ending in a block puts 0.3 - 1.2 ms of Viterbi in front of it: the decoder has its own stream (cfg2: +25 % in round 2; at 256
+		// channels the round-4 timeline shows a 1.18 ms decoder launch serially ahead of a half's first demodulator).
+		// fold_bound: with many channels the fold bounds the block; the demodulator launches of a half are then held back until the next
+		// half's forward FFTs are queued (launch_demod) instead of starting at once.
+		fe->fold_bound = nch >= 128;
+		fe->own_decode_stream = true;
+#ifdef HFDL_LAB
+		fe->own_decode_stream = env_long("HFDL_GPU_DECODE_STREAM", 0, 1, 1) != 0;
+#endif
 		if (fe->own_decode_stream) FE_TRY(hipStreamCreateWithFlags(&fe->stream_d, hipStreamNonBlocking));
 		else fe->stream_d = fe->stream_b;
 		fe->demod.separate_decode = fe->own_decode_stream;
 	}
 	for (int i = 0; i < 2; i++) {
-		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_ready[i], hipEventDisableTiming));
-		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_free[i], hipEventDisableTiming));
-		FE_TRY(hipEventCreateWithFlags(&fe->ev_copy[i], hipEventDisableTiming));
-		FE_TRY(hipEventCreateWithFlags(&fe->ev_copy[i + 2], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_chan[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_demod[i], hipEventDisableTiming));
 		for (auto &e : fe->ev_dm[i]) FE_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -414,7 +426,7 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 		FE_TRY(hipMemsetAsync(fe->d_hist[i], 0, sizeof(float2) * (size_t)pl.overlap, fe->stream));   // calloc'ed history, src/fft.c:79
 	}
 	FE_TRY(hipMalloc(&fe->d_work, sizeof(float2) * n));
-	FE_TRY(hipMalloc(&fe->d_taps, sizeof(float2) * n * (size_t)nch));
+	FE_TRY(hipMalloc(&fe->d_taps, sizeof(float2) * n * (size_t)g.nch_pad));
 	FE_TRY(hipMalloc(&fe->d_nco, sizeof(NcoState) * (size_t)nch));
 	FE_TRY(hipMemsetAsync(fe->d_nco, 0, sizeof(NcoState) * (size_t)nch, fe->stream));
 	FE_TRY(hipMalloc(&fe->d_ph_cont, sizeof(float2) * (size_t)nch));
@@ -436,6 +448,11 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	fe->batch = fe->demod.batch;        // what fits the demodulator's LDS
 	fe->fold_nb = pick_fold_batch();
 	fe->half_blocks = std::min((int)hfdl_gpu_frontend::MAX_HALF, ((std::max(fe->fold_nb, fe->batch) + fe->fold_nb - 1) / fe->fold_nb) * fe->fold_nb);
+	fe->n_stage = fe->half_blocks + 2;
+	for (int i = 0; i < fe->n_stage; i++) {
+		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_ready[i], hipEventDisableTiming));
+		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_free[i], hipEventDisableTiming));
+	}
 	const size_t hb = (size_t)fe->half_blocks;
 	FE_TRY(hipMalloc(&fe->d_spec, sizeof(float2) * n * 2 * hb));
 	FE_TRY(hipMalloc(&fe->d_partial, sizeof(float2) * fe->partial_stride() * hb));
@@ -464,6 +481,7 @@ extern "C" int hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_
 	g->channels = fe->geo.nch; g->fold_slices = fe->geo.slices;
 	g->demod_batch = fe->batch;
 	g->fold_batch = fe->fold_nb;
+	g->prefetch_depth = fe->n_stage - 1;
 	g->transition_bw = fe->tbw;
 	g->resamp_rate = (float)(1800 * 3) / ((float)fe->sample_rate / (float)fe->decimation);
 	return 0;
@@ -522,23 +540,27 @@ extern "C" void *hfdl_gpu_frontend_stream(hfdl_gpu_frontend *fe) { return fe ? (
 
 static size_t sample_bytes(int fmt) { return fmt == SFMT_CS16 ? 4 : fmt == SFMT_CU8 ? 2 : 8; }
 
-// queue the host -> device copy of the next host block on stream C into staging buffer (host_blocks & 1)
+// queue the host -> device copy of the next host block on stream C into staging buffer host_blocks % n_stage
 static int queue_input_copy(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, int fmt, int *sb_out)
 {
-	const uint64_t j = fe->host_blocks++;
-	const int sb = (int)(j & 1);
+	// buffer j % n_stage is freed by the forward FFT of host block j - n_stage: that block must have been pushed
+	if (fe->host_blocks - fe->host_pushed >= (uint64_t)fe->n_stage)
+		return fail(HFDL_GPU_ERANGE, "%d uploads are queued ahead of their blocks: push the oldest first", fe->n_stage);
+	const uint64_t j = fe->host_blocks;
+	const int sb = (int)(j % (uint64_t)fe->n_stage);
 	if (fe->stage_cap[sb] < nsamples) {
+		HIP_TRY(hipStreamSynchronize(fe->stream_c));
 		HIP_TRY(hipStreamSynchronize(fe->stream_f));
 		if (fe->d_stage[sb]) (void)hipFree(fe->d_stage[sb]);
 		fe->d_stage[sb] = nullptr; fe->stage_cap[sb] = 0;
 		HIP_TRY(hipMalloc(&fe->d_stage[sb], sizeof(float2) * nsamples));
 		fe->stage_cap[sb] = nsamples;
 	}
-	HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_stage_free[sb], 0));     // the forward FFT finished reading this buffer two blocks ago
+	HIP_TRY(hipStreamWaitEvent(fe->stream_c, fe->ev_stage_free[sb], 0));     // the forward FFT that read this buffer last is past its first pass
 	// (one hipMemcpyAsync per block: cutting a block in 2 or 4 pieces on as many streams was measured and is slower, profiles/r03_experiments.md)
 	HIP_TRY(hipMemcpyAsync(fe->d_stage[sb], iq, sample_bytes(fmt) * nsamples, hipMemcpyHostToDevice, fe->stream_c));
 	HIP_TRY(hipEventRecord(fe->ev_stage_ready[sb], fe->stream_c));
-	HIP_TRY(hipEventRecord(fe->ev_copy[j & 3], fe->stream_c));
+	fe->host_blocks = j + 1;
 	// a buffer this library did not allocate may be reused by the caller as soon as we return (include/hfdl_gpu.h): do not
 	// rely on the runtime staging pageable memory synchronously -- wait for the copy (the kernels of the previous block keep running)
 	if (!is_library_pinned(iq, sample_bytes(fmt) * nsamples)) HIP_TRY(hipStreamSynchronize(fe->stream_c));
@@ -546,8 +568,8 @@ static int queue_input_copy(hfdl_gpu_frontend *fe, const void *iq, size_t nsampl
 	return 0;
 }
 
-// Host input is double-buffered in HBM: the copy of block k+1 (stream C) runs while block k computes (stream A).
-// *stage_idx = staging buffer used (-1 for device input): the caller records ev_stage_free once stream A has read it.
+// Host input is staged in HBM: the copies (stream C) run up to a whole half ahead of the blocks that compute (stream A).
+// *stage_idx = staging buffer used (-1 for device input): the forward FFT's first pass signals ev_stage_free when it has read it.
 static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, int fmt, int on_device, const void **dev, int *stage_idx)
 {
 	*stage_idx = -1;
@@ -556,22 +578,23 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 	if (nsamples != (size_t)fe->plan.input_size)
 		return fail(HFDL_GPU_EINVAL, "a block is exactly %d samples (got %zu)", fe->plan.input_size, nsamples);
 	HIP_TRY(hipSetDevice(fe->device));
+	const bool queued = fe->host_pushed < fe->host_blocks;      // prefetched blocks are waiting
 	if (on_device) {
-		// the prefetched host block is numbered and staged: a device block slipped in front of it would be processed out of order
-		if (fe->prefetched != nullptr) return fail(HFDL_GPU_EINVAL, "a prefetched block is pending: push it or call hfdl_gpu_frontend_prefetch_cancel()");
+		// the prefetched host blocks are numbered and staged: a device block slipped in front of them would be processed out of order
+		if (queued) return fail(HFDL_GPU_EINVAL, "a prefetched block is pending: push it or call hfdl_gpu_frontend_prefetch_cancel()");
 		*dev = iq;
 		return 0;
 	}
 	int sb;
-	if (fe->prefetched != nullptr) {
-		// the copy of this block was queued ahead by hfdl_gpu_frontend_prefetch_block_raw()
-		if (fe->prefetched != iq || fe->prefetched_fmt != fmt) return fail(HFDL_GPU_EINVAL, "the block pushed after a prefetch must be the prefetched one");
-		sb = fe->prefetched_sb;
-		fe->prefetched = nullptr;
+	if (queued) {
+		// the copy of this block was queued ahead by hfdl_gpu_frontend_prefetch_block_raw(): blocks are pushed in the order they were prefetched
+		sb = (int)(fe->host_pushed % (uint64_t)fe->n_stage);
+		if (fe->pf_ptr[sb] != iq || fe->pf_fmt[sb] != fmt) return fail(HFDL_GPU_EINVAL, "the block pushed after a prefetch must be the (oldest) prefetched one");
 	} else {
 		int rc = queue_input_copy(fe, iq, nsamples, fmt, &sb);
 		if (rc) return rc;
 	}
+	fe->host_pushed++;
 	HIP_TRY(hipStreamWaitEvent(fe->stream_f, fe->ev_stage_ready[sb], 0));
 	*dev = fe->d_stage[sb];
 	*stage_idx = sb;
@@ -643,12 +666,12 @@ static int enqueue_fft(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int st
 	job.ph = fe->ph_slot(set, i); job.cont = fe->d_ph_cont;
 	job.nch = g.nch; job.outs = g.outs; job.post_input_size = g.post_input_size; job.post = g.post;
 	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->spec_slot(set, i), true, fe->stream_f,
-			FftOutLayout(), fe->fft_own_stream ? fe->ev_spec[set] : (pend ? fe->ev_fft : nullptr), job);
+			FftOutLayout(), fe->fft_own_stream ? fe->ev_spec[set] : (pend ? fe->ev_fft : nullptr), job,
+			stage_idx >= 0 ? fe->ev_stage_free[stage_idx] : nullptr);       // input consumed once pass 1 is done: the copy stream may refill the buffer
 	if (pend) {
 		int rc = flush_pending_demod(fe, true);
 		if (rc) return rc;
 	}
-	if (stage_idx >= 0) HIP_TRY(hipEventRecord(fe->ev_stage_free[stage_idx], fe->stream_f));   // input consumed: the copy stream may refill it
 	HIP_TRY(hipGetLastError());
 	fe->blocks++;
 	fe->batch_fill++;
@@ -755,7 +778,7 @@ static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int
 	// demodulator-bound geometry (few channels): the fold is short, there is nothing to place the demodulator under, and
 	// holding it back until the NEXT half's forward FFTs would put those blocks' host -> device copies on the demodulator's
 	// critical path (cfg2 fed from host memory: 0.56 -> 0.33 ms per block): launched at once.  Otherwise held back (launch_demod).
-	return close_half(fe, fe->own_decode_stream);
+	return close_half(fe, !fe->fold_bound);
 }
 
 extern "C" int hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
@@ -778,6 +801,7 @@ static int drain_events(hfdl_gpu_frontend *fe)
 		fe->fold_launches++;
 		fe->fold_timed_blocks += fe->ev_blocks[i];
 		fe->fold_last_blocks = fe->ev_blocks[i];
+		if (fe->ev_blocks[i] >= 1 && fe->ev_blocks[i] <= FOLD_MAX_BLOCKS) fe->fold_shapes[fe->ev_blocks[i]]++;
 		if (!fe->ev_first_fold) {
 			fe->ev_first_fold = e.first;            // kept until the next reset
 			HIP_TRY(hipEventCreate(&e.first));
@@ -829,13 +853,26 @@ extern "C" int hfdl_gpu_frontend_input_done_upto(hfdl_gpu_frontend *fe, uint64_t
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
 	if (host_block >= fe->host_blocks) return fail(HFDL_GPU_EINVAL, "host block %llu has not been pushed (%llu so far)", (unsigned long long)host_block, (unsigned long long)fe->host_blocks);
-	// The copy of host block j signals ev_copy[j & 3].  Copies run in order on one stream, so for a block more than three behind
-	// the newest (its event has been re-recorded since) the oldest event still its own block's implies it.
-	const uint64_t newest = fe->host_blocks - 1;
-	const uint64_t j = newest - host_block <= 3 ? host_block : newest - 3;
+	// The copy of host block j signals ev_stage_ready[j % n_stage].  Copies run in order on one stream, so for a block more than
+	// n_stage - 1 behind the newest (its event has been re-recorded since) the oldest event still its own block's implies it.
+	const uint64_t newest = fe->host_blocks - 1, span = (uint64_t)fe->n_stage - 1;
+	const uint64_t j = newest - host_block <= span ? host_block : newest - span;
 	HIP_TRY(hipSetDevice(fe->device));
-	HIP_TRY(hipEventSynchronize(fe->ev_copy[j & 3]));
+	HIP_TRY(hipEventSynchronize(fe->ev_stage_ready[j % (uint64_t)fe->n_stage]));
 	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_input_copied(hfdl_gpu_frontend *fe, uint64_t host_block)
+{
+	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
+	if (host_block >= fe->host_blocks) return fail(HFDL_GPU_EINVAL, "host block %llu has not been pushed (%llu so far)", (unsigned long long)host_block, (unsigned long long)fe->host_blocks);
+	const uint64_t newest = fe->host_blocks - 1, span = (uint64_t)fe->n_stage - 1;
+	const uint64_t j = newest - host_block <= span ? host_block : newest - span;
+	HIP_TRY(hipSetDevice(fe->device));
+	const hipError_t e = hipEventQuery(fe->ev_stage_ready[j % (uint64_t)fe->n_stage]);
+	if (e == hipSuccess) return 1;
+	if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }       // "not yet" is an answer, not an error to be found by a later check
+	return fail(HFDL_GPU_EHIP, "hipEventQuery: %s", hipGetErrorString(e));
 }
 
 extern "C" int hfdl_gpu_frontend_prefetch_block_raw(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int sample_format)
@@ -844,27 +881,27 @@ extern "C" int hfdl_gpu_frontend_prefetch_block_raw(hfdl_gpu_frontend *fe, const
 	if (sample_format != SFMT_CF32 && sample_format != SFMT_CS16 && sample_format != SFMT_CU8) return fail(HFDL_GPU_EINVAL, "unknown sample format %d", sample_format);
 	if (nsamples != (size_t)fe->plan.input_size)
 		return fail(HFDL_GPU_EINVAL, "a block is exactly %d samples (got %zu)", fe->plan.input_size, nsamples);
-	if (fe->prefetched != nullptr) return fail(HFDL_GPU_EINVAL, "one block can be prefetched at a time");
+	if (fe->host_blocks - fe->host_pushed >= (uint64_t)(fe->n_stage - 1))
+		return fail(HFDL_GPU_ERANGE, "%d blocks are prefetched already (geometry.prefetch_depth): push the oldest first", fe->n_stage - 1);
 	if (!is_library_pinned(raw, sample_bytes(sample_format) * nsamples)) return fail(HFDL_GPU_EINVAL, "only buffers from hfdl_gpu_host_alloc() can be prefetched");
 	HIP_TRY(hipSetDevice(fe->device));
 	int sb = -1;
 	int rc = queue_input_copy(fe, raw, nsamples, sample_format, &sb);
 	if (rc) return rc;
-	fe->prefetched = raw; fe->prefetched_sb = sb; fe->prefetched_fmt = sample_format;
+	fe->pf_ptr[sb] = raw; fe->pf_fmt[sb] = sample_format;
 	return 0;
 }
 
 extern "C" int hfdl_gpu_frontend_prefetch_cancel(hfdl_gpu_frontend *fe)
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
-	if (fe->prefetched == nullptr) return 0;
+	if (fe->host_pushed == fe->host_blocks) return 0;
 	HIP_TRY(hipSetDevice(fe->device));
-	// the copy is in flight on stream C: let it finish (the caller gets its buffer back), then forget the block.  It keeps its host
-	// block number -- input_done_upto() of that number returns at once -- so the next block goes to the OTHER staging buffer, and
-	// this one is refilled by the copy after that: its ev_stage_free was last recorded by the block that used it before the
-	// cancelled one, which stream C has already waited for.
+	// the copies are in flight on stream C: let them finish (the caller gets its buffers back), then forget the blocks.  They keep
+	// their host block numbers -- input_done_upto() of those numbers returns at once.  Their staging buffers are refilled by later
+	// copies, which wait for ev_stage_free as last recorded by the blocks that used the buffers BEFORE the cancelled ones: long done.
 	HIP_TRY(hipStreamSynchronize(fe->stream_c));
-	fe->prefetched = nullptr; fe->prefetched_sb = -1;
+	fe->host_pushed = fe->host_blocks;
 	return 0;
 }
 
@@ -874,6 +911,7 @@ extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
 	fe->fold_ms = 0; fe->fold_launches = 0; fe->fold_timed_blocks = 0; fe->fold_last_blocks = 0; fe->timing = enable != 0;
+	for (auto &c : fe->fold_shapes) c = 0;
 	fe->demod_ms = 0; fe->demod_launches = 0; fe->demod_timed_blocks = 0;
 	if (fe->ev_first_fold) { (void)hipEventDestroy(fe->ev_first_fold); fe->ev_first_fold = nullptr; }
 	fe->span_ms = 0;
@@ -887,38 +925,6 @@ extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
 	return 0;
 }
 
-extern "C" int hfdl_gpu_frontend_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_per_s)
-{
-	if (!fe || !gb_per_s) return fail(HFDL_GPU_EINVAL, "null argument");
-	int rc = hfdl_gpu_frontend_sync(fe);
-	if (rc) return rc;
-	// read the resident filter taps themselves (whole multiples of 4 MiB, at most 16 GiB): best launch of every variant
-	size_t bytes = sizeof(float2) * (size_t)fe->geo.n * (size_t)fe->geo.nch;
-	bytes -= bytes % ((size_t)4 << 20);
-	if (bytes > ((size_t)16 << 30)) bytes = (size_t)16 << 30;
-	if (bytes == 0) return fail(HFDL_GPU_ERANGE, "front end too small for the probe");
-	DevBuf sink;
-	HIP_TRY(sink.alloc(sizeof(float)));
-	hipEvent_t e0, e1;
-	HIP_TRY(hipEventCreate(&e0));
-	HIP_TRY(hipEventCreate(&e1));
-	double best = 0;
-	for (int variant = 0; variant < stream_read_variants(); variant++)
-		for (int it = 0; it < 3; it++) {
-			HIP_TRY(hipEventRecord(e0, fe->stream));
-			launch_stream_read(variant, fe->d_taps, bytes, sink.as<float>(), fe->stream);
-			HIP_TRY(hipEventRecord(e1, fe->stream));
-			HIP_TRY(hipEventSynchronize(e1));
-			float ms = 0;
-			HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-			if (getenv("HFDL_GPU_PROBE_VERBOSE")) fprintf(stderr, "stream read variant %d: %.1f GB/s\n", variant, (double)bytes / (ms * 1e-3) / 1e9);
-			if (it > 0 && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
-		}
-	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-	*gb_per_s = best;
-	return 0;
-}
-
 extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches)
 {
 	if (!fe) return fail(HFDL_GPU_EINVAL, "null argument");
@@ -929,63 +935,21 @@ extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *tot
 	return 0;
 }
 
+extern "C" int hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[17])
+{
+	if (!fe || !counts) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	for (int i = 0; i <= FOLD_MAX_BLOCKS; i++) counts[i] = fe->fold_shapes[i];
+	return 0;
+}
+
 extern "C" int hfdl_gpu_frontend_fold_blocks(hfdl_gpu_frontend *fe, int64_t *blocks)
 {
 	if (!fe || !blocks) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
 	*blocks = fe->fold_timed_blocks;
-	return 0;
-}
-
-extern "C" int hfdl_gpu_fold_variant_count(void) { return fold_variant_count(); }
-
-extern "C" int hfdl_gpu_fold_variant_describe(int variant, int32_t desc[6])
-{
-	int d[6];
-	if (!desc || fold_variant_describe(variant, d)) return fail(HFDL_GPU_EINVAL, "no fold variant %d", variant);
-	for (int i = 0; i < 6; i++) desc[i] = d[i];
-	return 0;
-}
-
-// Measurement aid (profiles/fold_variants.py): `reps` launches of one compiled tiling over the front end's own taps and the spectra /
-// partial sums of the half (whatever the last blocks left there), timed by the kernels' own events; *checksum = a 64-bit sum over the
-// partial sums' bit patterns, equal across tilings of the same NB when they are bit-identical.
-extern "C" int hfdl_gpu_frontend_fold_variant_probe(hfdl_gpu_frontend *fe, int variant, int reps, double *avg_ms, double *best_ms, uint64_t *checksum)
-{
-	if (!fe || !avg_ms || reps < 1) return fail(HFDL_GPU_EINVAL, "bad arguments");
-	int rc = hfdl_gpu_frontend_sync(fe);
-	if (rc) return rc;
-	int d[6];
-	if (fold_variant_describe(variant, d)) return fail(HFDL_GPU_EINVAL, "no fold variant %d", variant);
-	if (d[4] > fe->half_blocks) return fail(HFDL_GPU_ERANGE, "variant folds %d blocks, a half holds %d", d[4], fe->half_blocks);
-	const Geometry &g = fe->geo;
-	hipEvent_t e0, e1;
-	HIP_TRY(hipEventCreate(&e0));
-	HIP_TRY(hipEventCreate(&e1));
-	double sum = 0, best = 1e30;
-	for (int i = 0; i < reps + 1; i++) {
-		if (launch_fold_variant(variant, g, fe->d_taps, fe->spec_slot(fe->last_set, 0), (size_t)g.n, fe->d_partial, fe->partial_stride(), fe->stream, e0, e1) < 0) {
-			(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-			return fail(HFDL_GPU_ERANGE, "fold variant %d does not fit this geometry (M = %d)", variant, g.m);
-		}
-		HIP_TRY(hipEventSynchronize(e1));
-		float ms = 0;
-		HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-		if (i > 0) { sum += ms; best = std::min(best, (double)ms); }       // first launch: code load
-	}
-	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-	HIP_TRY(hipGetLastError());
-	*avg_ms = sum / reps;
-	if (best_ms) *best_ms = best;
-	if (checksum) {
-		const size_t words = 2 * fe->partial_stride() * (size_t)d[4];
-		std::vector<uint32_t> h(words);
-		HIP_TRY(hipMemcpy(h.data(), fe->d_partial, sizeof(uint32_t) * words, hipMemcpyDeviceToHost));
-		uint64_t acc = 0;
-		for (size_t i = 0; i < words; i++) acc += (uint64_t)h[i] * (uint64_t)(2 * (i % 65521) + 1);
-		*checksum = acc;
-	}
 	return 0;
 }
 
@@ -1110,10 +1074,13 @@ extern "C" int hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what,
 	switch (what) {
 	case HFDL_GPU_TAP_SPECTRUM: src = fe->spec_slot(fe->last_set, index); nf = 2 * (size_t)g.n; break;
 	case HFDL_GPU_TAP_FILTER: {
-		// rows of M bins, tap_row_stride apart: gather them into the caller's contiguous cf32[N]
+		// the taps lie pair-interleaved, rows tap_row_stride apart (fold_kernels.hip): a kernel gathers the channel into plain cf32[N]
 		if (2 * (size_t)g.n > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", 2 * (size_t)g.n, cap);
-		HIP_TRY(hipMemcpy2D(dst, sizeof(float2) * (size_t)g.m, fe->d_taps + (size_t)channel * (size_t)g.tap_chan_stride,
-				sizeof(float2) * (size_t)g.tap_row_stride, sizeof(float2) * (size_t)g.m, (size_t)g.pre, hipMemcpyDeviceToHost));
+		DevBuf plain;
+		HIP_TRY(plain.alloc(sizeof(float2) * (size_t)g.n));
+		launch_tap_extract(fe->d_taps, g, channel, plain.as<float2>(), fe->stream);
+		HIP_TRY(hipStreamSynchronize(fe->stream));
+		HIP_TRY(hipMemcpy(dst, plain.p, sizeof(float2) * (size_t)g.n, hipMemcpyDeviceToHost));
 		*n_floats = 2 * (size_t)g.n;
 		return 0; }
 	case HFDL_GPU_TAP_CHAN_OUT: {
@@ -1266,3 +1233,90 @@ extern "C" int hfdl_gpu_psk_slice(int device, int32_t arity, const float *xy, in
 	if (rc) return fail(rc, "psk slice failed: %s", hipGetErrorString(hipGetLastError()));
 	return 0;
 }
+
+// ---------------------------------------------------------------- laboratory build only (libhfdl_gpu_lab.so, include/hfdl_gpu_lab.h)
+#ifdef HFDL_LAB
+#include "../../include/hfdl_gpu_lab.h"
+
+extern "C" int hfdl_gpu_lab_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_per_s)
+{
+	if (!fe || !gb_per_s) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	// read the resident filter taps themselves (whole multiples of 4 MiB, at most 16 GiB): best launch of every variant
+	size_t bytes = sizeof(float2) * (size_t)fe->geo.n * (size_t)fe->geo.nch_pad;
+	bytes -= bytes % ((size_t)4 << 20);
+	if (bytes > ((size_t)16 << 30)) bytes = (size_t)16 << 30;
+	if (bytes == 0) return fail(HFDL_GPU_ERANGE, "front end too small for the probe");
+	DevBuf sink;
+	HIP_TRY(sink.alloc(sizeof(float)));
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	double best = 0;
+	for (int variant = 0; variant < stream_read_variants(); variant++)
+		for (int it = 0; it < 3; it++) {
+			HIP_TRY(hipEventRecord(e0, fe->stream));
+			launch_stream_read(variant, fe->d_taps, bytes, sink.as<float>(), fe->stream);
+			HIP_TRY(hipEventRecord(e1, fe->stream));
+			HIP_TRY(hipEventSynchronize(e1));
+			float ms = 0;
+			HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+			if (getenv("HFDL_GPU_PROBE_VERBOSE")) fprintf(stderr, "stream read variant %d: %.1f GB/s\n", variant, (double)bytes / (ms * 1e-3) / 1e9);
+			if (it > 0 && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+		}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	*gb_per_s = best;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_lab_fold_variant_count(void) { return fold_variant_count(); }
+
+extern "C" int hfdl_gpu_lab_fold_variant_describe(int variant, int32_t desc[6])
+{
+	int d[6];
+	if (!desc || fold_variant_describe(variant, d)) return fail(HFDL_GPU_EINVAL, "no fold variant %d", variant);
+	for (int i = 0; i < 6; i++) desc[i] = d[i];
+	return 0;
+}
+
+// `reps` launches of one compiled tiling (variant -1: the plain-VALU FMA-chain reference kernel) over the front end's own taps and the
+// spectra / partial sums of the newest half (whatever the last blocks left there), `nb` blocks per launch, timed by the kernels' own
+// events; *checksum = a 64-bit sum over the partial sums' bit patterns, equal across kernels when they are bit-identical.
+extern "C" int hfdl_gpu_lab_fold_variant_probe(hfdl_gpu_frontend *fe, int variant, int nb, int reps, double *avg_ms, double *best_ms, uint64_t *checksum)
+{
+	if (!fe || !avg_ms || reps < 1 || nb < 1) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	if (nb > fe->half_blocks) return fail(HFDL_GPU_ERANGE, "%d blocks asked for, a half holds %d", nb, fe->half_blocks);
+	const Geometry &g = fe->geo;
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipMemsetAsync(fe->d_partial, 0xff, sizeof(float2) * fe->partial_stride() * (size_t)nb, fe->stream));    // nothing left over from another kernel counts
+	double sum = 0, best = 1e30;
+	for (int i = 0; i < reps + 1; i++) {
+		if (launch_fold_variant(variant, g, fe->d_taps, fe->spec_slot(fe->last_set, 0), (size_t)g.n, fe->d_partial, fe->partial_stride(), nb, fe->stream, e0, e1) < 0) {
+			(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+			return fail(HFDL_GPU_ERANGE, "fold variant %d does not fit this geometry (M = %d, %d rows per slice) or block count %d", variant, g.m, g.rows_per_slice, nb);
+		}
+		HIP_TRY(hipEventSynchronize(e1));
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+		if (i > 0) { sum += ms; best = std::min(best, (double)ms); }       // first launch: code load
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	HIP_TRY(hipGetLastError());
+	*avg_ms = sum / reps;
+	if (best_ms) *best_ms = best;
+	if (checksum) {
+		const size_t words = 2 * fe->partial_stride() * (size_t)nb;
+		std::vector<uint32_t> h(words);
+		HIP_TRY(hipMemcpy(h.data(), fe->d_partial, sizeof(uint32_t) * words, hipMemcpyDeviceToHost));
+		uint64_t acc = 0;
+		for (size_t i = 0; i < words; i++) acc += (uint64_t)h[i] * (uint64_t)(2 * (i % 65521) + 1);
+		*checksum = acc;
+	}
+	return 0;
+}
+#endif

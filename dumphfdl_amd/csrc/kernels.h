@@ -35,9 +35,14 @@ struct NcoState {
 struct Geometry {
 	int32_t n, m, pre, post, scrap, post_input_size, overlap, input_size, outs;
 	int32_t slices, rows_per_slice, nch;
-	// filter taps in HBM: element (channel c, alias row r, bin j) at c*tap_chan_stride + r*tap_row_stride + j  (cf32 units)
+	int32_t nch_pad;                   // channels the tap buffer holds: nch, rounded up to even for the pair-interleaved layout (the extra one all zero)
+	int32_t pair_layout;               // 1: taps stored pair-interleaved for the matrix-pipe fold (fold_kernels.hip); 0: plain rows (M not a multiple of 64)
+	// filter taps in HBM as the forward FFT writes them: element (channel c, alias row r, bin j) at c*tap_chan_stride + r*tap_row_stride + j
+	// (cf32 units; tap_row_stride = nch_pad * M); launch_tap_interleave() then reorders every row's channel pairs in place
 	int64_t tap_chan_stride, tap_row_stride;
 };
+
+constexpr int FOLD_MAX_BLOCKS = 16;         // blocks one fold launch can take (four groups of four columns of the 4x4x1 matrix instruction)
 
 // The NCO phasor table of a block, made while that block's forward FFT runs.  decimating_shift_addition_cc's phasor recurrence
 // (src/libcsdr_gpl.c:48-66) is 1792 strictly serial fp32 steps per channel at cfg3 -- 47 us for a lone lane, which used to be the
@@ -75,17 +80,20 @@ enum { SFMT_CF32 = 0, SFMT_CS16 = 1, SFMT_CU8 = 2 };
 struct FftOutLayout { int row_log = 0; int64_t row_stride = 0; };
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
 		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay = FftOutLayout(), hipEvent_t done = nullptr,
-		NcoJob nco = NcoJob());
+		NcoJob nco = NcoJob(), hipEvent_t input_read = nullptr);      // input_read: signalled when the first pass has consumed `fresh`
 // optional events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL): no separate barrier packets in the queue
 // `nb` consecutive blocks: spectra `spec_stride` cf32 apart, partial sums `partial_stride` apart; launches of at most `nb_max` blocks
 // sharing one pass over the taps.  Returns the number of kernel launches made.
 int launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial, size_t partial_stride,
 		int nb, int nb_max, hipStream_t st, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
-// measurement aid (profiles/fold_variants.py): the compiled register tilings; launch one of them on `nb` spectra
+// the compiled tilings (the laboratory build carries the sweep set, profiles/fold_variants.py); launch one of them on `nb` spectra.
+// variant -1 = the plain-VALU FMA-chain reference kernel every tiling must equal bit for bit
 int fold_variant_count();
-int fold_variant_describe(int variant, int desc[6]);            // U, R, CS, NC, NB, WV
+int fold_variant_describe(int variant, int desc[6]);            // P, Q, W, D, max blocks, 0
 int launch_fold_variant(int variant, const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial,
-		size_t partial_stride, hipStream_t st, hipEvent_t start, hipEvent_t stop);
+		size_t partial_stride, int nb, hipStream_t st, hipEvent_t start, hipEvent_t stop);
+hipError_t launch_tap_interleave(float2 *taps, const Geometry &g, hipStream_t st);            // plain rows -> pair-interleaved, in place (create time)
+void launch_tap_extract(const float2 *taps, const Geometry &g, int channel, float2 *dst, hipStream_t st);      // one channel's taps back in plain order
 hipError_t prepare_ifft_nco(int m);     // LDS attribute of the inverse-FFT kernel for this size (checked at create time)
 // `nb` blocks in one launch (grid nch x nb): partial sums, carried-state snapshots, phasor tables [outs][nch], outputs and counts of
 // consecutive blocks lie `partial_stride` / nch / `ph_stride` / nch * outs / nch apart
@@ -93,7 +101,9 @@ void launch_ifft_nco(const Geometry &g, const float2 *partial, size_t partial_st
 		size_t ph_stride, const float2 *tw_m, float2 *chan_out, int *out_count, int nb, hipStream_t st, hipEvent_t done = nullptr);
 void launch_nco_decimate(const float2 *in, int input_size, float cosdelta, float sindelta, float rate, int decimation,
 		NcoState *state, float2 *phasor_scratch, float2 *out, hipStream_t st);
+#ifdef HFDL_LAB
 int stream_read_variants();
 void launch_stream_read(int variant, const float2 *src, size_t bytes, float *sink, hipStream_t st);
+#endif
 
 }  // namespace hfdl

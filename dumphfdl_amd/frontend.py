@@ -23,7 +23,8 @@ class Geometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "sample_rate", "decimation", "pre_decimation", "post_decimation", "taps_length", "overlap_length",
         "fft_size", "fft_inv_size", "input_size", "post_input_size", "scrap", "outputs_per_block",
-        "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float), ("max_outputs_per_block", C.c_int32), ("demod_batch", C.c_int32), ("fold_batch", C.c_int32)]
+        "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float), ("max_outputs_per_block", C.c_int32), ("demod_batch", C.c_int32), ("fold_batch", C.c_int32),
+                                       ("prefetch_depth", C.c_int32)]
 
 
 class Pdu(C.Structure):
@@ -54,27 +55,37 @@ def lib_path():
     return os.environ.get("HFDL_GPU_LIB") or os.path.join(_HERE, "libhfdl_gpu.so")
 
 
-_lib = None
+def lab_lib_path():
+    return os.environ.get("HFDL_GPU_LAB_LIB") or os.path.join(_HERE, "libhfdl_gpu_lab.so")
 
+
+_lib = None
+_lab = None
+
+# every symbol include/hfdl_gpu.h declares (tests/test_host_lib_cpu.py compares this list with the header and with `nm -D`)
 EXPORTS = [
     "hfdl_gpu_plan_geometry", "hfdl_gpu_host_alloc", "hfdl_gpu_host_free",
     "hfdl_gpu_frontend_create", "hfdl_gpu_frontend_destroy", "hfdl_gpu_frontend_geometry",
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_input_done_upto", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
-    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_demod_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_stream_read_probe", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
-    "hfdl_gpu_frontend_fold_blocks", "hfdl_gpu_frontend_read_tap_block", "hfdl_gpu_frontend_push_baseband", "hfdl_gpu_fold_variant_count", "hfdl_gpu_fold_variant_describe", "hfdl_gpu_frontend_fold_variant_probe",
+    "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_demod_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
+    "hfdl_gpu_frontend_fold_blocks", "hfdl_gpu_frontend_fold_launch_shapes", "hfdl_gpu_frontend_read_tap_block", "hfdl_gpu_frontend_push_baseband", "hfdl_gpu_frontend_input_copied",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk", "hfdl_gpu_frontend_prefetch_block_raw", "hfdl_gpu_frontend_prefetch_cancel", "hfdl_gpu_psk_slice",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
 
 
+# what include/hfdl_gpu_lab.h adds in the laboratory build (libhfdl_gpu_lab.so)
+LAB_EXPORTS = ["hfdl_gpu_lab_fold_variant_count", "hfdl_gpu_lab_fold_variant_describe", "hfdl_gpu_lab_fold_variant_probe", "hfdl_gpu_lab_stream_read_probe"]
+
+
 def fold_variants():
-    """The fold kernel's compiled register tilings: [(U, R, CS, NC, NB, WV)] (measurement aid)."""
-    L = load()
+    """The compiled tilings of the matrix-pipe fold kernel in the laboratory build: [(P, Q, W, D, max blocks, 0)]."""
+    L = load_lab()
     out = []
-    for v in range(L.hfdl_gpu_fold_variant_count()):
+    for v in range(L.hfdl_gpu_lab_fold_variant_count()):
         d = (C.c_int32 * 6)()
-        _check(L.hfdl_gpu_fold_variant_describe(v, C.byref(d)))
+        _check(L.hfdl_gpu_lab_fold_variant_describe(v, C.byref(d)), L)
         out.append(tuple(d))
     return out
 
@@ -91,7 +102,30 @@ def load():
                        "(dumphfdl_amd/csrc/build.sh). There is no CPU fallback.")
     if "torch" in sys.modules:
         import torch  # noqa: F401  (already imported: make sure its HIP runtime is the one resolved)
-    L = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    _lib = _bind(C.CDLL(p, mode=C.RTLD_GLOBAL))
+    return _lib
+
+
+def load_lab():
+    """Load the laboratory build (libhfdl_gpu_lab.so: include/hfdl_gpu_lab.h on top of include/hfdl_gpu.h).  It lives beside the
+    product library in one process; Frontend(..., lib=load_lab()) binds a front end to it."""
+    global _lab
+    if _lab is not None:
+        return _lab
+    p = lab_lib_path()
+    if not os.path.exists(p):
+        raise GpuError("libhfdl_gpu_lab.so is missing: build it with dumphfdl_amd/csrc/build.sh lab")
+    if "torch" in sys.modules:
+        import torch  # noqa: F401
+    L = _bind(C.CDLL(p, mode=C.RTLD_LOCAL))
+    L.hfdl_gpu_lab_fold_variant_describe.argtypes = [C.c_int, C.POINTER(C.c_int32 * 6)]
+    L.hfdl_gpu_lab_fold_variant_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.hfdl_gpu_lab_stream_read_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    _lab = L
+    return L
+
+
+def _bind(L):
     L.hfdl_gpu_last_error.restype = C.c_char_p
     L.hfdl_gpu_frontend_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
     L.hfdl_gpu_frontend_destroy.argtypes = [C.c_void_p]
@@ -121,10 +155,9 @@ def load():
     L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_demod_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_fold_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
-    L.hfdl_gpu_fold_variant_describe.argtypes = [C.c_int, C.POINTER(C.c_int32 * 6)]
-    L.hfdl_gpu_frontend_fold_variant_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.hfdl_gpu_frontend_fold_launch_shapes.argtypes = [C.c_void_p, C.POINTER(C.c_int64 * 17)]
+    L.hfdl_gpu_frontend_input_copied.argtypes = [C.c_void_p, C.c_uint64]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
-    L.hfdl_gpu_frontend_stream_read_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.hfdl_gpu_fft_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
     L.hfdl_gpu_viterbi27.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.hfdl_gpu_burst_decode.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -138,13 +171,12 @@ def load():
     L.hfdl_gpu_psk_slice.argtypes = [C.c_int, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.hfdl_gpu_frontend_prefetch_block_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.hfdl_gpu_frontend_prefetch_cancel.argtypes = [C.c_void_p]
-    _lib = L
     return L
 
 
-def _check(rc):
+def _check(rc, L=None):
     if rc != 0:
-        raise GpuError("hfdl_gpu error %d: %s" % (rc, load().hfdl_gpu_last_error().decode(errors="replace")))
+        raise GpuError("hfdl_gpu error %d: %s" % (rc, (L or load()).hfdl_gpu_last_error().decode(errors="replace")))
 
 
 def plan_geometry(decimation, transition_bw):
@@ -177,13 +209,13 @@ class Frontend:
     Mirrors the reference wiring fft_create + N x hfdl_channel_create (src/main.c:699-755): one block of
     `geometry.input_size` samples in, PDUs out."""
 
-    def __init__(self, sample_rate, centerfreq, freqs, device=0):
-        L = load()
+    def __init__(self, sample_rate, centerfreq, freqs, device=0, lib=None):
+        L = self._L = lib or load()
         fr = np.ascontiguousarray(freqs, dtype=np.int32)
         self._h = C.c_void_p()
-        _check(L.hfdl_gpu_frontend_create(C.byref(self._h), device, sample_rate, centerfreq, _p(fr), len(fr)))
+        _check(L.hfdl_gpu_frontend_create(C.byref(self._h), device, sample_rate, centerfreq, _p(fr), len(fr)), self._L)
         self.geometry = Geometry()
-        _check(L.hfdl_gpu_frontend_geometry(self._h, C.byref(self.geometry)))
+        _check(L.hfdl_gpu_frontend_geometry(self._h, C.byref(self.geometry)), self._L)
         self.freqs = [int(f) for f in fr]
 
     @property
@@ -192,27 +224,27 @@ class Frontend:
 
     def push_block(self, samples):
         """samples: complex64 numpy array of input_size samples (host), or an int device pointer."""
-        L = load()
+        L = self._L
         if isinstance(samples, int):
-            _check(L.hfdl_gpu_frontend_push_block(self._h, C.c_void_p(samples), self.geometry.input_size, 1))
+            _check(L.hfdl_gpu_frontend_push_block(self._h, C.c_void_p(samples), self.geometry.input_size, 1), self._L)
         else:
             s = np.ascontiguousarray(samples, dtype=np.complex64)
-            _check(L.hfdl_gpu_frontend_push_block(self._h, _p(s), len(s), 0))
+            _check(L.hfdl_gpu_frontend_push_block(self._h, _p(s), len(s), 0), self._L)
             # the copy is enqueued asynchronously from pageable memory: HIP stages it before returning
 
     def push_block_raw(self, raw, sample_format):
         """raw: int16 (SFMT_CS16) / uint8 (SFMT_CU8) / float32 (SFMT_CF32) numpy array of 2*input_size interleaved I,Q values."""
         dt = {SFMT_CF32: np.float32, SFMT_CS16: np.int16, SFMT_CU8: np.uint8}[sample_format]
         r = np.ascontiguousarray(raw, dtype=dt)
-        _check(load().hfdl_gpu_frontend_push_block_raw(self._h, _p(r), len(r) // 2, sample_format, 0))
+        _check(self._L.hfdl_gpu_frontend_push_block_raw(self._h, _p(r), len(r) // 2, sample_format, 0), self._L)
 
     def channelize_block(self, samples):
-        L = load()
+        L = self._L
         if isinstance(samples, int):
-            _check(L.hfdl_gpu_frontend_channelize_block(self._h, C.c_void_p(samples), self.geometry.input_size, 1))
+            _check(L.hfdl_gpu_frontend_channelize_block(self._h, C.c_void_p(samples), self.geometry.input_size, 1), self._L)
         else:
             s = np.ascontiguousarray(samples, dtype=np.complex64)
-            _check(L.hfdl_gpu_frontend_channelize_block(self._h, _p(s), len(s), 0))
+            _check(L.hfdl_gpu_frontend_channelize_block(self._h, _p(s), len(s), 0), self._L)
 
     def push_baseband(self, per_channel):
         """per_channel: one complex64 array of channelizer OUTPUT per channel (<= max_outputs_per_block + 1 samples each): the demodulator
@@ -226,36 +258,44 @@ class Frontend:
             x = np.asarray(x, np.complex64)
             buf[c, :len(x)] = x
             cnt[c] = len(x)
-        _check(load().hfdl_gpu_frontend_push_baseband(self._h, _p(buf), _p(cnt)))
+        _check(self._L.hfdl_gpu_frontend_push_baseband(self._h, _p(buf), _p(cnt)), self._L)
 
     def push_host_ptr(self, ptr, sample_format=SFMT_CF32):
         """ptr: address of a (page-locked) host buffer holding one block; valid until input_done() / sync()."""
-        _check(load().hfdl_gpu_frontend_push_block_raw(self._h, C.c_void_p(ptr), self.geometry.input_size, sample_format, 0))
+        _check(self._L.hfdl_gpu_frontend_push_block_raw(self._h, C.c_void_p(ptr), self.geometry.input_size, sample_format, 0), self._L)
 
     def prefetch_host_ptr(self, ptr, sample_format=SFMT_CF32):
-        """Queue the copy of the block that push_host_ptr(ptr, sample_format) will push next."""
-        _check(load().hfdl_gpu_frontend_prefetch_block_raw(self._h, C.c_void_p(ptr), self.geometry.input_size, sample_format))
+        """Queue the copy of a block that push_host_ptr(ptr, sample_format) will push later (up to geometry.prefetch_depth wait this
+        way; they are pushed in the order they were prefetched)."""
+        _check(self._L.hfdl_gpu_frontend_prefetch_block_raw(self._h, C.c_void_p(ptr), self.geometry.input_size, sample_format), self._L)
 
     def prefetch_cancel(self):
-        _check(load().hfdl_gpu_frontend_prefetch_cancel(self._h))
+        _check(self._L.hfdl_gpu_frontend_prefetch_cancel(self._h), self._L)
 
     def input_done(self):
-        _check(load().hfdl_gpu_frontend_input_done(self._h))
+        _check(self._L.hfdl_gpu_frontend_input_done(self._h), self._L)
+
+    def input_copied(self, host_block):
+        """True once the upload of that host block has finished (no waiting)."""
+        rc = self._L.hfdl_gpu_frontend_input_copied(self._h, C.c_uint64(host_block))
+        if rc < 0:
+            _check(rc, self._L)
+        return bool(rc)
 
     def input_done_upto(self, host_block):
-        _check(load().hfdl_gpu_frontend_input_done_upto(self._h, C.c_uint64(host_block)))
+        _check(self._L.hfdl_gpu_frontend_input_done_upto(self._h, C.c_uint64(host_block)), self._L)
 
     def sync(self):
-        _check(load().hfdl_gpu_frontend_sync(self._h))
+        _check(self._L.hfdl_gpu_frontend_sync(self._h), self._L)
 
     def poll_pdus_raw(self, max_pdus=4096, max_in_flight=0):
         """The C structs as the library hands them over: (ctypes array of hfdl_gpu_pdu, count)."""
         buf = (Pdu * max_pdus)()
         n = C.c_int32(0)
         if max_in_flight:
-            _check(load().hfdl_gpu_frontend_poll_pdus_ready(self._h, buf, max_pdus, C.byref(n), max_in_flight))
+            _check(self._L.hfdl_gpu_frontend_poll_pdus_ready(self._h, buf, max_pdus, C.byref(n), max_in_flight), self._L)
         else:
-            _check(load().hfdl_gpu_frontend_poll_pdus(self._h, buf, max_pdus, C.byref(n)))
+            _check(self._L.hfdl_gpu_frontend_poll_pdus(self._h, buf, max_pdus, C.byref(n)), self._L)
         return buf, n.value
 
     @staticmethod
@@ -272,19 +312,21 @@ class Frontend:
         return out
 
     def poll_pdus(self, max_pdus=4096, max_in_flight=0):
-        """max_in_flight=0: everything decoded so far (drains the pipeline); 1: leave the newest block running."""
+        """max_in_flight=0: everything decoded so far (drains the pipeline); 1: nothing is drained -- the half being filled keeps
+        filling, the newest closed half keeps running, and what is known complete (the half before it) is returned: nothing until two
+        halves of geometry.fold_batch blocks were closed, and the tail only comes with a draining poll (include/hfdl_gpu.h)."""
         return self.pdus_to_dicts(*self.poll_pdus_raw(max_pdus, max_in_flight))
 
     def counters(self):
         c = FrontendCounters()
-        _check(load().hfdl_gpu_frontend_counters(self._h, C.byref(c)))
+        _check(self._L.hfdl_gpu_frontend_counters(self._h, C.byref(c)), self._L)
         return {n: getattr(c, n) for n, _ in FrontendCounters._fields_}
 
     def all_channel_stats(self):
         nch = self.geometry.channels
         buf = (ChannelStats * nch)()
         n = C.c_int32(0)
-        _check(load().hfdl_gpu_frontend_all_channel_stats(self._h, buf, nch, C.byref(n)))
+        _check(self._L.hfdl_gpu_frontend_all_channel_stats(self._h, buf, nch, C.byref(n)), self._L)
         return [{k: getattr(buf[i], k) for k, _ in ChannelStats._fields_} for i in range(n.value)]
 
     def read_tap(self, what, channel=0, back=0):
@@ -293,62 +335,70 @@ class Frontend:
         cap = 2 * g.fft_size if what in (TAP_SPECTRUM, TAP_FILTER) else 2 * (g.post_input_size + 64) * max(1, g.demod_batch)   # demodulator taps cover a launch
         buf = np.empty(cap, np.float32)
         n = C.c_size_t(0)
-        _check(load().hfdl_gpu_frontend_read_tap_block(self._h, what, channel, back, _p(buf), cap, C.byref(n)))
+        _check(self._L.hfdl_gpu_frontend_read_tap_block(self._h, what, channel, back, _p(buf), cap, C.byref(n)), self._L)
         out = buf[:n.value].copy()
         return out if what in (TAP_AGC_LEVEL, TAP_PHASE_CYCLES) else out.view(np.complex64)
 
     def enable_taps(self, enable=True):
-        _check(load().hfdl_gpu_frontend_enable_taps(self._h, int(enable)))
+        _check(self._L.hfdl_gpu_frontend_enable_taps(self._h, int(enable)), self._L)
 
     def channel_stats(self, channel):
         st = ChannelStats()
-        _check(load().hfdl_gpu_frontend_channel_stats(self._h, channel, C.byref(st)))
+        _check(self._L.hfdl_gpu_frontend_channel_stats(self._h, channel, C.byref(st)), self._L)
         return {n: getattr(st, n) for n, _ in ChannelStats._fields_}
 
     def reset_timers(self, enable=True):
-        _check(load().hfdl_gpu_frontend_reset_timers(self._h, int(enable)))
+        _check(self._L.hfdl_gpu_frontend_reset_timers(self._h, int(enable)), self._L)
 
     def fold_time_ms(self):
         ms = C.c_double(0)
         n = C.c_int64(0)
-        _check(load().hfdl_gpu_frontend_fold_time_ms(self._h, C.byref(ms), C.byref(n)))
+        _check(self._L.hfdl_gpu_frontend_fold_time_ms(self._h, C.byref(ms), C.byref(n)), self._L)
         return ms.value, n.value
 
     def fold_blocks(self):
         """Blocks covered by the timed fold launches (a launch folds up to geometry.fold_batch blocks)."""
         n = C.c_int64(0)
-        _check(load().hfdl_gpu_frontend_fold_blocks(self._h, C.byref(n)))
+        _check(self._L.hfdl_gpu_frontend_fold_blocks(self._h, C.byref(n)), self._L)
         return n.value
 
-    def fold_variant_probe(self, variant, reps=3):
-        """(avg ms, best ms, checksum of the partial sums) of `reps` launches of one compiled fold tiling (measurement aid)."""
+    def fold_launch_shapes(self):
+        """{blocks per launch: timed fold launches of that size} since reset_timers(True)."""
+        c = (C.c_int64 * 17)()
+        _check(self._L.hfdl_gpu_frontend_fold_launch_shapes(self._h, C.byref(c)), self._L)
+        return {nb: int(c[nb]) for nb in range(1, 17) if c[nb]}
+
+    def fold_variant_probe(self, variant, nb, reps=3):
+        """Laboratory build: (avg ms, best ms, checksum of the partial sums) of `reps` launches of one compiled fold tiling on `nb` blocks
+        (variant -1: the plain-VALU FMA-chain reference kernel)."""
         avg, best, chk = C.c_double(0), C.c_double(0), C.c_uint64(0)
-        _check(load().hfdl_gpu_frontend_fold_variant_probe(self._h, variant, reps, C.byref(avg), C.byref(best), C.byref(chk)))
+        _check(self._L.hfdl_gpu_lab_fold_variant_probe(self._h, variant, nb, reps, C.byref(avg), C.byref(best), C.byref(chk)), self._L)
         return avg.value, best.value, chk.value
 
     def demod_time_ms(self):
         ms = C.c_double(0)
         n = C.c_int64(0)
         nb = C.c_int64(0)
-        _check(load().hfdl_gpu_frontend_demod_time_ms(self._h, C.byref(ms), C.byref(n), C.byref(nb)))
+        _check(self._L.hfdl_gpu_frontend_demod_time_ms(self._h, C.byref(ms), C.byref(n), C.byref(nb)), self._L)
         return ms.value, n.value, nb.value
 
     def step_period_ms(self):
         v = C.c_double(0)
-        _check(load().hfdl_gpu_frontend_step_period_ms(self._h, C.byref(v)))
+        _check(self._L.hfdl_gpu_frontend_step_period_ms(self._h, C.byref(v)), self._L)
         return v.value
 
     def stream_read_probe(self):
+        """Laboratory build: GB/s a bare read-only kernel reaches over the resident filter taps."""
         v = C.c_double(0)
-        _check(load().hfdl_gpu_frontend_stream_read_probe(self._h, C.byref(v)))
+        _check(self._L.hfdl_gpu_lab_stream_read_probe(self._h, C.byref(v)), self._L)
         return v.value
 
     def stream(self):
-        return load().hfdl_gpu_frontend_stream(self._h)
+        return self._L.hfdl_gpu_frontend_stream(self._h)
 
     def close(self):
         if self._h:
-            load().hfdl_gpu_frontend_destroy(self._h)
+            self._L.hfdl_gpu_frontend_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

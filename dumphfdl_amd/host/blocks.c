@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <unistd.h>
 #include "hfdl_host.h"
+#include "hfdl_gpu.h"
 #include "host_internal.h"
 
 #define PROD_MTU_MULT 8          /* ring = max(8 x producer MTU, 2 x consumer MRU): src/block.c:15-16,62-64 */
@@ -46,12 +47,13 @@ int32_t block_connect_one2one(struct block *source, struct block *sink)
 	size_t blk = hfdl_frontend_block_samples(sink);
 	if (blk > 0) {
 		/* The consumer is the GPU front end: page-locked storage, a whole number of its blocks long, so that every block it
-		 * takes is one contiguous run it can DMA from in place (6 blocks: up to two leased to the DMA engine, four for the producer to run ahead).
+		 * takes is one contiguous run it can DMA from in place: HFDL_GPU_PREFETCH_MAX + 5 blocks -- the block being pushed, up to
+		 * HFDL_GPU_PREFETCH_MAX uploaded ahead of it (frontend.c), four for the producer to run ahead.
 		 * If the producer is the library's own file input, the ring carries the file's RAW samples (cs16 / cu8 / cf32) and the
 		 * conversion of src/input-helpers.c:33-78 happens on the device; any other producer gets the cf32 ring
 		 * complex_samples_produce() expects. */
 		size_t nblk = (cap + blk - 1) / blk;
-		if (nblk < 6) nblk = 6;
+		if (nblk < HFDL_GPU_PREFETCH_MAX + 5) nblk = HFDL_GPU_PREFETCH_MAX + 5;
 		c->circ_buffer.buf = hfdl_ring_create_ex(nblk * blk, hfdl_file_input_raw_format(source), 1);
 	} else {
 		c->circ_buffer.buf = hfdl_ring_create(cap);

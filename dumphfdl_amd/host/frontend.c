@@ -238,9 +238,45 @@ static int gpu_format_of(int ring_fmt)
 	return ring_fmt == SFMT_CS16 ? HFDL_GPU_SFMT_CS16 : ring_fmt == SFMT_CU8 ? HFDL_GPU_SFMT_CU8 : HFDL_GPU_SFMT_CF32;
 }
 
+/* give ring slots back to the producer, oldest first, as the DMA engine finishes reading them.  wait_for_one: block until at least
+ * the oldest copy is done (the caller is about to sleep and the producer may be waiting for room); otherwise only what is done
+ * already.  Returns 0, or -1 if the state of a copy cannot be established (the slot is kept: the producer must never overwrite
+ * memory the DMA engine may still read). */
+static int release_copied(hfdl_gpu_frontend *fe, struct circ_buffer *ring, size_t need, uint64_t uploads, size_t *leased, bool wait_for_one)
+{
+	while (*leased > 0) {
+		const uint64_t oldest = uploads - *leased;
+		if (wait_for_one) {
+			if (hfdl_gpu_frontend_input_done_upto(fe, oldest) != 0 && hfdl_gpu_frontend_input_done(fe) != 0) return -1;
+			wait_for_one = false;
+		} else {
+			const int done = hfdl_gpu_frontend_input_copied(fe, oldest);
+			if (done < 0) return -1;
+			if (done == 0) break;
+		}
+		pthread_mutex_lock(ring->mutex);
+		hfdl_ring_drop(ring->buf, need);
+		pthread_mutex_unlock(ring->mutex);
+		pthread_cond_signal(ring->cond);
+		(*leased)--;
+	}
+	return 0;
+}
+
 /* The front-end thread.  A block never gets copied on the host: the ring in front of this block is page-locked and a whole
  * number of blocks long (block_connect_one2one), so each block is handed to the GPU where it lies -- raw cs16 / cu8 samples
- * included, which the device converts -- and its slot goes back to the producer once the DMA has read it. */
+ * included, which the device converts -- and its slot goes back to the producer once the DMA has read it.
+ *
+ * Uploads run AHEAD of the blocks that compute: whatever whole blocks the ring holds beyond the one being pushed are queued for
+ * upload at once (hfdl_gpu_frontend_prefetch_block_raw, up to geometry.prefetch_depth of them), so the copy engine keeps working
+ * while this thread waits for the GPU in the collection call -- the fold of a 40 Msps x 256-channel half takes 3 ms, five blocks
+ * of PCIe time.
+ *
+ * Live source or replay?  The pipeline is drained (everything pushed so far folded, demodulated and delivered at once) only when
+ * the ring has run EMPTY and the source has stayed silent for a grace period of a quarter of a block's own duration (at most
+ * 20 ms): a live radio delivers a block every block duration and gets its PDUs within that grace; a file reader that hiccups for
+ * a millisecond beside a GPU about as fast as itself never drains a filled pipeline (round 4's fixed 0.5 ms grace did, five times
+ * in a run, for 19 % of the rate). */
 static void *frontend_thread(void *ctx)
 {
 	struct block *block = ctx;
@@ -273,122 +309,149 @@ static void *frontend_thread(void *ctx)
 	const size_t need = ok ? (size_t)fb->geo.input_size : 1;
 	const size_t elem = hfdl_ring_elem_size(ring->buf);
 	const int gfmt = gpu_format_of(hfdl_ring_format(ring->buf));
+	/* uploads ahead of the pushes: what the library allows, and what the ring can hold beside the block being pushed and room for
+	 * the producer to write into */
+	size_t depth = 0;
+	if (ok) {
+		const size_t ring_blocks = hfdl_ring_capacity(ring->buf) / need;
+		depth = (size_t)fb->geo.prefetch_depth;
+		if (depth > HFDL_GPU_PREFETCH_MAX) depth = HFDL_GPU_PREFETCH_MAX;
+		if (ring_blocks < 4) depth = 0; else if (depth > ring_blocks - 3) depth = ring_blocks - 3;
+	}
+	double grace = ok ? 0.25 * (double)need / (double)slots[0]->sample_rate : 0.0;
+	if (grace > 0.020) grace = 0.020;
+	if (grace < 0.0005) grace = 0.0005;
 	uint64_t k = 0, npdus = 0;
 	double t_first = 0, t_last = 0, t_published = 0;
 	double s_wait = 0, s_push = 0, s_poll = 0, s_release = 0, s_grace = 0;      /* where this thread's time went (seconds) */
 	uint64_t drains = 0;
-	size_t leased = 0;                       /* ring slots the GPU may still read (0..3), oldest first: pushed blocks, then a prefetched one */
-	bool prefetched = false;                 /* the newest leased slot has been uploaded ahead (prefetch) but not pushed yet */
+	size_t leased = 0;                       /* ring slots the DMA engine may still read: the newest `leased` uploads, oldest at the ring's head */
 	uint64_t uploads = 0;                    /* host blocks whose copy has been queued, as the GPU library numbers them */
+	const void *queued[HFDL_GPU_PREFETCH_MAX + 1];      /* uploads not pushed yet, oldest at q_head */
+	size_t q_head = 0, q_len = 0;
+	uint64_t undelivered = 0;                /* blocks pushed since the pipeline was last drained */
 	for (;;) {
 		const double tw0 = now_s();
-		const size_t pushed_leases = leased - (prefetched ? 1 : 0);
-		pthread_mutex_lock(ring->mutex);
-		/* shutdown is honoured only when there is not a whole block left, so buffered samples are flushed (src/fft.c:39-48) */
-		while (hfdl_ring_size(ring->buf) < (pushed_leases + 1) * need) {
-			if (block_connection_is_shutdown_signaled(block->consumer.in)) { pthread_mutex_unlock(ring->mutex); goto shutdown; }
-			pthread_cond_wait(ring->cond, ring->mutex);
-		}
-		const void *blk = ok ? hfdl_ring_peek(ring->buf, pushed_leases * need, need) : NULL;
-		if (ok && blk == NULL) {
-			/* a block that wraps around the end of a ring this library did not size: one copy.  The blocks still leased
-			 * to the DMA engine sit in front of it; they go back to the producer first.  (Never with a prefetch pending: a
-			 * prefetched block was peeked as one contiguous run.) */
-			while (leased > 0) {
+		const void *blk = NULL;
+		bool from_bounce = false;
+		if (q_len > 0) {
+			blk = queued[q_head];            /* uploaded ahead: only its kernels remain to be queued */
+		} else {
+			bool waited_grace = false;
+			pthread_mutex_lock(ring->mutex);
+			/* shutdown is honoured only when there is not a whole block left, so buffered samples are flushed (src/fft.c:39-48) */
+			while (hfdl_ring_size(ring->buf) < (leased + 1) * need) {
+				if (block_connection_is_shutdown_signaled(block->consumer.in)) { pthread_mutex_unlock(ring->mutex); goto shutdown; }
+				if (ok && leased > 0) {
+					/* the producer may be out of room: slots whose upload is done go back before this thread sleeps */
+					pthread_mutex_unlock(ring->mutex);
+					const double tr = now_s();
+					if (release_copied(fe, ring, need, uploads, &leased, true) != 0) {
+						fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
+						do_exit = 1;
+						ok = 0;
+					}
+					s_release += now_s() - tr;
+					pthread_mutex_lock(ring->mutex);
+					continue;
+				}
+				if (ok && undelivered > 0 && !waited_grace) {
+					/* the ring is empty: a live source, or a reader catching its breath?  Wait the grace period, then deliver */
+					struct timespec until;
+					clock_gettime(CLOCK_REALTIME, &until);
+					until.tv_nsec += (long)(grace * 1e9);
+					while (until.tv_nsec >= 1000000000) { until.tv_sec++; until.tv_nsec -= 1000000000; }
+					const double tg = now_s();
+					int rc = 0;
+					while (rc == 0 && hfdl_ring_size(ring->buf) < (leased + 1) * need && !block_connection_is_shutdown_signaled(block->consumer.in))
+						rc = pthread_cond_timedwait(ring->cond, ring->mutex, &until);
+					s_grace += now_s() - tg;
+					waited_grace = true;
+					if (hfdl_ring_size(ring->buf) >= (leased + 1) * need || block_connection_is_shutdown_signaled(block->consumer.in)) continue;
+					pthread_mutex_unlock(ring->mutex);
+					int32_t n = 0;
+					do {                     /* draining collection: the half being filled is closed as it is */
+						if (hfdl_gpu_frontend_poll_pdus(fe, pdus, max_pdus, &n) != 0) break;
+						for (int32_t i = 0; i < n; i++) push_pdu(&pdus[i], &t0);
+						npdus += (uint64_t)n;
+					} while (n == max_pdus);
+					drains++;
+					undelivered = 0;
+					pthread_mutex_lock(ring->mutex);
+					continue;
+				}
+				pthread_cond_wait(ring->cond, ring->mutex);
+			}
+			blk = ok ? hfdl_ring_peek(ring->buf, leased * need, need) : NULL;
+			if (ok && blk == NULL) {
+				/* a block that wraps around the end of a ring this library did not size: one copy.  The blocks still leased
+				 * to the DMA engine sit in front of it; they go back to the producer first. */
 				pthread_mutex_unlock(ring->mutex);
-				/* a slot goes back only when the DMA engine is known to be done with it; if that cannot be established, wait for
-				 * every copy instead of handing the producer memory that may still be read */
-				if (hfdl_gpu_frontend_input_done_upto(fe, uploads - leased) != 0 && hfdl_gpu_frontend_input_done(fe) != 0) {
-					fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
+				while (ok && leased > 0)
+					if (release_copied(fe, ring, need, uploads, &leased, true) != 0) {
+						fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
+						do_exit = 1;
+						ok = 0;
+					}
+				pthread_mutex_lock(ring->mutex);
+				if (ok && bounce == NULL) bounce = hfdl_xcalloc(need, sizeof(float complex));
+				if (ok && hfdl_ring_read(ring->buf, bounce, need) != need) {      /* only a cf32 ring can be copied out of */
+					fprintf(stderr, "GPU front end: input ring holds raw samples in blocks that are not contiguous\n");
 					do_exit = 1;
 					ok = 0;
 				}
-				pthread_mutex_lock(ring->mutex);
-				if (!ok) break;
-				hfdl_ring_drop(ring->buf, need);
-				leased--;
+				blk = bounce;
+				from_bounce = true;
 			}
-			if (ok && bounce == NULL) bounce = hfdl_xcalloc(need, sizeof(float complex));
-			if (ok && hfdl_ring_read(ring->buf, bounce, need) != need) {      /* only a cf32 ring can be copied out of */
-				fprintf(stderr, "GPU front end: input ring holds raw samples in blocks that are not contiguous\n");
-				do_exit = 1;
-				ok = 0;
-			}
+			if (!ok) hfdl_ring_drop(ring->buf, hfdl_ring_size(ring->buf));
+			pthread_mutex_unlock(ring->mutex);
+			if (!ok) { pthread_cond_signal(ring->cond); continue; }
 		}
-		if (!ok) hfdl_ring_drop(ring->buf, hfdl_ring_size(ring->buf));
-		/* another whole block is already waiting behind this one: we are behind the source */
-		const bool backlog = hfdl_ring_size(ring->buf) >= (pushed_leases + 2) * need || (blk == NULL && hfdl_ring_size(ring->buf) >= need);
-		const void *next = (ok && blk != NULL && backlog) ? hfdl_ring_peek(ring->buf, (pushed_leases + 1) * need, need) : NULL;
-		pthread_mutex_unlock(ring->mutex);
-		if (!ok) continue;
 		const double tw1 = now_s();
 		if (k == 0) t_first = tw1; else s_wait += tw1 - tw0;
-		if (hfdl_gpu_frontend_push_block_raw(fe, blk ? blk : bounce, need, blk ? gfmt : HFDL_GPU_SFMT_CF32, 0) != 0) {
+		if (hfdl_gpu_frontend_push_block_raw(fe, blk, need, from_bounce ? HFDL_GPU_SFMT_CF32 : gfmt, 0) != 0) {
 			fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
 			do_exit = 1;
 			ok = 0;
+			/* nothing of ours may stay with the DMA engine: let the queued copies finish, then give every slot back */
+			(void)hfdl_gpu_frontend_prefetch_cancel(fe);
+			(void)hfdl_gpu_frontend_input_done(fe);
 			leased = 0;
-			prefetched = false;
+			q_len = 0;
 			continue;
 		}
 		k++;
-		if (prefetched) prefetched = false;      /* its slot was leased when the copy was queued */
-		else { uploads++; if (blk != NULL) leased++; }
-		/* Behind the source: queue the upload of the FOLLOWING block now, so that it runs beside the blocks still computing
-		 * instead of at the head of that block's own copy -> channelizer -> demodulator chain (on small geometries that chain
-		 * is longer than one demodulator, and with two blocks in flight the GPU would idle on it). */
-		if (next != NULL && hfdl_gpu_frontend_prefetch_block_raw(fe, next, need, gfmt) == 0) { prefetched = true; uploads++; leased++; }
+		undelivered++;
+		if (q_len > 0) { q_head = (q_head + 1) % (HFDL_GPU_PREFETCH_MAX + 1); q_len--; }       /* its slot was leased when the copy was queued */
+		else { uploads++; if (!from_bounce) leased++; }
+		/* queue the uploads of every further whole block the ring holds already: they run beside the blocks still computing */
+		while (!from_bounce && q_len < depth) {
+			pthread_mutex_lock(ring->mutex);
+			const void *next = hfdl_ring_size(ring->buf) >= (leased + 1) * need ? hfdl_ring_peek(ring->buf, leased * need, need) : NULL;
+			pthread_mutex_unlock(ring->mutex);
+			if (next == NULL || hfdl_gpu_frontend_prefetch_block_raw(fe, next, need, gfmt) != 0) break;
+			queued[(q_head + q_len) % (HFDL_GPU_PREFETCH_MAX + 1)] = next;
+			q_len++;
+			uploads++;
+			leased++;
+		}
 		const double tw2 = now_s();
 		s_push += tw2 - tw1;
-		/* Keeping up with the source (live radio): wait for this block and deliver its PDUs at once.  Behind (file
-		 * replay, catching up): leave it running and collect the previous block (or batch of blocks), so the producer's reads
-		 * and the copy of this block overlap it. */
-		/* "Keeping up" is only believed after a moment's grace: a source that delivers the next block a few hundred microseconds
-		 * late (a file reader that is about as fast as the GPU) is not a live radio, and draining the pipeline for it would idle
-		 * the GPU for a whole block (or batch of blocks) every time.  A live source sends a block every ~0.1 s: the grace costs it
-		 * half a millisecond of latency. */
-		bool behind = backlog;
-		if (!behind && blk != NULL) {
-			const size_t held = leased - (prefetched ? 1 : 0);          /* pushed blocks still in the ring, this one included */
-			struct timespec until;
-			clock_gettime(CLOCK_REALTIME, &until);
-			until.tv_nsec += 500000;
-			if (until.tv_nsec >= 1000000000) { until.tv_sec++; until.tv_nsec -= 1000000000; }
-			pthread_mutex_lock(ring->mutex);
-			while (hfdl_ring_size(ring->buf) < (held + 1) * need && !block_connection_is_shutdown_signaled(block->consumer.in)) {
-				if (pthread_cond_timedwait(ring->cond, ring->mutex, &until) != 0) break;
-			}
-			behind = hfdl_ring_size(ring->buf) >= (held + 1) * need;
-			pthread_mutex_unlock(ring->mutex);
-			s_grace += now_s() - tw2;
-		}
-		if (!behind) drains++;
+		/* collect what is known to be complete without draining anything: the call waits for the demodulators of the half before
+		 * the newest closed one -- that is the flow control -- while the queued uploads keep the link busy */
 		int32_t n = 0;
 		do {
-			if (hfdl_gpu_frontend_poll_pdus_ready(fe, pdus, max_pdus, &n, behind ? 1 : 0) != 0) break;
+			if (hfdl_gpu_frontend_poll_pdus_ready(fe, pdus, max_pdus, &n, 1) != 0) break;
 			for (int32_t i = 0; i < n; i++) push_pdu(&pdus[i], &t0);
 			npdus += (uint64_t)n;
 		} while (n == max_pdus);
 		const double tw3 = now_s();
 		s_poll += tw3 - tw2;
-		/* Ring slots go back to the producer when the DMA engine has read them.  With a backlog the copies of the block just
-		 * pushed and of the prefetched one are NOT waited for -- only older ones (done long ago), so the copy engine never
-		 * idles on this thread; without a backlog the pipeline was drained above and everything is free. */
-		const size_t keep = behind ? (prefetched ? 2u : 1u) : 0u;
-		while (leased > keep) {
-			/* the oldest leased block, as the GPU library numbers host blocks; on failure fall back to waiting for every copy, and
-			 * stop (slot kept) if even that fails: the producer must never overwrite memory the DMA engine may still read */
-			if (hfdl_gpu_frontend_input_done_upto(fe, uploads - leased) != 0 && hfdl_gpu_frontend_input_done(fe) != 0) {
-				fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
-				do_exit = 1;
-				ok = 0;
-				break;
-			}
-			pthread_mutex_lock(ring->mutex);
-			hfdl_ring_drop(ring->buf, need);
-			pthread_mutex_unlock(ring->mutex);
-			pthread_cond_signal(ring->cond);
-			leased--;
+		/* ring slots whose upload has finished go back to the producer; nothing is waited for here */
+		if (release_copied(fe, ring, need, uploads, &leased, false) != 0) {
+			fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());
+			do_exit = 1;
+			ok = 0;
 		}
 		s_release += now_s() - tw3;
 		/* the StatsD counters / gauges are read from the device every 50 ms of wall time at most: one strided device read per

@@ -70,15 +70,29 @@ typedef struct {
 	int32_t max_outputs_per_block;   /* ceil(post_input_size / post_decimation): what a block can emit when the carried
 	                                    decimation remainder is non-zero (post_input_size not a multiple of post_decimation);
 	                                    size HFDL_GPU_TAP_CHAN_OUT buffers from this */
-	int32_t demod_batch;             /* blocks one demodulator launch takes when they are pushed faster than they are collected (1 where the
-	                                    channelizer bounds the block; up to 8 on the small, demodulator-bound geometries).  Results do not
-	                                    depend on it; a poll / sync always demodulates what has been pushed.  0 from hfdl_gpu_plan_geometry() */
+	int32_t demod_batch;             /* blocks one demodulator launch takes when they are pushed faster than they are collected (up to one second
+	                                    of signal, cut down to what fits the LDS: 2 at 40 Msps, up to 8 on the small geometries).  Results do not
+	                                    depend on it; a poll / sync always demodulates what has been pushed.  HFDL_GPU_DEMOD_BATCH=1..8 overrides
+	                                    the default at create time.  0 from hfdl_gpu_plan_geometry() */
 	int32_t fold_batch;              /* blocks whose spectra one fold launch multiplies against ONE pass over the per-channel filter taps when
 	                                    they are pushed faster than they are collected (src/fastddc.c:123-150 run for that many blocks; the taps are
 	                                    > 99 % of a block's bytes on the 256-channel geometries).  Every block's result is bit-identical to a launch
-	                                    of its own; a poll / sync always folds what has been pushed.  HFDL_GPU_FOLD_BATCH=1..8 overrides the default
-	                                    of 8 at create time.  0 from hfdl_gpu_plan_geometry() */
+	                                    of its own; a poll / sync always folds what has been pushed.  HFDL_GPU_FOLD_BATCH=1..16 overrides the default
+	                                    of 16 at create time.  0 from hfdl_gpu_plan_geometry() */
+	int32_t prefetch_depth;          /* host blocks whose upload hfdl_gpu_frontend_prefetch_block_raw() may queue ahead of their push
+	                                    (fold_batch + 1: a staging ring of fold_batch + 2 buffers in HBM); at most HFDL_GPU_PREFETCH_MAX.
+	                                    0 from hfdl_gpu_plan_geometry() */
 } hfdl_gpu_geometry;
+#define HFDL_GPU_PREFETCH_MAX 17
+
+/* Create-time configuration read from the environment by hfdl_gpu_frontend_create() (every create reads it afresh; nothing is cached):
+ *   HFDL_GPU_FOLD_BATCH   1..16  blocks per fold launch (geometry.fold_batch)
+ *   HFDL_GPU_DEMOD_BATCH  1..8   blocks per demodulator launch (geometry.demod_batch)
+ *   HFDL_GPU_HOST_THREADS >= 1   host threads that design the filter taps (default: one per core; set to cores / processes when several
+ *                                front ends are created at once on one host)
+ *   HFDL_GPU_PDU_RING     >= 1   capacity of the device PDU ring (default max(4096, 64 per channel))
+ * The A/B switches of the measurement scripts (stream placement, tiling sweeps, probes) are in the laboratory build only:
+ * include/hfdl_gpu_lab.h, libhfdl_gpu_lab.so. */
 
 /* one decoded PDU: what dispatch_pdu() hands to pdu_decoder_queue_push (src/hfdl.c:1058-1080,
  * struct hfdl_pdu_metadata src/pdu.h:8-17).  The wall-clock rx_timestamp of the reference is
@@ -126,8 +140,8 @@ int  hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_geometry *
  * FFT is queued at once; fold, inverse FFT, demodulator and burst decoder follow when geometry.fold_batch blocks are waiting or the
  * caller syncs / polls, whichever comes first (the results do not depend on which).
  * on_device != 0: `iq` is a device pointer that stays valid until the next sync.
- * on_device == 0: the host -> device copy runs on its own stream into one of two staging buffers, so the copy of block
- *   k+1 overlaps the kernels of block k.  A buffer from hfdl_gpu_host_alloc() (page-locked) is read by DMA after the call
+ * on_device == 0: the host -> device copy runs on its own stream into a ring of fold_batch + 2 staging buffers, so the copies
+ *   run up to a whole fold batch ahead of the kernels.  A buffer from hfdl_gpu_host_alloc() (page-locked) is read by DMA after the call
  *   returns: reuse it only after hfdl_gpu_frontend_input_done() / _sync() / _poll_pdus().  Any other host buffer (pageable,
  *   or registered by the caller) is waited for inside the call and may be reused as soon as it returns. */
 int  hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);
@@ -137,16 +151,18 @@ int  hfdl_gpu_frontend_input_done(hfdl_gpu_frontend *fe);
  * waiting for the blocks pushed after it: a caller that leases two page-locked buffers pushes block k+1, then waits for block k and
  * reuses its buffer -- the copy engine never idles on the host thread */
 int  hfdl_gpu_frontend_input_done_upto(hfdl_gpu_frontend *fe, uint64_t host_block);
-/* Queue the host -> device copy of the block that will be pushed NEXT (a buffer from hfdl_gpu_host_alloc(), host pointer) without
- * pushing it: the copy then runs beside the blocks still computing, and the following hfdl_gpu_frontend_push_block_raw() of the
- * same pointer and format only queues kernels.  On small geometries (7 MB blocks) copy + channelizer of a block take longer than
- * one demodulator; with the copy taken off that chain two blocks in flight keep the GPU busy.  The prefetched block counts as a
- * host block for hfdl_gpu_frontend_input_done_upto() from this call on.  One block at a time; pushing anything else next is EINVAL. */
+/* the same question without waiting: 1 = the copy of that host block has finished, 0 = not yet, negative = error */
+int  hfdl_gpu_frontend_input_copied(hfdl_gpu_frontend *fe, uint64_t host_block);
+/* Queue the host -> device copy of a block that will be pushed LATER (a buffer from hfdl_gpu_host_alloc(), host pointer) without
+ * pushing it: the copy then runs beside the blocks still computing -- the fold of a 40 Msps x 256-channel half takes 3 ms, five blocks
+ * of PCIe time -- and the following hfdl_gpu_frontend_push_block_raw() of the same pointer and format only queues kernels.  Up to
+ * geometry.prefetch_depth blocks may wait this way (HFDL_GPU_ERANGE beyond); they must be pushed in the order they were prefetched.
+ * A prefetched block counts as a host block for hfdl_gpu_frontend_input_done_upto() from this call on. */
 int  hfdl_gpu_frontend_prefetch_block_raw(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int sample_format);
-/* Forget the prefetched block (a caller that hit an error between the prefetch and its push): waits for the copy, after which the
- * buffer is the caller's again and any block may be pushed next.  The block keeps its host block number.  No-op without a prefetch.
- * While a prefetch is pending, a push of anything but the prefetched block -- another pointer, another format, a device block --
- * is HFDL_GPU_EINVAL and leaves the prefetch in place. */
+/* Forget the prefetched blocks (a caller that hit an error between a prefetch and its push): waits for the copies, after which the
+ * buffers are the caller's again and any block may be pushed next.  The blocks keep their host block numbers.  No-op without a prefetch.
+ * While a prefetch is pending, a push of anything but the oldest prefetched block -- another pointer, another format, a device block --
+ * is HFDL_GPU_EINVAL and leaves the queue in place. */
 int  hfdl_gpu_frontend_prefetch_cancel(hfdl_gpu_frontend *fe);
 /* Same, for raw recorder / SDR samples converted on the device inside the overlap-assembly load of the forward FFT
  * (convert_cs16 / convert_cu8 / convert_cf32, src/input-helpers.c:10-78): interleaved I,Q int16 (full scale 32767.5),
@@ -238,13 +254,9 @@ int  hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what, int32_t c
  * blocks: hfdl_gpu_frontend_fold_blocks() = the blocks the timed launches covered */
 int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
 int  hfdl_gpu_frontend_fold_blocks(hfdl_gpu_frontend *fe, int64_t *blocks);
-/* measurement aids (profiles/fold_variants.py): the register tilings of the fold kernel compiled into the library --
- * desc = { float4 per thread and row, rows per trip, column split, channels per thread, blocks per launch, waves over channels } -- and `reps` timed
- * launches of one of them over the front end's resident taps and the spectra of its last blocks; *checksum sums the bit patterns
- * of the partial sums (equal for bit-identical tilings of the same block count) */
-int  hfdl_gpu_fold_variant_count(void);
-int  hfdl_gpu_fold_variant_describe(int variant, int32_t desc[6]);
-int  hfdl_gpu_frontend_fold_variant_probe(hfdl_gpu_frontend *fe, int variant, int reps, double *avg_ms, double *best_ms, uint64_t *checksum);
+/* timed fold launches by block count: counts[nb] = launches that folded nb blocks (nb = 1 .. 16; counts[0] unused) since the timers
+ * were reset -- what a caller needs to price the launches it timed (a launch of 4 blocks moves other bytes than one of 16) */
+int  hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[17]);
 int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
 /* the same for the demodulator kernel (the kernel that bounds the small geometries), from its dispatch's own start / stop events;
  * *blocks = the blocks those launches covered (a launch takes up to geometry.demod_batch blocks) */
@@ -252,9 +264,6 @@ int  hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, in
 /* steady-state period of one block: (start of the last timed fold launch - start of the first) / (blocks folded by all timed launches
  * but the last), free of the pipeline fill before the first block and the demodulator / burst-decoder drain after the last */
 int  hfdl_gpu_frontend_step_period_ms(hfdl_gpu_frontend *fe, double *period_ms);
-/* what the board's HBM delivers to a read-only streaming kernel with the fold's access pattern (reads the resident taps) */
-int  hfdl_gpu_frontend_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_per_s);
-
 /* ---- stage-level entry points (host pointers; allocate / copy / free internally) ---- */
 
 /* out[(k + n/2) mod n] = sum_t in[t] e^{-2 pi i k t / n} when shifted != 0 (plain order otherwise); n = power of two >= 512 */

@@ -30,7 +30,7 @@ def main(db_path, title):
         name = r[0].split("(")[0].replace("void ", "")
         gbs = ""
         frac = ""
-        if "fft_pass" in name and fft_points:
+        if ("fft_pass" in name or "fft_rpass" in name) and fft_points:
             b = 16.0 * fft_points
             gbs = "%.0f" % (b / (r[4] * 1e-6) / 1e9)
             frac = "%.2f" % (b / (r[4] * 1e-6) / 1e9 / 8000.0)

@@ -19,11 +19,10 @@ def test_algorithmic_bytes_per_launch_restates_the_per_block_model():
     assert b8 < 8 * bench.alg_bytes_per_block(G) / 7.7
 
 
-def test_launch_shapes_of_a_timed_region():
-    assert bench.fold_launch_shapes(20, 8) == [8, 8, 4]              # the driver's --steps 20
-    assert bench.fold_launch_shapes(256, 8) == [8] * 32
-    assert bench.fold_launch_shapes(39, 8) == [8, 8, 8, 8, 4, 2, 1]  # the PMC pass: every shape once
-    assert bench.fold_launch_shapes(7, 4) == [4, 2, 1] and bench.fold_launch_shapes(3, 1) == [1, 1, 1]
+def test_algorithmic_bytes_at_sixteen_blocks_per_launch():
+    b16 = bench.alg_bytes_per_launch(G, 16)
+    assert b16 == 8 * 16 * G.input_size + 256 * 8 * G.fft_size + 256 * 8 * 16 * 1792 == 18_178_113_536   # the taps ONCE for 16 blocks
+    assert b16 < 16 * bench.alg_bytes_per_block(G) / 15.1
 
 
 def test_stale_traffic_is_withheld(tmp_path, monkeypatch):
@@ -51,9 +50,9 @@ def test_committed_traffic_records_match_the_committed_kernels():
         assert rec["csrc_sha16"] == bench.csrc_hash(), \
             "%s: dumphfdl_amd/csrc changed since profiles/fold_traffic_%s.json was measured -- commit, run profiles/stamp.sh, then " \
             "`gpurun -- bash profiles/pmc_passes.sh %s gpurun_out/final <commit>` and copy the record into profiles/" % (wl, wl, wl)
-        assert set(rec["per_shape"]) >= {"8", "4"}
+        assert set(rec["per_shape"]) >= {"16", "4"}            # the driver's --steps 20 = 16 + 4
     r3 = json.load(open(os.path.join(bench.ROOT, "profiles", "fold_traffic_cfg3.json")))
-    assert r3["per_shape"]["8"]["traffic_over_algorithmic"] <= 1.05           # no wasted re-reads on the roofline kernel
+    assert r3["per_shape"]["16"]["traffic_over_algorithmic"] <= 1.05          # no wasted re-reads on the roofline kernel
 
 
 def test_xcd_aware_tile_placement_is_a_bijection():

@@ -32,7 +32,7 @@ def test_fft_forward_full_size_8mi(gpu):
     assert int(np.argmax(np.abs(spec))) == k and abs(abs(spec[k]) / n - 1) < 1e-4
 
 
-@pytest.mark.parametrize("n", [512, 2048, 32768, 1 << 20])
+@pytest.mark.parametrize("n", [512, 2048, 32768, 1 << 18, 1 << 19, 1 << 20, 1 << 22])
 @pytest.mark.parametrize("shifted", [False, True])
 def test_fft_forward_vs_float64(gpu, n, shifted):
     rng = np.random.default_rng(n)
@@ -737,10 +737,11 @@ def test_collect_without_draining_the_pipeline(gpu, oracle, monkeypatch, ring):
 
 
 def test_prefetched_uploads_same_pdus(gpu, oracle):
-    """hfdl_gpu_frontend_prefetch_block_raw: the upload of block k+1 is queued while block k is pushed (page-locked buffer,
-    cs16 converted on the device), slots are released through input_done_upto() with three host blocks outstanding.  Same
-    PDUs as the oracle fed the same quantised samples; misuse (another pointer pushed after a prefetch, a second prefetch, a
-    buffer that is not page-locked) is EINVAL and leaves the front end usable."""
+    """hfdl_gpu_frontend_prefetch_block_raw: uploads are queued up to geometry.prefetch_depth blocks ahead of their pushes (page-locked
+    buffer, cs16 converted on the device, a ring of fold_batch + 2 staging buffers in HBM), at every distance from 0 (pushed without a
+    prefetch) to the full depth; slots are released through input_done_upto() / input_copied().  Same PDUs as the oracle fed the same
+    quantised samples; misuse (a block other than the oldest prefetched one pushed, one prefetch too many, a buffer that is not
+    page-locked) is refused and leaves the front end usable."""
     import ctypes
     fs, cf = 250000, 10_000_000
     freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000]
@@ -753,33 +754,41 @@ def test_prefetched_uploads_same_pdus(gpu, oracle):
     ora = oracle.Frontend(fs, cf, freqs)
     n = fe.input_size
     nb = len(x) // n
+    depth = fe.geometry.prefetch_depth
+    assert depth == fe.geometry.fold_batch + 1 and nb > 3 * depth
     hbuf = gpu.host_alloc(raw.nbytes)
     ctypes.memmove(hbuf, raw.ctypes.data, raw.nbytes)
     ptr = lambda b: hbuf + 4 * b * n
     got = []
-    fe.prefetch_host_ptr(ptr(0), F.SFMT_CS16)
+    for b in range(depth):
+        fe.prefetch_host_ptr(ptr(b), F.SFMT_CS16)
     with pytest.raises(gpu.GpuError):
-        fe.prefetch_host_ptr(ptr(1), F.SFMT_CS16)                       # one at a time
+        fe.prefetch_host_ptr(ptr(depth), F.SFMT_CS16)                   # one too many
     with pytest.raises(gpu.GpuError):
-        fe.push_host_ptr(ptr(1), F.SFMT_CS16)                           # not the prefetched block
+        fe.push_host_ptr(ptr(1), F.SFMT_CS16)                           # not the OLDEST prefetched block
     dev_blk = np.zeros(n, np.complex64)
     with pytest.raises(gpu.GpuError):
-        fe.push_block(dev_blk)                                          # nor anything else while the prefetch is pending ...
-    fe.prefetch_cancel()                                                # ... until it is cancelled: the front end takes any block again
+        fe.push_block(dev_blk)                                          # nor anything else while prefetches are pending ...
+    fe.prefetch_cancel()                                                # ... until they are cancelled: the front end takes any block again
     fe.prefetch_cancel()                                                # (no-op without a prefetch)
-    fe.input_done_upto(0)                                               # the cancelled block kept its number: answers at once
-    fe.prefetch_host_ptr(ptr(0), F.SFMT_CS16)                           # host block 1 from here on
+    fe.input_done_upto(depth - 1)                                       # the cancelled blocks kept their numbers: answers at once
+    assert fe.input_copied(0) and fe.input_copied(depth - 1)
+    base, q = depth, 0                                                  # stream block b is host block base + b from here on
     for b in range(nb):
-        fe.push_host_ptr(ptr(b), F.SFMT_CS16)
-        if b + 1 < nb:
-            fe.prefetch_host_ptr(ptr(b + 1), F.SFMT_CS16)
+        ahead = (b * 7) % (depth + 1)                                   # 0 .. depth uploads queued ahead of this push
+        while q < nb and q - b < ahead:
+            fe.prefetch_host_ptr(ptr(q), F.SFMT_CS16)
+            q += 1
+        fe.push_host_ptr(ptr(b), F.SFMT_CS16)                           # the oldest prefetched block, or (ahead == 0) a block uploaded now
+        q = max(q, b + 1)
         if b >= 1:
-            fe.input_done_upto(b)                                       # (host block b = stream block b-1, after the cancelled one) three outstanding
+            fe.input_done_upto(base + b - 1)
+            assert fe.input_copied(base + b - 1)
         got += fe.poll_pdus(max_in_flight=1)
         ora.push_block(xq[b * n:(b + 1) * n])
     got += fe.poll_pdus()
     with pytest.raises(gpu.GpuError):
-        fe.input_done_upto(nb + 1)                                      # never uploaded
+        fe.input_done_upto(base + nb + 1)                               # never uploaded
     fe.input_done_upto(0)                                               # long overwritten events: still answers
     pageable = np.zeros(2 * n, np.int16)
     with pytest.raises(gpu.GpuError):
@@ -886,13 +895,14 @@ def test_demodulator_stage_fed_with_the_oracles_channelizer_output(gpu, oracle):
 
 @pytest.mark.parametrize("fs,nch", [(250000, 5), (2_400_000, 130)])
 def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
-    """One fold launch multiplies the spectra of up to geometry.fold_batch queued blocks against ONE pass over the filter taps
-    (fold_kernels.hip, NB; src/fastddc.c:123-150 run for that many blocks).  Every bin's sum is the same FMA chain whatever the
-    company, so the channelizer output of EVERY block -- read back per block, compared as uint32 -- and every PDU equal those of a
-    pass over the taps per block (HFDL_GPU_FOLD_BATCH=1), for full batches, batches of 8, and the ragged batches that draining
-    polls / syncs cut (3 + 1, 2, 7 = 4 + 2 + 1 ...).  5 channels: demodulator-bound geometry (decoder on its own stream, 4 blocks per
-    demodulator launch, an odd channel left over for the single-channel tiling); 130 channels: fold-bound shape (one block per
-    demodulator launch, launches held back behind the next half's forward FFTs)."""
+    """One fold launch multiplies the spectra of up to geometry.fold_batch (16) queued blocks against ONE pass over the filter taps on
+    the matrix pipe (fold_kernels.hip; src/fastddc.c:123-150 run for that many blocks).  Every bin's sum is the same FMA chain whatever
+    the company, so the channelizer output of EVERY block -- read back per block, compared as uint32 -- and every PDU equal those of a
+    pass over the taps per block (HFDL_GPU_FOLD_BATCH=1), for full batches of 16 / 8 / 4 / 2 and the ragged batches that draining
+    polls / syncs cut (13, 7, 5, 3, 1 blocks: columns of the 4x4 tiles left empty).  5 channels: demodulator-bound geometry (several
+    blocks per demodulator launch, an odd channel padded to a pair, only the single-wave workgroups of the left-over pairs run);
+    130 channels: fold-bound shape (eight 16-channel workgroups + one left-over pair; demodulator launches held back behind the next
+    half's forward FFTs)."""
     cf = 10_000_000
     rng = np.random.default_rng(nch)
     if nch == 5:
@@ -921,8 +931,8 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
             i += 1
             for j in range(k):
                 fe.push_block(x[(b + j) * n:(b + j + 1) * n])
-            got += fe.poll_pdus()                 # closes the half as it is: a batch of k blocks (split 8 / 4 / 2 / 1 inside)
-            half = min(8, -(-max(g.fold_batch, g.demod_batch) // g.fold_batch) * g.fold_batch)      # blocks a half holds (hfdl_gpu.cpp half_blocks)
+            got += fe.poll_pdus()                 # closes the half as it is: one fold launch for its k blocks
+            half = min(16, -(-max(g.fold_batch, g.demod_batch) // g.fold_batch) * g.fold_batch)      # blocks a half holds (hfdl_gpu.cpp half_blocks)
             held = min(k, ((k - 1) % half) + 1)   # blocks of the newest half: what read_tap(back=...) still reaches
             for j in range(held):
                 outs.append((b + k - held + j, [fe.read_tap(F.TAP_CHAN_OUT, c, back=held - 1 - j).view(np.uint32).copy() for c in watch]))
@@ -934,7 +944,7 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
     ref_outs, ref_pdus, ref_stats = run(1, [1])
     assert len(ref_outs) == len(x) // (28672 if fs == 250000 else 458752)
     assert len(ref_pdus) >= len(bursts) - 2
-    for fold_env, cuts in ((4, [4]), (4, [3, 1, 2, 4]), (8, [8]), (8, [7, 5, 8, 3]), (2, [2, 1])):
+    for fold_env, cuts in ((4, [4]), (4, [3, 1, 2, 4]), (8, [8]), (8, [7, 5, 8, 3]), (2, [2, 1]), (16, [16]), (16, [13, 5, 16, 3, 9])):
         outs, pdus, stats = run(fold_env, cuts)
         assert outs, (fold_env, cuts)
         for blk, chans in outs.items():
@@ -944,11 +954,49 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
         assert stats == ref_stats, (fold_env, cuts)
 
 
+@pytest.mark.parametrize("fs,nch", [(250000, 5), (2_400_000, 130), (1_200_000, 32)])
+def test_fold_mfma_equals_fma_chain(gpu, fs, nch):
+    """The fold runs on the fp32 matrix pipe (v_mfma_f32_4x4x1_16B_f32: per instruction sixteen bins x (two channels' Re / Im rows) x
+    four blocks).  Every compiled tiling (laboratory build: the sweep set included) must leave the partial sums of EVERY block count
+    1 .. 16 bit-identical to the plain-VALU reference kernel, which spells each bin's sum out as the same chain of fused multiply-adds
+    one thread at a time: the checksum over the bit patterns of all partial sums is compared, the buffer poisoned before every kernel."""
+    cf = 10_000_000
+    lab = F.load_lab()
+    freqs = [int(cf + (i - nch // 2) * (15_000 if nch > 5 else 40_000) + 4_000) for i in range(nch)]
+    fe = gpu.Frontend(fs, cf, freqs, lib=lab)
+    g = fe.geometry
+    assert g.fold_batch == 16
+    rng = np.random.default_rng(nch)
+    n = fe.input_size
+    for b in range(16):
+        fe.channelize_block((rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.1))
+    # channelize_block closes a half per block; fill one half with 16 spectra for the probe
+    for b in range(16):
+        fe.push_block((rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.1))
+    fe.sync()
+    variants = F.fold_variants()
+    ran = 0
+    for nb in (1, 2, 3, 4, 5, 8, 11, 13, 16):
+        ref = fe.fold_variant_probe(-1, nb, 1)[2]
+        for v, (p, q, w, d, nbmax, _) in enumerate(variants):
+            if nb > nbmax:
+                continue
+            try:
+                chk = fe.fold_variant_probe(v, nb, 1)[2]
+            except gpu.GpuError:
+                continue                              # rows per slice not a multiple of the tiling's look-ahead
+            assert chk == ref, (nb, (p, q, w, d))
+            ran += 1
+    assert ran >= 20
+    fe.close()
+
+
 def test_fft_stream_switch_changes_nothing(gpu, monkeypatch):
     """HFDL_GPU_FFT_STREAM=1 (forward FFTs of the half being filled on a stream of their own, beside the fold of the half before: two
-    sets of spectra, phasor tables and state snapshots chained by events) is an A/B switch that is off by default (measured slower on
+    sets of spectra, phasor tables and state snapshots chained by events) is an A/B switch of the LABORATORY build (measured slower on
     cfg3): it must give the same channelizer output, bit for bit, and the same PDUs -- full halves, ragged cuts,
-    lagging collections and channelizer-only blocks in between."""
+    lagging collections and channelizer-only blocks in between.  The reference run goes through the product library, which does not
+    read the switch at all: the laboratory build's default path is the product's."""
     fs, cf = 250000, 10_000_000
     freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000, 10_101_000]
     dur = 10.0
@@ -956,8 +1004,8 @@ def test_fft_stream_switch_changes_nothing(gpu, monkeypatch):
     x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.012, seed=61)
 
     def run(own_stream):
-        monkeypatch.setenv("HFDL_GPU_FFT_STREAM", "1" if own_stream else "0")
-        fe = gpu.Frontend(fs, cf, freqs)
+        monkeypatch.setenv("HFDL_GPU_FFT_STREAM", "1")                 # the product library ignores it
+        fe = gpu.Frontend(fs, cf, freqs, lib=F.load_lab() if own_stream else None)
         n, got, outs = fe.input_size, [], []
         for b in range(len(x) // n):
             blk = x[b * n:(b + 1) * n]
@@ -1051,7 +1099,7 @@ def test_random_call_sequences_on_a_fold_bound_geometry(gpu):
 
     def run(script):
         fe = gpu.Frontend(fs, cf, freqs)
-        assert fe.geometry.demod_batch == 1
+        assert fe.geometry.demod_batch >= 2          # 0.19 s blocks: two fit the demodulator's LDS
         n, got = fe.input_size, []
         for b in range(len(x) // n):
             blk = x[b * n:(b + 1) * n]
