@@ -39,6 +39,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
+    # BASELINE.json configs[0] as SURVEY.md 8(d) words it: 250 ksps cf32, ONE channel at centre + 37 kHz, 60 s (523 blocks of 28672 samples), one single-slot 300 bps
+    # SPDU on the 32 s frame grid, AWGN at 15 dB Es/N0, seed 1.  (Es/N0 = in-channel SNR + 10 log10(7812.5 Hz / 1800 Bd) = SNR + 6.4 dB:
+    # amplitude 0.0135 over sigma 0.02 per component.)  The reference's CPU-runnable plumbing case; here it exercises the
+    # single-channel shape of the fold (one channel padded to a pair, the single-wave workgroups) through the same kernels.
+    "cfg1": dict(fs=250_000, centerfreq=10_000_000, nch=1, freqs=[10_037_000], blocks=523, seed=1, noise=0.02, slot_grid_s=32.0, es_n0_db=15.0,
+                 name="250 ksps cf32 --iq-file, 1 HFDL channel at centre + 37 kHz, 60 s, one 300 bps SPDU per 32 s frame, 15 dB Es/N0 (BASELINE.json configs[0])"),
     # BASELINE.json configs[2]: 40 Msps synthetic cf32, 256 channels on a 150 kHz grid, 1 MI355X
     "cfg3": dict(fs=40_000_000, centerfreq=15_000_000, nch=256, grid=150_000, blocks=16, seed=3, noise=0.05,
                  name="40 Msps cf32, 256 HFDL channels (BASELINE.json configs[2]; per rank at N>1 = configs[4])"),
@@ -54,6 +60,8 @@ NBITS = [540, 1080, 2160, 3240, 1260, 2520, 5040, 7560]      # decoded bits = tr
 
 
 def channel_plan(w):
+    if "freqs" in w:
+        return list(w["freqs"])
     nch, grid, cf = w["nch"], w["grid"], w["centerfreq"]
     return [int(cf + (i - nch // 2) * grid + grid // 2 - 1440) for i in range(nch)]
 
@@ -131,6 +139,16 @@ def plan_bursts(w, freqs, dur, seed):
                     amp=float(rng.uniform(0.01, 0.03)),        # ~19..29 dB in-channel SNR
                     cfo=float(rng.uniform(-15, 15)))
 
+    if "slot_grid_s" in w:
+        # one single-slot 300 bps SPDU per frame of 32 s (13 slots of 2.461 s, ARINC 635), the first one second into the stretch
+        noise_rms = w["noise"] * np.sqrt(2.0) / np.sqrt(2 ** int(np.floor(np.log2(w["fs"] / 5400.0))))        # in the channel's fs / decimation band
+        amp = float(noise_rms * 10 ** ((w["es_n0_db"] - 10 * np.log10((w["fs"] / 2 ** int(np.floor(np.log2(w["fs"] / 5400.0)))) / 1800.0)) / 20))
+        t = 1.0
+        while t + synth.burst_symbols_len(0) / 1800 < dur - 0.05:
+            for f in freqs:
+                bursts.append(dict(freq=f, mode=0, octets=synth.make_spdu(rng), lpdus=None, t0=t, amp=amp, cfo=float(rng.uniform(-15, 15))))
+            t += w["slot_grid_s"]
+        return bursts
     for i, f in enumerate(freqs):
         if w.get("dense"):
             # as many bursts as fit the resident stretch, modes cycling 0..7 from a per-channel offset
@@ -399,6 +417,21 @@ def csrc_hash():
         if name.endswith((".hip", ".h", ".cpp")):
             h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
+
+
+def stream_budget(stages, steps, half_blocks):
+    """Kernel time per stream for one half of `half_blocks` blocks: stream A = forward FFTs + fold + inverse FFT / NCO, stream B =
+    demodulators, stream D = burst decoders (hfdl_gpu_frontend_stage_times over the timed region, scaled to a half)."""
+    if not steps:
+        return None
+    per_block = {k: (v[0] / steps) for k, v in stages.items()}
+    a = per_block["fft"] + per_block["fold"] + per_block["ifft"]
+    return dict(half_blocks=half_blocks,
+                stream_a_ms=a * half_blocks, stream_b_ms=per_block["demod"] * half_blocks, stream_d_ms=per_block["decode"] * half_blocks,
+                per_block_ms={k: round(v, 5) for k, v in per_block.items()},
+                launches={k: v[1] for k, v in stages.items()},
+                note="A = forward FFT (%.3f ms / block) + fold + inverse FFT / NCO; B = demodulators; D = burst decoders; the streams run beside each other"
+                     % per_block["fft"])
 
 
 def stream_read_leg(w, freqs, dev_index):
@@ -715,6 +748,7 @@ def main():
     dm_ms, dm_n, dm_blk = fe.demod_time_ms()
     period_ms = fe.step_period_ms()
     shapes = fe.fold_launch_shapes()                       # {blocks per launch: timed launches}
+    stages = fe.stage_times()                              # kernel time by stage, from the dispatches' own events
     barrier()
     fe.reset_timers(False)
     good = sum(1 for p in pdus if matches_sent(p, bursts_by_freq))
@@ -797,6 +831,9 @@ def main():
             "fill_drain_ms": max(0.0, elapsed * 1e3 - period_ms * args.steps) if period_ms else None,
             "trellis_steps_per_s_in_run": total_trellis / elapsed_max,
             "demod_kernel_ms_per_block": (dm_ms / dm_blk) if dm_blk else None, "demod_blocks_per_launch": demod_batch,
+            # who bounds a half: kernel time per stream and half of `fold_batch` blocks, summed from the dispatches'
+            # own events over the timed region (streams overlap: the largest is the bound, the sum is not the step)
+            "streams": stream_budget(stages, args.steps, fold_batch),
             "roofline": {"bound": "hbm", "kernel": "fold_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n,

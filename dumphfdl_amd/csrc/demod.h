@@ -49,7 +49,7 @@ struct Demod {
 	// chan_out / out_count: `nblk` consecutive blocks, [nblk][nch][outs] and [nblk][nch]
 	int enqueue_demod(const float2 *chan_out, const int *out_count, int nblk, hipStream_t st, hipEvent_t done = nullptr, bool frames_free = false, hipEvent_t start = nullptr);
 	hipEvent_t frames_free_event() const { return separate_decode ? ev_dec[launches & 1] : nullptr; }   // of the NEXT launch; may be null
-	int enqueue_decode(int buf, hipStream_t st);                                              // K5 + PDU-ring snapshot of the same block
+	int enqueue_decode(int buf, hipStream_t st, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);   // K5 + PDU-ring snapshot of the same block; the events ride on the kernel's dispatch (timing)
 	int collect(hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);                    // stream idle: everything produced
 	int collect_snapshot(int buf, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);  // up to the end of that buffer's block
 	int take(unsigned produced, hfdl_gpu_pdu *out, int32_t max, int32_t *n, hipStream_t st);

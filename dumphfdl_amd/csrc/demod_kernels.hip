@@ -13,18 +13,12 @@
 #include <utility>
 #include <vector>
 #include <cstring>
-#ifdef HFDL_DM_STRICT
-// TEST-ONLY BUILD (csrc/build_strict.sh, never the shipped library; same standing as HFDL_DM_LIBM_TRIG): the demodulator runs the
-// one-lane serial loop of tests/hostsim/serial_demod.h with the fixed-sequence elementary functions of tests/hostsim/shared_math.h --
-// the arithmetic the oracle runs under orc_variant.shared_math -- so that device and oracle can be compared BIT FOR BIT, and the
-// pipeline's fast forms can be switched back on one at a time (HFDL_DM_STRICT_FAST).  profiles/strict_study.py, DESIGN.md section 5.
-#define SM_FN __host__ __device__ static inline
-#include "../../tests/hostsim/shared_math.h"
-#define HFDL_ATAN2F sm_atan2f
-#endif
 #include "demod_core.h"
 #ifdef HFDL_DM_STRICT
-#include "../../tests/hostsim/serial_demod.h"
+// Hook of the TEST-ONLY strict builds (tests/hostsim/strict_demod_kernels.hip includes this file after defining HFDL_DM_STRICT, the
+// fixed-sequence elementary functions and HFDL_DM_SERIAL_LOOP = the header with the one-lane serial loop it wants run instead of the
+// three-wave pipeline).  The product build defines none of it and this file names nothing under tests/.
+#include HFDL_DM_SERIAL_LOOP
 #endif
 #include "demod_tables.h"
 #include "demod.h"
@@ -666,13 +660,13 @@ int Demod::enqueue_demod(const float2 *chan_out, const int *out_count, int nblk,
 	return 0;
 }
 
-int Demod::enqueue_decode(int buf, hipStream_t st)
+int Demod::enqueue_decode(int buf, hipStream_t st, hipEvent_t start, hipEvent_t stop)
 {
 	DemodPriv *pv = priv_of(this);
 	if (!pv) return HFDL_GPU_EINVAL;
 	const uint64_t i = decodes++;
 	if (i + 1 != launches) return HFDL_GPU_EINVAL;      // one decoder launch per demodulator launch, in order
-	hipLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), k5_lds_bytes(), st, (const FrameRec *)(d_frames + (size_t)(i & 1) * nch), d_counts,
+	hipExtLaunchKernelGGL(burst_decode_kernel, dim3((unsigned)nch), dim3(64), (unsigned)k5_lds_bytes(), st, start, stop, 0, (const FrameRec *)(d_frames + (size_t)(i & 1) * nch), d_counts,
 			d_counts + 4 + (int)(i & 3), d_counts + 4 + (int)((i + 2) & 3), nch,
 			(const cf *)d_data, pv->t.scrambler, (const int32_t *)d_freqs, d_pdus, pdu_cap);
 	// what the ring holds once this block is done, for a host that collects without draining the pipeline

@@ -29,6 +29,16 @@ __device__ __forceinline__ float2 load_sample(const void *__restrict__ raw, int 
 	return ((const float2 *)raw)[i];
 }
 
+// last-pass store: plain index, or (the transform is a channel's filter) straight into the matrix-operand tap layout
+__device__ __forceinline__ void store_out(float2 *out, const FftOutLayout &lay, unsigned i, size_t at, float2 v)
+{
+	if (lay.kind == TAPL_PLAIN) { out[at] = v; return; }
+	float *o = (float *)out + (size_t)(i >> lay.row_log) * (size_t)(2 * lay.row_stride)
+			+ tap_offset_f(lay.kind, 1 << lay.row_log, lay.chan, (int)(i & ((1u << lay.row_log) - 1u)), 0);
+	o[0] = v.x;
+	o[4] = v.y;              // Im sits one lane on: four floats
+}
+
 // pass 1: columns c = n2*R3+n3 (stride R2*R3 between the R1 samples of a column).  Input is the
 // virtual concatenation [hist(split) , fresh(n-split)] -- the overlap assembly of src/fft.c:49-54.
 // The last `split` samples of the block are the next block's history: they are written to `hist_next` (a second buffer,
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass3(const float2 *__restric
 		const unsigned i = (k + half) & (unsigned)(p.n - 1);
 		const size_t at = lay.row_log ? (size_t)(i >> lay.row_log) * (size_t)lay.row_stride + (i & ((1u << lay.row_log) - 1u)) : (size_t)i;
 		const int r = bitrev(k3, p.l3);
-		out[at] = sm[r * FFT_TILE + ((col + r) & (FFT_TILE - 1))];
+		store_out(out, lay, i, at, sm[r * FFT_TILE + ((col + r) & (FFT_TILE - 1))]);
 	}
 }
 
@@ -262,26 +272,26 @@ __global__ __launch_bounds__(16 * B) void fft_rpass3(const float2 *__restrict__ 
 			const unsigned k = kbase + ((unsigned)(ka + 16 * kb) << (p.l1 + p.l2));
 			const unsigned i = (k + half) & (unsigned)(p.n - 1);
 			const size_t at = lay.row_log ? (size_t)(i >> lay.row_log) * (size_t)lay.row_stride + (i & ((1u << lay.row_log) - 1u)) : (size_t)i;
-			out[at] = z[slot_small<B>(kb)];
+			store_out(out, lay, i, at, z[slot_small<B>(kb)]);
 		}
 	}
 }
 
 template <int B>
-static void launch_rpass1(int fmt, int grid, hipStream_t st, hipEvent_t input_read, const float2 *hist, const void *fresh, int split, float2 *hist_next,
+static void launch_rpass1(int fmt, int grid, hipStream_t st, hipEvent_t start, hipEvent_t input_read, const float2 *hist, const void *fresh, int split, float2 *hist_next,
 		float2 *work, const FftPlan &p, const NcoJob &nco, int riders)
 {
 	const dim3 blk(16 * B);
-	if (fmt == SFMT_CS16) hipExtLaunchKernelGGL((fft_rpass1<B, SFMT_CS16>), dim3(grid), blk, 0, st, nullptr, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
-	else if (fmt == SFMT_CU8) hipExtLaunchKernelGGL((fft_rpass1<B, SFMT_CU8>), dim3(grid), blk, 0, st, nullptr, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
-	else hipExtLaunchKernelGGL((fft_rpass1<B, SFMT_CF32>), dim3(grid), blk, 0, st, nullptr, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
+	if (fmt == SFMT_CS16) hipExtLaunchKernelGGL((fft_rpass1<B, SFMT_CS16>), dim3(grid), blk, 0, st, start, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
+	else if (fmt == SFMT_CU8) hipExtLaunchKernelGGL((fft_rpass1<B, SFMT_CU8>), dim3(grid), blk, 0, st, start, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
+	else hipExtLaunchKernelGGL((fft_rpass1<B, SFMT_CF32>), dim3(grid), blk, 0, st, start, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
 }
 
 // the register-resident passes take radices 64 / 128 / 256 (N = 2^18 .. 2^24); smaller transforms keep the LDS radix-4 passes
 static bool fast_plan(const FftPlan &p) { return p.l1 >= 6 && p.l1 <= 8 && p.l2 >= 6 && p.l2 <= 8 && p.l3 >= 6 && p.l3 <= 8; }
 
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
-		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay, hipEvent_t done, NcoJob nco, hipEvent_t input_read)
+		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay, hipEvent_t done, NcoJob nco, hipEvent_t input_read, hipEvent_t start)
 {
 	const int c1 = (p.n >> p.l1), c2 = p.r1 * p.r3, c3 = p.r1 * p.r2;
 	const int g1 = (c1 + FFT_TILE - 1) / FFT_TILE, g2 = (c2 + FFT_TILE - 1) / FFT_TILE, g3 = (c3 + FFT_TILE - 1) / FFT_TILE;
@@ -292,9 +302,9 @@ void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh,
 		const int rd1 = riders_of(p.l1), rd2 = riders_of(p.l2), rd3 = riders_of(p.l3);
 		nco.seg = 0;
 		switch (p.l1) {
-		case 6: launch_rpass1<4>(fmt, g1 + rd1, st, input_read, hist, fresh, split, hist_next, work, p, nco, rd1); break;
-		case 7: launch_rpass1<8>(fmt, g1 + rd1, st, input_read, hist, fresh, split, hist_next, work, p, nco, rd1); break;
-		default: launch_rpass1<16>(fmt, g1 + rd1, st, input_read, hist, fresh, split, hist_next, work, p, nco, rd1); break;
+		case 6: launch_rpass1<4>(fmt, g1 + rd1, st, start, input_read, hist, fresh, split, hist_next, work, p, nco, rd1); break;
+		case 7: launch_rpass1<8>(fmt, g1 + rd1, st, start, input_read, hist, fresh, split, hist_next, work, p, nco, rd1); break;
+		default: launch_rpass1<16>(fmt, g1 + rd1, st, start, input_read, hist, fresh, split, hist_next, work, p, nco, rd1); break;
 		}
 		nco.seg = 1;
 		switch (p.l2) {
@@ -315,9 +325,9 @@ void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh,
 	// tile + the radix's twiddle table
 	const size_t l1 = (size_t)p.r1 * (FFT_TILE + 1) * sizeof(float2), l2 = (size_t)p.r2 * (FFT_TILE + 1) * sizeof(float2);
 	nco.seg = 0;
-	if (fmt == SFMT_CS16) hipExtLaunchKernelGGL(fft_pass1<SFMT_CS16>, dim3(g1 + riders), blk, l1, st, nullptr, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
-	else if (fmt == SFMT_CU8) hipExtLaunchKernelGGL(fft_pass1<SFMT_CU8>, dim3(g1 + riders), blk, l1, st, nullptr, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
-	else hipExtLaunchKernelGGL(fft_pass1<SFMT_CF32>, dim3(g1 + riders), blk, l1, st, nullptr, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
+	if (fmt == SFMT_CS16) hipExtLaunchKernelGGL(fft_pass1<SFMT_CS16>, dim3(g1 + riders), blk, l1, st, start, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
+	else if (fmt == SFMT_CU8) hipExtLaunchKernelGGL(fft_pass1<SFMT_CU8>, dim3(g1 + riders), blk, l1, st, start, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
+	else hipExtLaunchKernelGGL(fft_pass1<SFMT_CF32>, dim3(g1 + riders), blk, l1, st, start, input_read, 0, hist, fresh, split, hist_next, work, p, nco, riders);
 	nco.seg = 1;
 	hipLaunchKernelGGL(fft_pass2, dim3(g2 + riders), blk, l2, st, work, p, nco, riders);
 	nco.seg = 2;

@@ -21,37 +21,12 @@ constexpr int FOLD_THREADS = 256;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// ---- tap layout -------------------------------------------------------------------------------------------------------------
-// Plain (M not a multiple of 64): element (channel c, alias row r, bin j) at r * tap_row_stride + c * M + j, cf32.
-// Pair-interleaved (every other geometry), in floats: row r, channel pair q = c / 2, group g = j / 64 of 64 bins:
-//      r * 2 * tap_row_stride + q * 4 M + g * 256 + lane * 4 + v,      lane = 4 * (j % 16) + i,   v = (j / 16) % 4,
-//      i = 0: Re H_c0   1: Im H_c0   2: Re H_c1   3: Im H_c1        (c0 = 2 q, c1 = 2 q + 1)
-// i.e. one 1 KiB wave load (16 bytes per lane) of a pair's group yields, in register v of lane 4 b + i, operand A of the 4x4x1
-// instruction that handles bins 64 g + 16 v + b (b = 0..15, one per block of the instruction): rows (Re c0, Im c0, Re c1, Im c1).
-// Alias row r of ALL channels is still one nch * M run, so the workgroups of all channels, which walk the rows together, stream
-// through a few moving windows of HBM.
+// ---- tap layouts: kernels.h (TAPL_*, tap_offset_f) ----
 
-__device__ __forceinline__ float2 tap_at(const float *taps, size_t row_stride_f, int m, int pair_layout, int c, int row, int j)
+__device__ __forceinline__ float2 tap_at(const float *taps, size_t row_stride_f, int m, int layout, int c, int row, int j)
 {
-	if (!pair_layout) return ((const float2 *)taps)[(size_t)row * (row_stride_f >> 1) + (size_t)c * m + j];
-	const int g = j >> 6, v = (j >> 4) & 3, b = j & 15, i0 = (c & 1) * 2;
-	const float *p = taps + (size_t)row * row_stride_f + (size_t)(c >> 1) * 4 * m + (size_t)g * 256 + v;
-	return make_float2(p[(4 * b + i0) * 4], p[(4 * b + i0 + 1) * 4]);
-}
-
-// plain -> pair-interleaved, in place, one workgroup per (alias row, channel pair): the pair's 2 M taps go through LDS
-__global__ __launch_bounds__(FOLD_THREADS) void tap_interleave_kernel(float *taps, size_t row_stride_f, int m, int npairs)
-{
-	extern __shared__ float sm_t[];         // 4 M floats
-	const int pr = blockIdx.x % npairs, row = blockIdx.x / npairs;
-	float *base = taps + (size_t)row * row_stride_f + (size_t)pr * 4 * m;
-	for (int e = threadIdx.x; e < 4 * m; e += FOLD_THREADS) sm_t[e] = base[e];
-	__syncthreads();
-	for (int e = threadIdx.x; e < 4 * m; e += FOLD_THREADS) {
-		const int v = e & 3, lane = (e >> 2) & 63, g = e >> 8;
-		const int i = lane & 3, b = lane >> 2, j = g * 64 + v * 16 + b;
-		base[e] = sm_t[(i >> 1) * 2 * m + 2 * j + (i & 1)];
-	}
+	const float *p = taps + (size_t)row * row_stride_f + tap_offset_f(layout, m, c, j, 0);
+	return make_float2(p[0], p[layout == TAPL_PLAIN ? 1 : 4]);
 }
 
 // One complex multiply-accumulate per bin as a FIXED chain of four fused multiply-adds -- the order the matrix instructions below
@@ -66,7 +41,7 @@ __device__ __forceinline__ void cmac_chain(float2 &a, const float2 h, const floa
 
 // reference / fallback: one thread per (channel, slice, bin), either tap layout, any geometry, `nb` blocks one after the other
 __global__ __launch_bounds__(FOLD_THREADS) void fold_ref_kernel(const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
-		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int pair_layout, int nb)
+		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int layout, int nb)
 {
 	const int s = blockIdx.x % slices, c = blockIdx.x / slices;
 	for (int b0 = 0; b0 < nb; b0 += 4)              // four blocks per pass over the taps
@@ -74,7 +49,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_ref_kernel(const float *__r
 			const float2 *sp = spec + (size_t)b0 * spec_stride + (size_t)s * rows * (size_t)m + j;
 			float2 acc[4] = { make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f) };
 			for (int r = 0; r < rows; r++) {
-				const float2 h = tap_at(taps, row_stride_f, m, pair_layout, c, s * rows + r, j);
+				const float2 h = tap_at(taps, row_stride_f, m, layout, c, s * rows + r, j);
 #pragma unroll
 				for (int k = 0; k < 4; k++)
 					if (b0 + k < nb) cmac_chain(acc[k], h, sp[(size_t)k * spec_stride + (size_t)r * m]);
@@ -92,6 +67,145 @@ __device__ __forceinline__ float rot90(float a, int sign_mask)
 	return __int_as_float(v ^ sign_mask);
 }
 
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int fold16_waves(int p, int w, int d)
+{
+	const int mine = (2 + w - 1) / w;
+	const int regs = 64 * p + 4 * p * d + 4 * mine * d + 8 + 4 * p + 28;
+	return regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
+}
+
+// THE fold: v_mfma_f32_16x16x1_4B_f32, TAPL_OCTET taps.  One instruction = four bins x (8 channels' Re / Im rows) x 16 blocks: 1024
+// multiply-accumulates, a quarter of the register-file traffic per product of the 4x4x1 form (whose launches the board ran at
+// 1.3 - 1.5 GHz: profiles/r05_experiments.md), and the whole batch of up to 16 blocks in its sixteen columns.
+// P channel OCTETS per wave, W waves per workgroup, D rows of loads in flight.  A workgroup = one group of 16 bins x one slice of alias
+// rows x 8 P W channels; its W waves cover the SAME bins and different channels, so each alias row's spectrum tile (16 blocks x 16
+// bins = 2 KiB) is fetched ONCE per workgroup (two waves load half of it each, already in operand-B order: lane n + 16 blk = bin blk
+// of block n), written to LDS and read from there by all waves.  Per alias row and wave: P tap loads of 1 KiB (non-temporal), two LDS
+// reads, 4 P vector instructions (the rotated operand) and 8 P matrix instructions: first every accumulator's Re(X) product, then every
+// Im(X) product.  Loads run D rows ahead, the spectrum tile one row ahead through two LDS stages, one barrier per row.
+template <int P, int W, int D>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_waves(P, W, D), fold16_waves(P, W, D)))) void fold_mfma16_kernel(
+		const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
+		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int octet_base, int nch, int nb)
+{
+	static_assert(D == 2 || D == 4, "the LDS stage of a trip is a compile-time constant for even D");
+	// a row's spectrum tile = 4 pieces of 512 B (bin-set v = 0 .. 3: lane n + 16 blk <- bin 4 v + blk of block n).  EVERY wave fetches
+	// MINE of them -- with more than four waves the upper ones fetch (and store) what the lower ones do -- so that all waves issue the
+	// same loads and no branch sits in the loop: behind a branch the compiler's s_waitcnt count assumes the path with the most loads,
+	// and the waves on the other path wait for all but one row of theirs
+	constexpr int MINE = W >= 4 ? 1 : 4 / W;
+	__shared__ v2f xt[2][4][64];                              // [stage][bin-set][lane] = (Re, Im)
+	const int ngrp = m >> 4;
+	// blockIdx -> (tile = bin group x slice, channel group), XCD-aware as in fold_mfma_kernel
+	const int ntile = ngrp * slices, groups = (int)gridDim.x / ntile;
+	int tile_id, grp;
+	if ((ntile & 7) == 0) {
+		const int xcd = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+		grp = i % groups;
+		tile_id = (i / groups) * 8 + xcd;
+	} else {
+		tile_id = (int)blockIdx.x % ntile;
+		grp = (int)blockIdx.x / ntile;
+	}
+	const int g = tile_id % ngrp, s = tile_id / ngrp;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+	const int n = lane & 15, blk = lane >> 4;
+	const int octet0 = octet_base + (grp * W + wave) * P;
+	const int sign_mask = (lane & 1) ? 0 : (int)0x80000000;
+	const char *tb = (const char *)(taps + (size_t)s * rows * row_stride_f + (size_t)octet0 * 16 * m + (size_t)g * 256) + lane * 16;
+	const size_t rs_b = row_stride_f * 4, os_b = (size_t)m * 64, xrow_b = (size_t)m * 8;
+	const int v0 = (wave * MINE) & 3;                         // this wave's first piece
+	const char *xp;
+	{
+		const int bi = n < nb ? n : nb - 1;                   // columns past the last block repeat it; they are never stored
+		xp = (const char *)(spec + (size_t)bi * spec_stride + (size_t)s * rows * (size_t)m + g * 16 + 4 * v0 + blk);
+	}
+	v16f acc[P][4];
+#pragma unroll
+	for (int p = 0; p < P; p++)
+#pragma unroll
+		for (int v = 0; v < 4; v++)
+#pragma unroll
+			for (int e = 0; e < 16; e++) acc[p][v][e] = 0.f;
+	v4f h[D][P];
+	v2f xs[D][MINE];
+	auto issue = [&](int slot) {               // the loads of the next row not yet asked for: spectrum share first, then the taps
+#pragma unroll
+		for (int i = 0; i < MINE; i++) xs[slot][i] = *(const v2f *)(xp + 32 * i);       // consecutive bin-sets: four bins apart
+		xp += xrow_b;
+#pragma unroll
+		for (int p = 0; p < P; p++) h[slot][p] = __builtin_nontemporal_load((const v4f *)(tb + (size_t)p * os_b));
+		tb += rs_b;
+	};
+	auto stash = [&](int slot, int stage) {
+#pragma unroll
+		for (int i = 0; i < MINE; i++) xt[stage][v0 + i][lane] = xs[slot][i];
+	};
+	auto multiply = [&](int slot, int stage) {
+		v2f x[4];
+#pragma unroll
+		for (int v = 0; v < 4; v++) x[v] = xt[stage][v][lane];
+#pragma unroll
+		for (int p = 0; p < P; p++)
+#pragma unroll
+			for (int v = 0; v < 4; v++)
+				acc[p][v] = __builtin_amdgcn_mfma_f32_16x16x1f32(h[slot][p][v], x[v].x, acc[p][v], 0, 0, 0);
+#pragma unroll
+		for (int p = 0; p < P; p++)
+#pragma unroll
+			for (int v = 0; v < 4; v++)
+				acc[p][v] = __builtin_amdgcn_mfma_f32_16x16x1f32(rot90(h[slot][p][v], sign_mask), x[v].y, acc[p][v], 0, 0, 0);
+	};
+	// loads of different rows must stay in program order (see fold_mfma_kernel): scheduling barriers between the rows
+#pragma unroll
+	for (int d = 0; d < D; d++) {
+		issue(d);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	stash(0, 0);
+	__syncthreads();
+	for (int r = 0; r < rows - D; r += D) {
+#pragma unroll
+		for (int d = 0; d < D; d++) {
+			multiply(d, d & 1);
+			issue(d);
+			stash((d + 1) % D, (d + 1) & 1);
+			__builtin_amdgcn_sched_barrier(0);
+			__syncthreads();
+		}
+	}
+#pragma unroll
+	for (int d = 0; d < D; d++) {
+		multiply(d, d & 1);
+		if (d + 1 < D) {
+			stash(d + 1, (d + 1) & 1);
+			__builtin_amdgcn_sched_barrier(0);
+			__syncthreads();
+		}
+	}
+	// D[bin blk][row i][block n] sits in register 4 blk + (i & 3) of lane 16 (i >> 2) + n: this lane holds block n, channels
+	// 2 (lane >> 4) and + 1 of each octet (Re, Im in adjacent registers), bins 4 v + (0 .. 3): 32 contiguous bytes per channel and v
+	if (n < nb) {
+#pragma unroll
+		for (int p = 0; p < P; p++)
+#pragma unroll
+			for (int cp = 0; cp < 2; cp++) {
+				const int c = 8 * (octet0 + p) + 2 * blk + cp;
+				if (c >= nch) continue;
+				float2 *po = partial + (size_t)n * partial_stride + ((size_t)c * slices + s) * (size_t)m + g * 16;
+#pragma unroll
+				for (int v = 0; v < 4; v++) {
+					const v16f a = acc[p][v];
+					((v4f *)(po + 4 * v))[0] = v4f{ a[2 * cp], a[2 * cp + 1], a[4 + 2 * cp], a[4 + 2 * cp + 1] };
+					((v4f *)(po + 4 * v))[1] = v4f{ a[8 + 2 * cp], a[8 + 2 * cp + 1], a[12 + 2 * cp], a[12 + 2 * cp + 1] };
+				}
+			}
+	}
+}
+
+#ifdef HFDL_LAB
 // registers the tile asks for -> waves per SIMD told to the compiler (512 per lane and SIMD): left to itself it aims at 8 waves,
 // squeezes the loop into 64 registers and gets there by loading, waiting, multiplying, loading again
 constexpr int fold_mfma_waves(int p, int q, int w, int d)
@@ -246,7 +360,6 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold_mfm
 	}
 }
 
-#ifdef HFDL_LAB
 // Read-only streaming probe: what this board's HBM delivers to a bare kernel doing nothing but non-temporal 16-byte loads
 // (1 KiB per wave instruction).  L loads in flight per thread; SPAN: every workgroup walks its own contiguous 4 MiB span,
 // otherwise the whole grid sweeps one moving window (workgroup b reads chunks b, b + grid, ...).  bench.py prints the best of the
@@ -289,17 +402,38 @@ struct FoldArgs {
 	const float2 *spec;
 	float2 *partial;
 	size_t rs_f, ss, ps;
-	int m, slices, rows, nch, npairs, nb;
+	int m, slices, rows, nch, ngroups, nb;            // ngroups: channel groups of the tap layout (octets / pairs) the buffer holds
 	hipStream_t st;
 	hipEvent_t start, stop;
 };
 
-// channel groups of 2 P W channels first; the pairs left over get single-wave workgroups in a launch of their own
+// workgroups of 8 P W channels first; the octets left over get single-wave workgroups in a launch of their own
+template <int P, int W, int D>
+static int fold16_go(const FoldArgs &a)
+{
+	const int ntile = (a.m >> 4) * a.slices;
+	const int groups = a.ngroups / (P * W), rest = a.ngroups - groups * P * W;
+	int launches = 0;
+	if (groups > 0) {
+		hipExtLaunchKernelGGL((fold_mfma16_kernel<P, W, D>), dim3((unsigned)(groups * ntile)), dim3(64 * W), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, 0, a.nch, a.nb);
+		launches++;
+	}
+	if (rest > 0) {
+		hipExtLaunchKernelGGL((fold_mfma16_kernel<1, 1, D>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, groups * P * W, a.nch, a.nb);
+		launches++;
+	}
+	return launches;
+}
+
+#ifdef HFDL_LAB
+// the 4x4x1 family (TAPL_PAIR): channel groups of 2 P W channels first; the pairs left over get single-wave workgroups
 template <int P, int Q, int W, int D>
 static int fold_go(const FoldArgs &a)
 {
 	const int ntile = (a.m >> 6) * a.slices;
-	const int groups = a.npairs / (P * W), rest = a.npairs - groups * P * W;
+	const int groups = a.ngroups / (P * W), rest = a.ngroups - groups * P * W;
 	int launches = 0;
 	if (groups > 0) {
 		hipExtLaunchKernelGGL((fold_mfma_kernel<P, Q, W, D>), dim3((unsigned)(groups * ntile)), dim3(64 * W), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
@@ -307,28 +441,32 @@ static int fold_go(const FoldArgs &a)
 		launches++;
 	}
 	if (rest > 0) {
-		hipExtLaunchKernelGGL((fold_mfma_kernel<1, Q, 1, D>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+		hipExtLaunchKernelGGL((fold_mfma_kernel<1, Q, 1, 2>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
 			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, groups * P * W, a.nch, a.nb);
 		launches++;
 	}
 	return launches;
 }
+#endif
 
-struct FoldVariant { int p, q, w, d; int (*go)(const FoldArgs &); };
-#define FM(P, Q, W, D) { P, Q, W, D, fold_go<P, Q, W, D> }
-// The first entry of a block-group count Q whose row look-ahead D divides the slice is the one used (nb <= 4 Q blocks per launch).
+// layout: the tap layout the tiling reads; q: groups of four blocks it takes (4x4x1 family; 4 = any count up to 16 for the 16x16x1 family)
+struct FoldVariant { int layout, p, q, w, d; int (*go)(const FoldArgs &); };
+#define F16(P, W, D) { TAPL_OCTET, P, 4, W, D, fold16_go<P, W, D> }
+#define FM(P, Q, W, D) { TAPL_PAIR, P, Q, W, D, fold_go<P, Q, W, D> }
+// The first entry whose layout is the geometry's and whose row look-ahead D divides the slice is the one used.
 // Measured on cfg3 (M = 4096, 512 rows per slice) with profiles/fold_variants.py: profiles/r05/fold_variants_cfg3.md.
 static const FoldVariant fold_variants[] = {
-	FM(2, 1, 4, 4), FM(2, 1, 4, 2),
-	FM(2, 2, 4, 4), FM(2, 2, 4, 2),
-	FM(2, 4, 4, 2), FM(2, 4, 4, 4),
+	F16(2, 4, 4), F16(2, 4, 2),
 #ifdef HFDL_LAB
-	// the sweep: more pairs per wave, eight waves per workgroup
-	FM(4, 1, 4, 4), FM(4, 2, 4, 4), FM(4, 2, 4, 2), FM(1, 2, 4, 4), FM(2, 2, 8, 4), FM(2, 2, 8, 2), FM(1, 2, 8, 4),
-	FM(2, 4, 8, 2), FM(2, 4, 8, 4), FM(1, 4, 8, 4), FM(1, 4, 4, 4), FM(4, 4, 4, 2),
+	F16(1, 4, 4), F16(1, 4, 2), F16(1, 8, 4), F16(1, 8, 2), F16(2, 2, 4), F16(1, 2, 4), F16(2, 8, 2),
+	// the 4x4x1 family of the first matrix-pipe build (HFDL_GPU_FOLD_MFMA=4 at create): measured, kept for the record
+	FM(2, 1, 4, 4), FM(2, 1, 4, 2), FM(4, 1, 4, 4),
+	FM(2, 2, 4, 4), FM(2, 2, 4, 2), FM(4, 2, 4, 4), FM(4, 2, 4, 2), FM(2, 2, 8, 2),
+	FM(2, 4, 4, 2), FM(2, 4, 8, 2), FM(2, 4, 8, 4),
 #endif
 };
 #undef FM
+#undef F16
 constexpr int N_FOLD_VARIANTS = (int)(sizeof(fold_variants) / sizeof(fold_variants[0]));
 
 int fold_variant_count() { return N_FOLD_VARIANTS; }
@@ -337,13 +475,13 @@ int fold_variant_describe(int v, int desc[6])
 {
 	if (v < 0 || v >= N_FOLD_VARIANTS) return -1;
 	const FoldVariant &f = fold_variants[v];
-	desc[0] = f.p; desc[1] = f.q; desc[2] = f.w; desc[3] = f.d; desc[4] = 4 * f.q; desc[5] = 0;
+	desc[0] = f.p; desc[1] = f.q; desc[2] = f.w; desc[3] = f.d; desc[4] = 4 * f.q; desc[5] = f.layout;
 	return 0;
 }
 
 static bool variant_fits(const FoldVariant &f, const Geometry &g)
 {
-	return g.pair_layout && g.rows_per_slice % f.d == 0;
+	return g.tap_layout == f.layout && g.rows_per_slice % f.d == 0;
 }
 
 // the tiling used for `nb` blocks of this geometry: the first entry of the list that fits
@@ -351,7 +489,7 @@ static const FoldVariant *pick_variant(const Geometry &g, int nb)
 {
 	const int q = nb <= 4 ? 1 : nb <= 8 ? 2 : 4;
 	for (const FoldVariant &f : fold_variants)
-		if (f.q == q && variant_fits(f, g)) return &f;
+		if ((f.layout == TAPL_OCTET || f.q == q) && variant_fits(f, g)) return &f;
 	return nullptr;
 }
 
@@ -361,7 +499,7 @@ static FoldArgs fold_args(const Geometry &g, const float2 *taps, const float2 *s
 	FoldArgs a;
 	a.taps = (const float *)taps; a.spec = spectrum; a.partial = partial;
 	a.rs_f = (size_t)g.tap_row_stride * 2; a.ss = spec_stride; a.ps = partial_stride;
-	a.m = g.m; a.slices = g.slices; a.rows = g.rows_per_slice; a.nch = g.nch; a.npairs = g.nch_pad / 2; a.nb = nb;
+	a.m = g.m; a.slices = g.slices; a.rows = g.rows_per_slice; a.nch = g.nch; a.ngroups = g.nch_pad / tap_layout_group(g.tap_layout); a.nb = nb;
 	a.st = st; a.start = start; a.stop = stop;
 	return a;
 }
@@ -370,7 +508,7 @@ static void launch_fold_ref(const Geometry &g, const float2 *taps, const float2 
 		int nb, hipStream_t st, hipEvent_t start, hipEvent_t stop)
 {
 	hipExtLaunchKernelGGL(fold_ref_kernel, dim3((unsigned)(g.nch * g.slices)), dim3(FOLD_THREADS), 0, st, start, stop, 0,
-		(const float *)taps, spectrum, partial, (size_t)g.tap_row_stride * 2, spec_stride, partial_stride, g.m, g.slices, g.rows_per_slice, g.pair_layout, nb);
+		(const float *)taps, spectrum, partial, (size_t)g.tap_row_stride * 2, spec_stride, partial_stride, g.m, g.slices, g.rows_per_slice, g.tap_layout, nb);
 }
 
 int launch_fold_variant(int v, const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial,
@@ -386,7 +524,7 @@ int launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, s
 {
 	int launches = 0;
 	if (nb_max > FOLD_MAX_BLOCKS) nb_max = FOLD_MAX_BLOCKS;
-	// one launch per nb_max blocks: a launch takes ANY block count up to 4 Q (columns past the last block are computed and dropped)
+	// one launch per nb_max blocks: a launch takes ANY block count up to 16 (columns past the last block are computed and dropped)
 	for (int done = 0; done < nb;) {
 		const int take = nb - done < nb_max ? nb - done : nb_max;
 		const bool first = done == 0, last = done + take >= nb;
@@ -400,29 +538,17 @@ int launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, s
 	return launches;
 }
 
-hipError_t launch_tap_interleave(float2 *taps, const Geometry &g, hipStream_t st)
-{
-	if (!g.pair_layout) return hipSuccess;
-	const size_t lds = sizeof(float) * 4 * (size_t)g.m;
-	if (lds > 64 * 1024) {
-		hipError_t e = hipFuncSetAttribute((const void *)tap_interleave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (e != hipSuccess) return e;
-	}
-	hipLaunchKernelGGL(tap_interleave_kernel, dim3((unsigned)(g.pre * (g.nch_pad / 2))), dim3(FOLD_THREADS), lds, st, (float *)taps, (size_t)g.tap_row_stride * 2, g.m, g.nch_pad / 2);
-	return hipGetLastError();
-}
-
 // filter taps of one channel back in plain order (HFDL_GPU_TAP_FILTER): dst[N] cf32
-__global__ __launch_bounds__(FOLD_THREADS) void tap_extract_kernel(const float *__restrict__ taps, float2 *__restrict__ dst, size_t row_stride_f, int m, int pre, int pair_layout, int c)
+__global__ __launch_bounds__(FOLD_THREADS) void tap_extract_kernel(const float *__restrict__ taps, float2 *__restrict__ dst, size_t row_stride_f, int m, int pre, int layout, int c)
 {
 	const size_t n = (size_t)m * pre;
 	for (size_t e = (size_t)blockIdx.x * FOLD_THREADS + threadIdx.x; e < n; e += (size_t)gridDim.x * FOLD_THREADS)
-		dst[e] = tap_at(taps, row_stride_f, m, pair_layout, c, (int)(e / m), (int)(e % m));
+		dst[e] = tap_at(taps, row_stride_f, m, layout, c, (int)(e / m), (int)(e % m));
 }
 
 void launch_tap_extract(const float2 *taps, const Geometry &g, int channel, float2 *dst, hipStream_t st)
 {
-	hipLaunchKernelGGL(tap_extract_kernel, dim3(1024), dim3(FOLD_THREADS), 0, st, (const float *)taps, dst, (size_t)g.tap_row_stride * 2, g.m, g.pre, g.pair_layout, channel);
+	hipLaunchKernelGGL(tap_extract_kernel, dim3(1024), dim3(FOLD_THREADS), 0, st, (const float *)taps, dst, (size_t)g.tap_row_stride * 2, g.m, g.pre, g.tap_layout, channel);
 }
 
 // ---- inverse FFT + scrap + NCO/decimate : one workgroup per channel, M bins in LDS ----
@@ -524,12 +650,12 @@ hipError_t prepare_ifft_nco(int m)
 }
 
 void launch_ifft_nco(const Geometry &g, const float2 *partial, size_t partial_stride, const ChanConst *cc, const NcoState *snap, const float2 *ph,
-		size_t ph_stride, const float2 *tw_m, float2 *chan_out, int *out_count, int nb, hipStream_t st, hipEvent_t done)
+		size_t ph_stride, const float2 *tw_m, float2 *chan_out, int *out_count, int nb, hipStream_t st, hipEvent_t done, hipEvent_t start)
 {
 	int logm = 0;
 	while ((1 << logm) < g.m) logm++;
 	size_t lds = sizeof(float2) * ((size_t)g.m + 1);
-	hipExtLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)(g.nch * nb)), dim3(IFFT_THREADS), (unsigned)lds, st, nullptr, done, 0, partial, partial_stride, cc, snap, ph, ph_stride,
+	hipExtLaunchKernelGGL(ifft_nco_kernel, dim3((unsigned)(g.nch * nb)), dim3(IFFT_THREADS), (unsigned)lds, st, start, done, 0, partial, partial_stride, cc, snap, ph, ph_stride,
 			tw_m, chan_out, out_count, g, logm);
 }
 

@@ -120,6 +120,11 @@ struct hfdl_gpu_frontend {
 	hipEvent_t ev_dm[2][MAX_HALF] = {};              // demodulator launch j of the half in buffer 0 / 1 done (the decoder may start)
 	hipEvent_t ev_dm_cur[2] = { nullptr, nullptr };  // LAST demodulator launch of that half done (chan_out free): an ev_dm, or (timing on) the stop event of a timed pair
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_dmt;      // timed demodulator launches not yet read
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fftt, ev_ifftt, ev_dect;      // ... forward FFTs (first pass start -> last pass stop), inverse FFT / NCO launches, burst decoders
+	double fft_ms = 0, ifft_ms = 0, decode_ms = 0;
+	int64_t fft_timed = 0, ifft_timed = 0, decode_timed = 0;
+	hipEvent_t ev_chan_cur[2] = { nullptr, nullptr };       // "channelizer output of this half ready": ev_chan, or (timing on) the stop event of the timed inverse FFT
+	hipEvent_t ev_fft_cur = nullptr;                        // what the held-back demodulators wait for: ev_fft, or the stop event of a timed forward FFT
 	double demod_ms = 0;
 	int64_t demod_launches = 0, demod_timed_blocks = 0;
 	hipStream_t stream_c = nullptr;     // C: host -> device copies of block k+1 into the other staging buffer
@@ -215,6 +220,7 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	for (auto &e : fe->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	for (auto &e : fe->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	for (auto &e : fe->ev_dmt) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+	for (auto *v : { &fe->ev_fftt, &fe->ev_ifftt, &fe->ev_dect }) for (auto &e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 	if (fe->ev_fft) (void)hipEventDestroy(fe->ev_fft);
 	if (fe->ev_first_fold) (void)hipEventDestroy(fe->ev_first_fold);
 	fe->demod.release();
@@ -268,6 +274,11 @@ static int pick_demod_batch(const hfdl_gpu_frontend *fe)
 	const double block_s = (double)fe->plan.input_size / (double)fe->sample_rate;
 	int want = (int)std::floor(1.0 / block_s);
 	want = std::max(1, std::min(8, want));
+	// Where the fold bounds the block the demodulator workgroups (one per channel, ~one per CU) must stay CO-RESIDENT with the fold's:
+	// three cfg3 blocks per launch take 159 KiB of a CU's 160 KiB of LDS, no fold workgroup fits beside that, and the two kernels
+	// take turns (measured: the demodulator launch beside a 4.8 ms fold took 5.5 ms, profiles/r05_experiments.md).  Two blocks
+	// (118 KiB) leave room for the fold's 4 KiB workgroups and a forward-FFT tile.
+	if (fe->fold_bound) want = std::min(want, 2);
 	return (int)env_long("HFDL_GPU_DEMOD_BATCH", 1, 8, want);       // 1 = a launch per block
 }
 
@@ -324,15 +335,17 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	HIP_TRY(pad.alloc(sizeof(float2) * n));
 	float2 *d_pad = pad.as<float2>();
 	HIP_TRY(hipMemsetAsync(d_pad, 0, sizeof(float2) * n, fe->stream));
-	if (fe->geo.nch_pad > nch)          // the odd channel's partner in the pair-interleaved layout: all-zero taps
-		HIP_TRY(hipMemset2DAsync(fe->d_taps + (size_t)nch * (size_t)fe->geo.tap_chan_stride, sizeof(float2) * (size_t)fe->geo.tap_row_stride, 0,
-				sizeof(float2) * (size_t)pl.m, (size_t)pl.pre, fe->stream));
+	if (fe->geo.nch_pad > nch)          // the channels that fill the last group of the interleaved layout up: all-zero taps
+		HIP_TRY(hipMemsetAsync(fe->d_taps, 0, sizeof(float2) * n * (size_t)fe->geo.nch_pad, fe->stream));
 	for (int c = 0; c < nch; c++) {
 		HIP_TRY(hipMemcpyAsync(d_pad, host.data() + (size_t)c * pl.taps_length, sizeof(float2) * (size_t)pl.taps_length,
 				hipMemcpyHostToDevice, fe->stream));
-		launch_fft_forward(fe->fft.p, nullptr, d_pad, SFMT_CF32, 0, nullptr, fe->d_work, fe->d_taps + (size_t)c * (size_t)fe->geo.tap_chan_stride, true, fe->stream, fe->tap_layout);
+		// the last pass writes the channel's filter straight into the matrix-operand layout (kernels.h tap_offset_f)
+		FftOutLayout lay = fe->tap_layout;
+		lay.chan = c;
+		float2 *dst = lay.kind == TAPL_PLAIN ? fe->d_taps + (size_t)c * (size_t)fe->geo.tap_chan_stride : fe->d_taps;
+		launch_fft_forward(fe->fft.p, nullptr, d_pad, SFMT_CF32, 0, nullptr, fe->d_work, dst, true, fe->stream, lay);
 	}
-	HIP_TRY(launch_tap_interleave(fe->d_taps, fe->geo, fe->stream));      // rows of channel pairs into matrix-operand order (fold_kernels.hip)
 	HIP_TRY(hipStreamSynchronize(fe->stream));
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -368,9 +381,16 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	// Filter taps row-major over channels: alias row r of every channel sits in one nch*M run, so the workgroups of all
 	// channels, which walk the rows together, stream through a few moving windows of HBM instead of nch windows 8N bytes
 	// apart (fold kernel 2.58 -> 2.48 ms on cfg3 and a tighter run-to-run spread, profiles/r01_experiments.md)
-	g.pair_layout = (pl.m % 64) == 0 ? 1 : 0;
-	g.nch_pad = g.pair_layout ? (nch + 1) & ~1 : nch;
+	g.tap_layout = (pl.m % 16) == 0 ? TAPL_OCTET : TAPL_PLAIN;
+#ifdef HFDL_LAB
+	if (env_long("HFDL_GPU_FOLD_MFMA", 4, 16, 16) == 4 && (pl.m % 64) == 0) g.tap_layout = TAPL_PAIR;      // the 4x4x1 family of the first matrix-pipe build
+#endif
+	{
+		const int grp = tap_layout_group(g.tap_layout);
+		g.nch_pad = (nch + grp - 1) / grp * grp;
+	}
 	g.tap_chan_stride = pl.m; g.tap_row_stride = (int64_t)g.nch_pad * pl.m;
+	fe->tap_layout.kind = g.tap_layout;
 	fe->tap_layout.row_log = ilog2(pl.m); fe->tap_layout.row_stride = g.tap_row_stride;
 	g.slices = pick_slices(nch, pl.pre);
 	g.rows_per_slice = pl.pre / g.slices;
@@ -611,8 +631,8 @@ static int stage_input(hfdl_gpu_frontend *fe, const void *iq, size_t nsamples, i
 static int launch_demod(hfdl_gpu_frontend *fe, int buf, int nblk, bool after_fft)
 {
 	// the forward FFTs of the next half follow this half's inverse FFT on stream A, so their event covers ev_chan too
-	if (after_fft) HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_fft, 0));
-	else HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan[buf], 0));
+	if (after_fft) HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_fft_cur, 0));
+	else HIP_TRY(hipStreamWaitEvent(fe->stream_b, fe->ev_chan_cur[buf] ? fe->ev_chan_cur[buf] : fe->ev_chan[buf], 0));
 	for (int j0 = 0, l = 0; j0 < nblk; j0 += fe->batch, l++) {
 		const int take = std::min(fe->batch, nblk - j0);
 		// the done event rides on the kernel's dispatch; with the decoder on its own stream the channelizer has already waited for the
@@ -631,7 +651,14 @@ static int launch_demod(hfdl_gpu_frontend *fe, int buf, int nblk, bool after_fft
 		int rc = fe->demod.enqueue_demod(fe->chan_slot(slot), fe->cnt_slot(slot), take, fe->stream_b, done, l == 0 && fe->frames_wait_on_a, t_start);
 		if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 		if (fe->own_decode_stream) HIP_TRY(hipStreamWaitEvent(fe->stream_d, done, 0));
-		rc = fe->demod.enqueue_decode(buf, fe->stream_d);
+		hipEvent_t k5_start = nullptr, k5_stop = nullptr;
+		if (fe->timing && !fe->ev_pool.empty()) {
+			std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
+			fe->ev_pool.pop_back();
+			k5_start = e.first; k5_stop = e.second;
+			fe->ev_dect.push_back(e);
+		}
+		rc = fe->demod.enqueue_decode(buf, fe->stream_d, k5_start, k5_stop);
 		if (rc) return fail(rc, "burst decoder enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 	}
 	fe->frames_wait_on_a = false;
@@ -660,14 +687,24 @@ static int enqueue_fft(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int st
 	const bool pend = !fe->fft_own_stream && fe->pending_demod_buf >= 0 && i + 1 == fe->half_blocks;
 	if (pend && !fe->ev_fft) HIP_TRY(hipEventCreateWithFlags(&fe->ev_fft, hipEventDisableTiming));
 	// FFT on its own stream: this set of spectra / phasor tables / snapshots was last read by the fold and inverse FFT two halves ago
-	if (fe->fft_own_stream && i == 0) HIP_TRY(hipStreamWaitEvent(fe->stream_f, fe->ev_chan[set], 0));
+	if (fe->fft_own_stream && i == 0) HIP_TRY(hipStreamWaitEvent(fe->stream_f, fe->ev_chan_cur[set] ? fe->ev_chan_cur[set] : fe->ev_chan[set], 0));
 	NcoJob job;
 	job.cc = fe->d_cc; job.chain = fe->d_nco; job.snap = fe->snap_slot(set, i);
 	job.ph = fe->ph_slot(set, i); job.cont = fe->d_ph_cont;
 	job.nch = g.nch; job.outs = g.outs; job.post_input_size = g.post_input_size; job.post = g.post;
+	hipEvent_t fft_done = fe->fft_own_stream ? fe->ev_spec[set] : (pend ? fe->ev_fft : nullptr), fft_start = nullptr;
+	if (fe->timing && !fe->fft_own_stream && !fe->ev_pool.empty()) {
+		// the first pass' start and the last pass' stop ride on their dispatches; the stop event doubles as "this forward FFT is done"
+		std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
+		fe->ev_pool.pop_back();
+		fft_start = e.first; fft_done = e.second;
+		fe->ev_fftt.push_back(e);
+	}
+	if (pend) fe->ev_fft_cur = fft_done;
 	launch_fft_forward(fe->fft.p, fe->d_hist[fe->blocks & 1], fresh, fmt, g.overlap, fe->d_hist[(fe->blocks + 1) & 1], fe->d_work, fe->spec_slot(set, i), true, fe->stream_f,
-			FftOutLayout(), fe->fft_own_stream ? fe->ev_spec[set] : (pend ? fe->ev_fft : nullptr), job,
-			stage_idx >= 0 ? fe->ev_stage_free[stage_idx] : nullptr);       // input consumed once pass 1 is done: the copy stream may refill the buffer
+			FftOutLayout(), fft_done, job,
+			stage_idx >= 0 ? fe->ev_stage_free[stage_idx] : nullptr,        // input consumed once pass 1 is done: the copy stream may refill the buffer
+			fft_start);
 	if (pend) {
 		int rc = flush_pending_demod(fe, true);
 		if (rc) return rc;
@@ -706,16 +743,26 @@ static int close_half(hfdl_gpu_frontend *fe, bool launch_now, bool with_demod = 
 	}
 	// this half is free once the demodulator launches that read it last (two halves ago) are done
 	if (fe->ev_dm_cur[half]) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm_cur[half], 0));
-	if (with_demod && fe->own_decode_stream) {
+	if (with_demod && fe->own_decode_stream && !fe->fold_bound) {
 		// this half's first demodulator (launched right after this kernel, on stream B) reuses the frame queue the decoder of two
-		// launches ago read: wait for it HERE, where the stream has slack, instead of in front of the demodulator
+		// launches ago read: on the demodulator-bound geometries wait for it HERE, where the stream has slack, instead of in front of
+		// the demodulator.  (Where the fold bounds the block stream A is the critical one and must not wait for a burst decoder:
+		// measured, a 4.3 ms hole in front of every inverse FFT.  There the demodulator waits itself, enqueue_demod.)
 		hipEvent_t e = fe->demod.frames_free_event();
 		if (e) HIP_TRY(hipStreamWaitEvent(fe->stream, e, 0));
 		fe->frames_wait_on_a = true;
 	}
 	const int slot0 = half * fe->half_blocks;
+	hipEvent_t ifft_start = nullptr, ifft_done = fe->ev_chan[half];
+	if (fe->timing && !fe->ev_pool.empty()) {
+		std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
+		fe->ev_pool.pop_back();
+		ifft_start = e.first; ifft_done = e.second;
+		fe->ev_ifftt.push_back(e);
+	}
+	fe->ev_chan_cur[half] = ifft_done;
 	launch_ifft_nco(g, fe->d_partial, fe->partial_stride(), fe->d_cc, fe->snap_slot(half, 0), fe->ph_slot(half, 0), fe->ph_stride(), fe->d_tw_m,
-			fe->chan_slot(slot0), fe->cnt_slot(slot0), nblk, fe->stream, fe->ev_chan[half]);
+			fe->chan_slot(slot0), fe->cnt_slot(slot0), nblk, fe->stream, ifft_done, ifft_start);
 	HIP_TRY(hipGetLastError());
 	fe->last_slot = slot0 + nblk - 1;
 	fe->last_index = nblk - 1;
@@ -821,8 +868,22 @@ static int drain_events(hfdl_gpu_frontend *fe)
 		fe->ev_pool.push_back(e);
 	}
 	fe->ev_dmt.clear();
+	struct { std::vector<std::pair<hipEvent_t, hipEvent_t>> *v; double *ms; int64_t *n; } more[] = {
+		{ &fe->ev_fftt, &fe->fft_ms, &fe->fft_timed }, { &fe->ev_ifftt, &fe->ifft_ms, &fe->ifft_timed }, { &fe->ev_dect, &fe->decode_ms, &fe->decode_timed } };
+	for (auto &m : more) {
+		for (auto &e : *m.v) {
+			float ms = 0;
+			HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+			*m.ms += ms;
+			(*m.n)++;
+			fe->ev_pool.push_back(e);
+		}
+		m.v->clear();
+	}
 	// everything is complete: the pooled events may be reused (a completed event stands for "done" as well as the half's own)
 	for (int i = 0; i < 2; i++) if (fe->ev_dm_cur[i]) fe->ev_dm_cur[i] = fe->ev_dm[i][0];
+	for (int i = 0; i < 2; i++) fe->ev_chan_cur[i] = nullptr;
+	fe->ev_fft_cur = fe->ev_fft;
 	return 0;
 }
 
@@ -913,10 +974,11 @@ extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
 	fe->fold_ms = 0; fe->fold_launches = 0; fe->fold_timed_blocks = 0; fe->fold_last_blocks = 0; fe->timing = enable != 0;
 	for (auto &c : fe->fold_shapes) c = 0;
 	fe->demod_ms = 0; fe->demod_launches = 0; fe->demod_timed_blocks = 0;
+	fe->fft_ms = fe->ifft_ms = fe->decode_ms = 0; fe->fft_timed = fe->ifft_timed = fe->decode_timed = 0;
 	if (fe->ev_first_fold) { (void)hipEventDestroy(fe->ev_first_fold); fe->ev_first_fold = nullptr; }
 	fe->span_ms = 0;
 	// enough event pairs for the launches between two drains (a sync / poll recycles them): created here, not in the timed loop
-	while (enable && fe->ev_pool.size() < 640) {
+	while (enable && fe->ev_pool.size() < 1280) {
 		std::pair<hipEvent_t, hipEvent_t> e;
 		HIP_TRY(hipEventCreate(&e.first));
 		HIP_TRY(hipEventCreate(&e.second));
@@ -961,6 +1023,16 @@ extern "C" int hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *to
 	if (total_ms) *total_ms = fe->demod_ms;
 	if (launches) *launches = fe->demod_launches;
 	if (blocks) *blocks = fe->demod_timed_blocks;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_frontend_stage_times(hfdl_gpu_frontend *fe, double ms[5], int64_t launches[5])
+{
+	if (!fe || !ms || !launches) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	ms[0] = fe->fft_ms; ms[1] = fe->fold_ms; ms[2] = fe->ifft_ms; ms[3] = fe->demod_ms; ms[4] = fe->decode_ms;
+	launches[0] = fe->fft_timed; launches[1] = fe->fold_launches; launches[2] = fe->ifft_timed; launches[3] = fe->demod_launches; launches[4] = fe->decode_timed;
 	return 0;
 }
 

@@ -35,12 +35,27 @@ struct NcoState {
 struct Geometry {
 	int32_t n, m, pre, post, scrap, post_input_size, overlap, input_size, outs;
 	int32_t slices, rows_per_slice, nch;
-	int32_t nch_pad;                   // channels the tap buffer holds: nch, rounded up to even for the pair-interleaved layout (the extra one all zero)
-	int32_t pair_layout;               // 1: taps stored pair-interleaved for the matrix-pipe fold (fold_kernels.hip); 0: plain rows (M not a multiple of 64)
-	// filter taps in HBM as the forward FFT writes them: element (channel c, alias row r, bin j) at c*tap_chan_stride + r*tap_row_stride + j
-	// (cf32 units; tap_row_stride = nch_pad * M); launch_tap_interleave() then reorders every row's channel pairs in place
+	int32_t nch_pad;                   // channels the tap buffer holds: nch rounded up to a whole group of the tap layout (the extra ones all zero)
+	int32_t tap_layout;                // TAPL_*: how an alias row of the filter taps lies in HBM (fold_kernels.hip)
+	// an alias row of ALL channels is tap_row_stride cf32 long (nch_pad * M); inside it, TAPL_PLAIN: channel c at c*tap_chan_stride,
+	// bins in order; the interleaved layouts: tap_offset_f()
 	int64_t tap_chan_stride, tap_row_stride;
 };
+
+// Filter-tap layouts.  The fold runs on the fp32 matrix pipe: one wave load of 1 KiB (16 bytes per lane) must yield, register by
+// register, operand A of an instruction -- so the taps are stored in operand order (the forward FFT that makes them writes it directly).
+//   TAPL_OCTET (default; v_mfma_f32_16x16x1_4B_f32): 8 channels x 16 bins per KiB.  lane = 2 (c % 8) + comp + 16 (j % 4), register (j / 4) % 4
+//   TAPL_PAIR  (laboratory; v_mfma_f32_4x4x1_16B_f32): 2 channels x 64 bins per KiB. lane = 4 (j % 16) + 2 (c % 2) + comp, register (j / 16) % 4
+//   TAPL_PLAIN: rows of M cf32 per channel (geometries whose M is no multiple of 16: none that create accepts)
+enum { TAPL_PLAIN = 0, TAPL_PAIR = 1, TAPL_OCTET = 2 };
+// float index of (channel c, bin j, comp 0 = Re / 1 = Im) inside an alias row of 2 * tap_row_stride floats
+__host__ __device__ inline size_t tap_offset_f(int layout, int m, int c, int j, int comp)
+{
+	if (layout == TAPL_OCTET) return (size_t)(c >> 3) * 16 * m + (size_t)(j >> 4) * 256 + (size_t)(16 * (j & 3) + 2 * (c & 7) + comp) * 4 + ((j >> 2) & 3);
+	if (layout == TAPL_PAIR) return (size_t)(c >> 1) * 4 * m + (size_t)(j >> 6) * 256 + (size_t)(4 * (j & 15) + 2 * (c & 1) + comp) * 4 + ((j >> 4) & 3);
+	return ((size_t)c * m + j) * 2 + comp;
+}
+inline int tap_layout_group(int layout) { return layout == TAPL_OCTET ? 8 : layout == TAPL_PAIR ? 2 : 1; }
 
 constexpr int FOLD_MAX_BLOCKS = 16;         // blocks one fold launch can take (four groups of four columns of the 4x4x1 matrix instruction)
 
@@ -76,11 +91,14 @@ struct DevBuf {
 // ---- launchers (host side, defined next to their kernels) ----
 // sample formats of the raw ingest path (reference: src/input-helpers.c:10-78,108-125)
 enum { SFMT_CF32 = 0, SFMT_CS16 = 1, SFMT_CU8 = 2 };
-// output index i of the transform is stored at (i >> row_log) * row_stride + (i & (2^row_log - 1)); row_log = 0: contiguous
-struct FftOutLayout { int row_log = 0; int64_t row_stride = 0; };
+// output index i of the transform is stored at (i >> row_log) * row_stride + (i & (2^row_log - 1)); row_log = 0: contiguous.
+// kind != TAPL_PLAIN: the transform is the filter of channel `chan`, `out` is the tap buffer, and element (row i >> row_log, bin) goes
+// to row * 2 * row_stride + tap_offset_f(kind, 2^row_log, chan, bin, comp) floats
+struct FftOutLayout { int row_log = 0; int64_t row_stride = 0; int kind = 0; int chan = 0; };
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
 		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay = FftOutLayout(), hipEvent_t done = nullptr,
-		NcoJob nco = NcoJob(), hipEvent_t input_read = nullptr);      // input_read: signalled when the first pass has consumed `fresh`
+		NcoJob nco = NcoJob(), hipEvent_t input_read = nullptr, hipEvent_t start = nullptr);
+		// input_read: signalled when the first pass has consumed `fresh`; start: rides on the first pass' dispatch (timing)
 // optional events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL): no separate barrier packets in the queue
 // `nb` consecutive blocks: spectra `spec_stride` cf32 apart, partial sums `partial_stride` apart; launches of at most `nb_max` blocks
 // sharing one pass over the taps.  Returns the number of kernel launches made.
@@ -92,13 +110,12 @@ int fold_variant_count();
 int fold_variant_describe(int variant, int desc[6]);            // P, Q, W, D, max blocks, 0
 int launch_fold_variant(int variant, const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial,
 		size_t partial_stride, int nb, hipStream_t st, hipEvent_t start, hipEvent_t stop);
-hipError_t launch_tap_interleave(float2 *taps, const Geometry &g, hipStream_t st);            // plain rows -> pair-interleaved, in place (create time)
 void launch_tap_extract(const float2 *taps, const Geometry &g, int channel, float2 *dst, hipStream_t st);      // one channel's taps back in plain order
 hipError_t prepare_ifft_nco(int m);     // LDS attribute of the inverse-FFT kernel for this size (checked at create time)
 // `nb` blocks in one launch (grid nch x nb): partial sums, carried-state snapshots, phasor tables [outs][nch], outputs and counts of
 // consecutive blocks lie `partial_stride` / nch / `ph_stride` / nch * outs / nch apart
 void launch_ifft_nco(const Geometry &g, const float2 *partial, size_t partial_stride, const ChanConst *cc, const NcoState *snap, const float2 *ph,
-		size_t ph_stride, const float2 *tw_m, float2 *chan_out, int *out_count, int nb, hipStream_t st, hipEvent_t done = nullptr);
+		size_t ph_stride, const float2 *tw_m, float2 *chan_out, int *out_count, int nb, hipStream_t st, hipEvent_t done = nullptr, hipEvent_t start = nullptr);
 void launch_nco_decimate(const float2 *in, int input_size, float cosdelta, float sindelta, float rate, int decimation,
 		NcoState *state, float2 *phasor_scratch, float2 *out, hipStream_t st);
 #ifdef HFDL_LAB

@@ -69,7 +69,7 @@ EXPORTS = [
     "hfdl_gpu_frontend_push_block", "hfdl_gpu_frontend_push_block_raw", "hfdl_gpu_frontend_input_done", "hfdl_gpu_frontend_input_done_upto", "hfdl_gpu_frontend_channelize_block", "hfdl_gpu_frontend_sync",
     "hfdl_gpu_frontend_poll_pdus", "hfdl_gpu_frontend_poll_pdus_ready", "hfdl_gpu_frontend_counters", "hfdl_gpu_frontend_all_channel_stats", "hfdl_gpu_frontend_stream", "hfdl_gpu_frontend_read_tap",
     "hfdl_gpu_frontend_channel_stats", "hfdl_gpu_frontend_enable_taps", "hfdl_gpu_frontend_fold_time_ms", "hfdl_gpu_frontend_demod_time_ms", "hfdl_gpu_frontend_reset_timers", "hfdl_gpu_frontend_step_period_ms", "hfdl_gpu_last_stage_ms",
-    "hfdl_gpu_frontend_fold_blocks", "hfdl_gpu_frontend_fold_launch_shapes", "hfdl_gpu_frontend_read_tap_block", "hfdl_gpu_frontend_push_baseband", "hfdl_gpu_frontend_input_copied",
+    "hfdl_gpu_frontend_fold_blocks", "hfdl_gpu_frontend_fold_launch_shapes", "hfdl_gpu_frontend_stage_times", "hfdl_gpu_frontend_read_tap_block", "hfdl_gpu_frontend_push_baseband", "hfdl_gpu_frontend_input_copied",
     "hfdl_gpu_fft_forward", "hfdl_gpu_viterbi27", "hfdl_gpu_burst_decode", "hfdl_gpu_nco_decimate", "hfdl_gpu_crc16_ccitt", "hfdl_gpu_pdu_triage", "hfdl_gpu_lpdu_walk", "hfdl_gpu_frontend_prefetch_block_raw", "hfdl_gpu_frontend_prefetch_cancel", "hfdl_gpu_psk_slice",
     "hfdl_gpu_last_error", "hfdl_gpu_device_count",
 ]
@@ -157,6 +157,7 @@ def _bind(L):
     L.hfdl_gpu_frontend_fold_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_fold_launch_shapes.argtypes = [C.c_void_p, C.POINTER(C.c_int64 * 17)]
     L.hfdl_gpu_frontend_input_copied.argtypes = [C.c_void_p, C.c_uint64]
+    L.hfdl_gpu_frontend_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 5), C.POINTER(C.c_int64 * 5)]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
     L.hfdl_gpu_fft_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
     L.hfdl_gpu_viterbi27.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -367,6 +368,12 @@ class Frontend:
         c = (C.c_int64 * 17)()
         _check(self._L.hfdl_gpu_frontend_fold_launch_shapes(self._h, C.byref(c)), self._L)
         return {nb: int(c[nb]) for nb in range(1, 17) if c[nb]}
+
+    def stage_times(self):
+        """{stage: (total ms, launches)} of the timed kernels since reset_timers(True): fft (per block), fold, ifft, demod, decode."""
+        ms, n = (C.c_double * 5)(), (C.c_int64 * 5)()
+        _check(self._L.hfdl_gpu_frontend_stage_times(self._h, C.byref(ms), C.byref(n)), self._L)
+        return {k: (ms[i], int(n[i])) for i, k in enumerate(("fft", "fold", "ifft", "demod", "decode"))}
 
     def fold_variant_probe(self, variant, nb, reps=3):
         """Laboratory build: (avg ms, best ms, checksum of the partial sums) of `reps` launches of one compiled fold tiling on `nb` blocks

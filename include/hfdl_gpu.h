@@ -261,6 +261,11 @@ int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
 /* the same for the demodulator kernel (the kernel that bounds the small geometries), from its dispatch's own start / stop events;
  * *blocks = the blocks those launches covered (a launch takes up to geometry.demod_batch blocks) */
 int  hfdl_gpu_frontend_demod_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches, int64_t *blocks);
+/* kernel time by stage since the timers were reset, from start / stop events that ride on the dispatches themselves:
+ * ms / launches [0] forward FFTs (first pass start -> last pass stop, one per block), [1] fold launches, [2] inverse FFT / NCO launches
+ * (one per half) -- together the channelizer's stream; [3] demodulator launches -- their own stream; [4] burst decoder launches -- theirs.
+ * Kernels of different streams overlap: the sums say which stream bounds a half, not what a block costs. */
+int  hfdl_gpu_frontend_stage_times(hfdl_gpu_frontend *fe, double ms[5], int64_t launches[5]);
 /* steady-state period of one block: (start of the last timed fold launch - start of the first) / (blocks folded by all timed launches
  * but the last), free of the pipeline fill before the first block and the demodulator / burst-decoder drain after the last */
 int  hfdl_gpu_frontend_step_period_ms(hfdl_gpu_frontend *fe, double *period_ms);

@@ -38,9 +38,12 @@ for nb in nbs:
         ref[nb] = fe.fold_variant_probe(-1, nb, 1)
     except hf.GpuError as e:
         print("reference kernel at %d blocks: %s" % (nb, e), file=sys.stderr)
-for v, (p, q, wv, d, nbmax, _) in enumerate(F.fold_variants()):
+only = [int(v) for v in os.environ["FOLD_VARIANTS"].split(",")] if os.environ.get("FOLD_VARIANTS") else None      # PMC passes: a few tilings only
+for v, (p, q, wv, d, nbmax, layout) in enumerate(F.fold_variants()):
+    if only is not None and v not in only:
+        continue
     for nb in nbs:
-        if nb > nbmax or nb <= nbmax // 2 and nbmax > 4:        # a tiling serves nb in (2 Q, 4 Q]
+        if nb > nbmax or (layout == 1 and nb <= nbmax // 2 and nbmax > 4):        # a 4x4x1 tiling serves nb in (2 Q, 4 Q]; a 16x16x1 tiling any nb <= 16
             continue
         try:
             avg, best, chk = fe.fold_variant_probe(v, nb, reps)
@@ -48,19 +51,19 @@ for v, (p, q, wv, d, nbmax, _) in enumerate(F.fold_variants()):
             print("variant %d skipped: %s" % (v, e), file=sys.stderr)
             continue
         byt = bench.alg_bytes_per_launch(g, nb)
-        rows.append(dict(variant=v, P=p, Q=q, W=wv, D=d, NB=nb, avg_ms=avg, best_ms=best, ms_per_block=avg / nb, GBs=byt / (avg * 1e-3) / 1e9,
+        rows.append(dict(variant=v, family="16x16x1_4B" if layout == 2 else "4x4x1_16B", P=p, Q=q, W=wv, D=d, NB=nb, avg_ms=avg, best_ms=best, ms_per_block=avg / nb, GBs=byt / (avg * 1e-3) / 1e9,
                          frac=byt / (avg * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, checksum=chk,
                          bit_identical_to_fma_reference=(chk == ref[nb][2]) if nb in ref else None))
 print("# matrix-pipe fold tilings on %s (M = %d, %d channels, %d slices x %d alias rows; %d launches each after one untimed)" %
       (wl, g.fft_inv_size, g.channels, g.fold_slices, g.pre_decimation // g.fold_slices, reps))
 print()
-print("P = channel pairs per wave, Q = groups of four blocks, W = waves per workgroup, D = rows of loads in flight.  FMA-chain reference kernel: "
+print("P = channel groups (octets / pairs) per wave, Q = groups of four blocks, W = waves per workgroup, D = rows of loads in flight.  FMA-chain reference kernel: "
       + ", ".join("%d blocks %.1f ms" % (nb, r[0]) for nb, r in sorted(ref.items())))
 print()
-print("| P | Q | W | D | NB | ms / launch (avg) | best | ms / block | algorithmic GB/s | of 8 TB/s | same bits as the FMA-chain reference |")
-print("|---|---|---|---|---|---|---|---|---|---|---|")
+print("| MFMA | P | Q | W | D | NB | ms / launch (avg) | best | ms / block | algorithmic GB/s | of 8 TB/s | same bits as the FMA-chain reference |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 for r_ in rows:
-    print("| %d | %d | %d | %d | %d | %.3f | %.3f | %.3f | %.0f | %.3f | %s |" % (r_["P"], r_["Q"], r_["W"], r_["D"], r_["NB"], r_["avg_ms"], r_["best_ms"],
+    print("| %s | %d | %d | %d | %d | %d | %.3f | %.3f | %.3f | %.0f | %.3f | %s |" % (r_["family"], r_["P"], r_["Q"], r_["W"], r_["D"], r_["NB"], r_["avg_ms"], r_["best_ms"],
                                                                         r_["ms_per_block"], r_["GBs"], r_["frac"], {True: "yes", False: "NO", None: "?"}[r_["bit_identical_to_fma_reference"]]))
 print()
 print("```json")

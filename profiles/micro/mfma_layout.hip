@@ -20,6 +20,32 @@ __global__ void probe(const float *a, const float *b, const float *c, float *d)
 	for (int i = 0; i < 4; i++) d[l * 4 + i] = acc[i];
 }
 
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_16x16x1_4B_f32: four independent 16x16 outer products per instruction
+__global__ void probe16(const float *a, const float *b, float *d)
+{
+	const int l = threadIdx.x;
+	v16f acc;
+	for (int i = 0; i < 16; i++) acc[i] = 0.f;
+	acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[l], b[l], acc, 0, 0, 0);
+	for (int i = 0; i < 16; i++) d[l * 16 + i] = acc[i];
+}
+
+__global__ void rate16(float *sink, int n)
+{
+	v16f acc[4];
+	for (int i = 0; i < 4; i++) for (int k = 0; k < 16; k++) acc[i][k] = 0.f;
+	float a = (float)threadIdx.x, b = 1.0f / (1 + threadIdx.x);
+	for (int k = 0; k < n; k++) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc[i], 0, 0, 0);
+	}
+	float s = 0;
+	for (int i = 0; i < 4; i++) s += acc[i][0] + acc[i][15];
+	if (s == 1.2345f) *sink = s;
+}
+
 // throughput: `n` dependent-free instructions per wave on 16 accumulators
 __global__ void rate(float *sink, int n)
 {
@@ -70,6 +96,50 @@ int main()
 		hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, da, db, dc, dd);
 		hipMemcpy(hd, dd, sizeof(hd), hipMemcpyDeviceToHost);
 		printf("subnormal accumulate: mfma gives %.9g, fmaf gives %.9g (%s)\n", hd[0], fmaf(1e-20f, 1e-20f, 2e-39f), hd[0] == fmaf(1e-20f, 1e-20f, 2e-39f) ? "same" : "MFMA flushes");
+	}
+	// 16x16x1 4B: hypothesis A lane i + 16 blk, B lane j + 16 blk, D[blk][i][j] in vgpr 4 blk + (i & 3) of lane 16 (i >> 2) + j
+	{
+		float ta[64], tb[64], td[1024];
+		for (int l = 0; l < 64; l++) { ta[l] = 1.0f + (float)l; tb[l] = 100.0f + 3.0f * (float)l; }
+		float *dd16;
+		hipMalloc(&dd16, sizeof(td));
+		hipMemcpy(da, ta, sizeof(ta), hipMemcpyHostToDevice); hipMemcpy(db, tb, sizeof(tb), hipMemcpyHostToDevice);
+		hipLaunchKernelGGL(probe16, dim3(1), dim3(64), 0, 0, da, db, dd16);
+		hipMemcpy(td, dd16, sizeof(td), hipMemcpyDeviceToHost);
+		int bad16 = 0;
+		for (int blk = 0; blk < 4; blk++)
+			for (int i = 0; i < 16; i++)
+				for (int j = 0; j < 16; j++) {
+					const float got = td[(16 * (i >> 2) + j) * 16 + 4 * blk + (i & 3)], want = ta[i + 16 * blk] * tb[j + 16 * blk];
+					if (got != want) { bad16++; if (bad16 <= 6) printf("16x16x1 blk %d i %d j %d: got %.1f want %.1f\n", blk, i, j, got, want); }
+				}
+		if (!bad16) printf("16x16x1_4B layout ok: A lane i + 16 blk, B lane j + 16 blk, D[blk][i][j] = vgpr 4 blk + (i & 3) of lane 16 (i >> 2) + j\n");
+		else {
+			printf("16x16x1_4B MISMATCH in %d of 1024; decoding the real layout:\n", bad16);
+			for (int v = 0; v < 16; v += 5)
+				for (int l = 0; l < 64; l += 21) {
+					const float got = td[l * 16 + v];
+					for (int blk = 0; blk < 4; blk++) for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++)
+						if (got == ta[i + 16 * blk] * tb[j + 16 * blk]) printf("  vgpr %d lane %d holds blk %d i %d j %d (if A lane i+16blk, B lane j+16blk)\n", v, l, blk, i, j);
+				}
+		}
+	}
+	{
+		hipEvent_t e0, e1;
+		hipEventCreate(&e0); hipEventCreate(&e1);
+		const int n = 4096;
+		for (int waves = 1; waves <= 2; waves++) {
+			hipLaunchKernelGGL(rate16, dim3(256 * waves), dim3(256), 0, 0, dd, 16);
+			hipEventRecord(e0, 0);
+			hipLaunchKernelGGL(rate16, dim3(256 * waves), dim3(256), 0, 0, dd, n);
+			hipEventRecord(e1, 0);
+			hipEventSynchronize(e1);
+			float ms = 0;
+			hipEventElapsedTime(&ms, e0, e1);
+			const double inst = (double)n * 4 * 4 * 256 * waves;
+			printf("16x16x1_4B rate, %d wave(s)/SIMD: %.1f G wave-inst/s = %.1f TFLOP/s (%.2f ms); at 2.4 GHz that is %.1f cycles per instruction and SIMD\n",
+					waves, inst / ms / 1e6, inst * 2048 / ms / 1e9, ms, 2.4e9 * 1024 * (ms * 1e-3) / inst);
+		}
 	}
 	// issue rate: one workgroup of 4 waves per CU
 	{

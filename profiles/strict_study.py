@@ -32,7 +32,7 @@ import low_snr_parity as L          # noqa: E402
 
 TMP = "/tmp/strict_study"
 KEY = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"].hex())
-VARIANTS = [("shipped", None)] + [("strict_%d" % f, os.path.join(ROOT, "dumphfdl_amd", "strict", "libhfdl_gpu_strict_%d.so" % f)) for f in (0, 1, 2, 4, 8, 15)]
+VARIANTS = [("shipped", None)] + [("strict_%d" % f, os.path.join(ROOT, "build", "strict", "libhfdl_gpu_strict_%d.so" % f)) for f in (0, 1, 2, 4, 8, 15)]
 FORMS = {0: "none (serial loop, shared elementary functions)", 1: "dot products in the DPP scan's order", 2: "AGC on v_log / v_exp / v_rcp",
          4: "carrier NCO on v_sin / v_cos", 8: "nearest-point slicer", 15: "all four"}
 

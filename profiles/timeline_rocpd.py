@@ -10,7 +10,7 @@ def main(db_path, blocks=2):
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     rows = cur.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else ", 0")).fetchall()
-    folds = [i for i, r in enumerate(rows) if "fold_kernel" in r[0] and "generic" not in r[0]]
+    folds = [i for i, r in enumerate(rows) if ("fold_kernel" in r[0] or "fold_mfma" in r[0]) and "generic" not in r[0]]
     if len(folds) < blocks + 2:
         print("not enough fold launches")
         return

@@ -23,6 +23,41 @@ def rel_rms(a, b):
     return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / max(np.mean(np.abs(b) ** 2), 1e-300)))
 
 
+def test_cfg1_through_the_c_host_program(gpu, oracle, tmp_path):
+    """BASELINE.json configs[0] exactly as SURVEY.md 8(d) words it (bench.WORKLOADS["cfg1"]: 250 ksps cf32 file, ONE channel at centre
+    + 37 kHz, 60 s, a single-slot 300 bps SPDU per 32 s frame, 15 dB Es/N0, seed 1) through `hfdl_replay --iq-file` -- the reference's
+    own invocation shape (README.md:876-902, src/main.c:626-651) -- against the oracle on the same file: the same PDUs, both SPDUs
+    recovered.  One channel: the fold runs its single-pair shape (the channel padded to a pair, single-wave workgroups only)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from test_gpu_parity import _replay
+    w = bench.WORKLOADS["cfg1"]
+    freqs = bench.channel_plan(w)
+    assert freqs == [w["centerfreq"] + 37_000]
+    g = F.plan_geometry(32, 250 / w["fs"])
+    x, bursts = bench.make_input(w, g.input_size, 0, 1)
+    assert len(bursts) == 2 and abs(len(x) / w["fs"] - 60.0) < 0.2
+    got = _replay(tmp_path, x.view(np.float32), "CF32", w["fs"], w["centerfreq"], freqs)
+    ora = oracle.Frontend(w["fs"], w["centerfreq"], freqs)
+    n = ora.ddc.input_size
+    assert n == g.input_size
+    for b in range(len(x) // n):
+        ora.push_block(x[b * n:(b + 1) * n])
+    want = [(p["freq"], p["bit_rate"], p["slot"], p["octets"]) for p in ora.pdus]
+    assert sorted(got) == sorted(want)
+    assert sorted(o[:66] for _, _, _, o in got) == sorted(b["octets"] for b in bursts) and all(r == 300 and s == "S" for _, r, s, _ in got)
+    # and through the C ABI directly with the bench's own checks: every PDU a sent payload, FCS good on the device
+    fe = gpu.Frontend(w["fs"], w["centerfreq"], freqs)
+    assert fe.geometry.channels == 1
+    for b in range(len(x) // n):
+        fe.push_block(x[b * n:(b + 1) * n])
+    pdus = fe.poll_pdus()
+    by_freq = {freqs[0]: bursts}
+    assert len(pdus) == 2 and all(bench.matches_sent(p, by_freq) and p["fcs_status"] == 0 for p in pdus)
+    assert sorted((p["freq"], p["sample_index"], p["mode"], p["octets"]) for p in pdus) == sorted((p["freq"], p["sample_index"], p["mode"], p["octets"]) for p in ora.pdus)
+    fe.close()
+
+
 def test_full_size_cfg4_burst_dense(gpu, oracle):
     """BASELINE.json configs[3] as bench.py runs it: 256 channels x 40 Msps, every channel back-to-back bursts cycling all
     eight modes, 32 blocks (235 M samples).  Every PDU carries a sent payload with its mode and a good on-device FCS,

@@ -1,6 +1,6 @@
 """What separates the device demodulator from the oracle, SHOWN (profiles/strict_study.py; the full table is profiles/r04/strict_study.md).
 
-Test-only builds of the library (dumphfdl_amd/csrc/build_strict.sh): `strict_0` runs the demodulator as the one-lane serial loop of
+Test-only builds of the library (dumphfdl_amd/csrc/build_strict.sh -> build/strict/, made by this test when missing): `strict_0` runs the demodulator as the one-lane serial loop of
 tests/hostsim/serial_demod.h on the fixed fp32 sequences of tests/hostsim/shared_math.h -- the arithmetic the oracle runs under
 orc_variant.shared_math; `strict_15` is the same loop with the shipped pipeline's four fast forms (DPP-order sums, hardware log / exp /
 rcp in the AGC, hardware sin / cos, nearest-point slicer) emulated operation for operation.
@@ -22,9 +22,11 @@ pytestmark = pytest.mark.gpu
 
 
 def test_strict_build_is_the_oracle_and_the_shipped_pipeline_is_strict_plus_four_fast_forms(gpu):
+    import subprocess
     import strict_study as S
-    for f in (0, 15):
-        assert os.path.exists(os.path.join(ROOT, "dumphfdl_amd", "strict", "libhfdl_gpu_strict_%d.so" % f)), "run dumphfdl_amd/csrc/build_strict.sh (__graft_entry__.build() does)"
+    if not all(os.path.exists(os.path.join(ROOT, "build", "strict", "libhfdl_gpu_strict_%d.so" % f)) for f in (0, 15)):
+        # test-only libraries, built where the test runs (hipcc cross-compiles gfx950 anywhere): never part of the product build
+        subprocess.check_call(["bash", os.path.join(ROOT, "dumphfdl_amd", "csrc", "build_strict.sh"), "0", "15"], stdout=subprocess.DEVNULL)
     out = S.run_study([-6, -2, 2], bursts_per_channel=2, builds=("shipped", "strict_0", "strict_15"))
     rows = out["rows"]
     pick = lambda build, feed, against: [r for r in rows if (r["build"], r["feed"], r["against"]) == (build, feed, against)]
