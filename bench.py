@@ -569,7 +569,7 @@ def host_ram_leg(torch, hf, F, fe, x, g, nblocks, steps):
     """SURVEY.md 8(d) "input pre-loaded in host RAM": the same blocks from page-locked host memory, the upload of block k+1
     queued while block k is pushed (hfdl_gpu_frontend_prefetch_block_raw) -- PCIe-inclusive."""
     hbuf, hpush, hprefetch = host_feed(hf, F, fe, x, g, nblocks, "cf32")
-    k2 = min(steps, 96)
+    k2 = 256          # whatever --steps says: the leg is PCIe-bound and has a ~8 ms drain (the last half's kernels after the last upload) to amortise
     # one untimed pass over EVERY block first: the first DMA out of a freshly page-locked page costs more than the later ones
     # (address translation for the device is set up as pages are first touched), and the stream is replayed several times below
     warm = max(4, nblocks)
@@ -579,8 +579,8 @@ def host_ram_leg(torch, hf, F, fe, x, g, nblocks, steps):
     hprefetch(warm % nblocks)
     el2, raw2, _ = timed_blocks(torch, fe, hpush, k2, warm, nblocks, prefetch_fn=hprefetch)
     return hbuf, dict(value=k2 * g.input_size / el2 / 1e6, unit="Msamples/s", steps=k2, ms_per_step=el2 / k2 * 1e3,
-                      path="cf32 blocks in page-locked host RAM -> hfdl_gpu_frontend_prefetch_block_raw (copy stream, two HBM staging "
-                           "buffers, one block ahead) -> hfdl_gpu_frontend_push_block_raw -> same kernels; PCIe-inclusive",
+                      path="cf32 blocks in page-locked host RAM -> hfdl_gpu_frontend_prefetch_block_raw / push_block_raw (copy stream, a ring of "
+                           "fold_batch + 2 staging buffers in HBM: uploads run a whole half ahead of the kernels) -> same kernels; PCIe-inclusive",
                       pcie_GBs=k2 * g.input_size * 8 / el2 / 1e9, pdus=sum(n for _, n in raw2))
 
 

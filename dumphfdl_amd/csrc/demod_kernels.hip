@@ -97,6 +97,9 @@ template <bool TAPS>
 __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
 		const int *__restrict__ n_in, int outs_stride, int nblk, int nch)
 {
+	// These workgroups are a handful of wavefronts that run serial recurrences beside thousands of throughput-bound ones (fold, forward
+	// FFT): whenever one of them has an instruction ready it goes first (the instruction arbiter otherwise treats all waves of a SIMD alike)
+	__builtin_amdgcn_s_setprio(3);
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const int c = blockIdx.x, tid = threadIdx.x;
 	const DemodLds L(B.cap);
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(64) void burst_decode_kernel(const FrameRec *__rest
 		hfdl_gpu_pdu *__restrict__ pdus, int pdu_cap)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	__builtin_amdgcn_s_setprio(2);          // one wavefront per frame beside the fold: first in line when it has something to issue (see demod_kernel)
 	const int f = blockIdx.x, lane = threadIdx.x;
 	int nframes = *nframes_ptr;
 	if (f == 0 && lane == 0 && stale_count) *stale_count = 0;      // the counter of the launch after next: its last users finished before this launch began

@@ -1072,7 +1072,18 @@ extern "C" int hfdl_gpu_frontend_poll_pdus_ready(hfdl_gpu_frontend *fe, hfdl_gpu
 	const int buf = fe->prev_demod_buf;
 	if (buf < 0) return 0;                              // fewer than two launches: nothing is known to be done
 	HIP_TRY(hipSetDevice(fe->device));
-	HIP_TRY(hipEventSynchronize(fe->ev_dm_cur[buf] ? fe->ev_dm_cur[buf] : fe->ev_demod[buf]));
+	{
+		hipEvent_t ev = fe->ev_dm_cur[buf] ? fe->ev_dm_cur[buf] : fe->ev_demod[buf];
+		if (max_in_flight >= 2) {
+			// no waiting at all: a caller whose flow control is elsewhere (the C host: the page-locked ring slots it leases to the
+			// uploads) only takes what is complete, and comes back
+			const hipError_t q = hipEventQuery(ev);
+			if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+			if (q != hipSuccess) return fail(HFDL_GPU_EHIP, "hipEventQuery: %s", hipGetErrorString(q));
+		} else {
+			HIP_TRY(hipEventSynchronize(ev));
+		}
+	}
 	// The snapshot slot of that half is written by its burst decoders' 16-byte copies: read it only once the last of them is known to be
 	// done (ev_demod is recorded behind it); until then the OTHER slot is the stable one -- it was written two halves ago, and the
 	// newest half's decoders, which write it next, sit behind this half's on their stream.

@@ -437,11 +437,12 @@ static void *frontend_thread(void *ctx)
 		}
 		const double tw2 = now_s();
 		s_push += tw2 - tw1;
-		/* collect what is known to be complete without draining anything: the call waits for the demodulators of the half before
-		 * the newest closed one -- that is the flow control -- while the queued uploads keep the link busy */
+		/* collect what is known to be complete without draining anything and WITHOUT waiting: what this thread may queue ahead is
+		 * bounded by the ring slots it leases to the uploads (it sleeps in release_copied() when the ring has nothing new and the
+		 * oldest upload is still running), and slots can only go back to the producer while this thread is not blocked elsewhere */
 		int32_t n = 0;
 		do {
-			if (hfdl_gpu_frontend_poll_pdus_ready(fe, pdus, max_pdus, &n, 1) != 0) break;
+			if (hfdl_gpu_frontend_poll_pdus_ready(fe, pdus, max_pdus, &n, 2) != 0) break;
 			for (int32_t i = 0; i < n; i++) push_pdu(&pdus[i], &t0);
 			npdus += (uint64_t)n;
 		} while (n == max_pdus);

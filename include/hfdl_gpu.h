@@ -185,7 +185,9 @@ int  hfdl_gpu_frontend_poll_pdus(hfdl_gpu_frontend *fe, hfdl_gpu_pdu *out, int32
 /* Same without draining the pipeline: with max_in_flight = 1 whatever was pushed since the last half filled keeps filling, the newest
  * CLOSED half (geometry.fold_batch blocks, or max(fold_batch, demod_batch)) keeps running; the call waits only for the demodulators of the
  * half before it and returns the PDUs known to be complete at that moment -- those of that half if its burst decoders have finished too,
- * otherwise they come with the next call (nothing until two halves were closed).  max_in_flight = 0 is hfdl_gpu_frontend_poll_pdus().
+ * otherwise they come with the next call (nothing until two halves were closed).  max_in_flight = 0 is hfdl_gpu_frontend_poll_pdus();
+ * max_in_flight >= 2 does not wait at all: if those demodulators are still running the call returns no PDUs (for a caller that bounds
+ * what it queues by other means -- the C host program by the ring slots it leases to the uploads).
  * A file replay pushes block k+1, then collects this way, so copies, channelizer, demodulator and burst decoder of consecutive halves
  * overlap and the fold shares its pass over the filter taps between the blocks of a half; a live receiver that has no further input
  * queued uses 0 and gets its PDUs at once. */

@@ -109,8 +109,10 @@ typedef enum {
 	INPUT_TYPE_MAX
 } input_type;
 /* libhfdl_host.so is ONE binary for both builds of the host program.  The two entry points that interpret an input_type value bind,
- * through these names, to the symbol that reads the caller's numbering -- a host program compiled against dumphfdl's own
- * input-common.h (either way) and this library agree on what cfg->type means. */
+ * THROUGH THE TWO #defines BELOW, to the symbol that reads the caller's numbering.  The rebinding lives in this header only: a
+ * WITH_SOAPYSDR host program must compile its callers of input_create() / input_vtable_register() against THIS header (in place of
+ * src/input-common.h) -- built against dumphfdl's own header it would call the plain symbols with INPUT_TYPE_FILE = 2, which the
+ * plain symbols read in the default numbering (no such type: NULL).  A default build (no SoapySDR) agrees either way. */
 #ifdef WITH_SOAPYSDR
 #define input_create          input_create_with_soapysdr
 #define input_vtable_register input_vtable_register_with_soapysdr

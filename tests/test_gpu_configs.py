@@ -54,7 +54,12 @@ def test_cfg1_through_the_c_host_program(gpu, oracle, tmp_path):
     pdus = fe.poll_pdus()
     by_freq = {freqs[0]: bursts}
     assert len(pdus) == 2 and all(bench.matches_sent(p, by_freq) and p["fcs_status"] == 0 for p in pdus)
-    assert sorted((p["freq"], p["sample_index"], p["mode"], p["octets"]) for p in pdus) == sorted((p["freq"], p["sample_index"], p["mode"], p["octets"]) for p in ora.pdus)
+    # octets, mode and frequency exactly; the detection sample of the SECOND burst may differ by a sample or two: it follows 32 s of
+    # noise through which the two implementations' timing loops have random-walked with different last-ulp roundings
+    # (tests/test_gpu_parity.py::test_long_idle_then_burst states the same bound)
+    a = sorted((p["freq"], p["mode"], p["octets"], p["sample_index"]) for p in pdus)
+    b = sorted((p["freq"], p["mode"], p["octets"], p["sample_index"]) for p in ora.pdus)
+    assert [t[:3] for t in a] == [t[:3] for t in b] and all(abs(x[3] - y[3]) <= 3 for x, y in zip(a, b)), (a, b)
     fe.close()
 
 
@@ -268,6 +273,43 @@ def test_eight_rank_rehearsal_independent_streams(tmp_path):
     else:
         assert d["backend"] == "gloo" and "share a device" in d["fallback"]
     assert all(p["frontend_create_s"] < 120 and p["input_synthesis_s"] < 120 for p in pr)
+
+
+def test_eight_rank_rehearsal_at_full_size(tmp_path):
+    """The real thing at the real size, on the one GPU of the test box: `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`
+    with the DEFAULT workload -- BASELINE.json configs[4]: eight independent 40 Msps x 256-channel streams, seeds 5 .. 12 -- eight front
+    ends of ~19 GiB each beside one another in 288 GB of HBM, eight filter-tap designs on cpus / 8 host threads each, eight 0.94 GB
+    input syntheses at once.  Eight per-rank rows in rank order, every rank's PDUs are what ITS stream carried, no rank's set-up comes
+    near HFDL_BENCH_SETUP_BUDGET_S; the wall time of the whole launch goes to gpurun_out/ for profiles/.  What the first run on an
+    8-GPU node then adds is RCCL between devices (exercised at world size 1 above) and eight times the HBM."""
+    import time
+    import torch
+    t0 = time.time()
+    r, keys = _run_bench(["--steps", "16", "--warmup", "4"], 8, 29571, tmp_path, "full8", backend="nccl")
+    wall = time.time() - t0
+    assert r["n_gpus"] == 8 and r["steps"] == 16 and r["scaling"] == "weak"
+    assert "configs[2]" in r["config"]["workload"] and r["config"]["channels"] == 256 and r["config"]["fft_size"] == 1 << 23
+    assert r["config"]["stream_seeds"] == [5, 6, 7, 8, 9, 10, 11, 12] and r["config"]["shard"] == "streams"
+    pr = r["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(8)) and [p["stream_seed"] for p in pr] == list(range(5, 13))
+    assert all(p["channels"] == 256 and p["pdus"] > 0 and p["pdus"] == p["pdus_matching_sent_payload"] and p["fold_avg_ms"] > 0 for p in pr)
+    assert sum(p["pdus"] for p in pr) == r["pdus_in_timed_region"] == sum(len(k) for k in keys)
+    assert len({tuple(sorted(k)) for k in keys}) == 8                                             # eight different streams
+    assert abs(r["value"] * 1e6 * r["ms_per_step"] * 16e-3 - 8 * 16 * 7340032) < 2000             # eight streams' samples over the slowest rank's time
+    budget = float(os.environ.get("HFDL_BENCH_SETUP_BUDGET_S", "600"))
+    worst = max(p["frontend_create_s"] + p["input_synthesis_s"] for p in pr)
+    assert worst < 0.5 * budget, (worst, pr)
+    d = r["distributed"]
+    assert d["requested"] == "nccl" and d["world_size"] == 8
+    if torch.cuda.device_count() >= 8:
+        assert d["backend"] == "nccl" and d["fallback"] is None
+    else:
+        assert d["backend"] == "gloo" and "share a device" in d["fallback"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(dict(what="torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 --steps 16 --warmup 4 (cfg3 per rank) on ONE MI355X",
+                   wall_s=round(wall, 1), value_Msamples_s=r["value"], ms_per_step=r["ms_per_step"], worst_rank_setup_s=round(worst, 1),
+                   per_rank=[{k: p[k] for k in ("rank", "stream_seed", "frontend_create_s", "input_synthesis_s", "ms_per_step", "pdus")} for p in pr],
+                   distributed=d), open(os.path.join(ROOT, "gpurun_out", "r05_eight_rank_cfg3.json"), "w"), indent=1)
 
 
 def test_eight_rank_rehearsal_one_stream_channel_sharded(tmp_path):

@@ -173,7 +173,7 @@ def test_end_to_end_small_matches_oracle(gpu, oracle):
     # (another FFT factorisation, ~1e-6 relative) is in front of it (profiles/r04/strict_study.md).  So a worst-block bound below
     # that would gate the channelizer's last bits, not the demodulator: the typical block is gated tightly, the worst one loosely, the
     # decoded octets below exactly -- and the demodulator alone in tests/test_gpu_strict.py and the oracle-fed stage test below.
-    assert np.median(worst["symbols"]) < 2e-3 and max(worst["symbols"]) < 0.3, (np.median(worst["symbols"]), max(worst["symbols"]))
+    assert np.median(worst["symbols"]) < 2e-3 and max(worst["symbols"]) < 0.1, (np.median(worst["symbols"]), max(worst["symbols"]))
     key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
     assert sorted(map(key, got)) == sorted(map(key, want))
     assert len(got) == 8
@@ -706,9 +706,13 @@ def test_host_c_program_statsd_counters(gpu, oracle, tmp_path):
 @pytest.mark.parametrize("ring", [0, 3])
 def test_collect_without_draining_the_pipeline(gpu, oracle, monkeypatch, ring):
     """hfdl_gpu_frontend_poll_pdus_ready(max_in_flight=1) after every push + one draining poll at the end delivers each
-    PDU exactly once; with a 3-entry device ring (HFDL_GPU_PDU_RING) the slots wrap many times without loss."""
+    PDU exactly once; with a 3-entry device ring (HFDL_GPU_PDU_RING) the slots wrap many times without loss -- there with one block
+    per fold / demodulator launch, so that what waits in the ring between two collections is a block's PDUs (with 16-block halves
+    the three entries would overflow by design: the ring is sized for two halves of traffic, max(4096, 64 per channel) by default)."""
     if ring:
         monkeypatch.setenv("HFDL_GPU_PDU_RING", str(ring))
+        monkeypatch.setenv("HFDL_GPU_FOLD_BATCH", "1")
+        monkeypatch.setenv("HFDL_GPU_DEMOD_BATCH", "1")
     fs, cf = 250000, 10_000_000
     freqs = [9_915_000, 9_972_000, 10_026_000, 10_083_000]
     dur = 14.0

@@ -69,6 +69,35 @@ def test_abi_exports_match_header():
     assert set(hf.frontend.EXPORTS) == declared
 
 
+def test_product_library_exports_exactly_the_public_header():
+    """`nm -D libhfdl_gpu.so`: the dynamic symbols named hfdl_gpu_* are EXACTLY the declarations of include/hfdl_gpu.h -- no probe, no
+    tiling sweep, no laboratory entry point (those live in libhfdl_gpu_lab.so, include/hfdl_gpu_lab.h) -- the product library carries
+    the kernels the front end can launch and nothing else (round 4's, with the 47-tiling sweep inside, was twice the size; half of
+    what is left are the fifteen register-resident FFT passes: three radices x three sample formats of pass 1, three of pass 2 and 3)
+    and reads no laboratory switch from the environment; the laboratory build exports the public header plus its own."""
+    def dyn(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("hfdl_gpu_")}
+    pub = set(re.findall(r"\b(hfdl_gpu_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "hfdl_gpu.h")).read())) - {"hfdl_gpu_frontend"}
+    lab = set(re.findall(r"\b(hfdl_gpu_lab_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "hfdl_gpu_lab.h")).read()))
+    prod = dyn(hf.lib_path())
+    assert prod == pub, (sorted(prod - pub), sorted(pub - prod))
+    assert not [s for s in prod if "probe" in s or "variant" in s or "_lab_" in s]
+    assert os.path.getsize(hf.lib_path()) < 700 * 1024
+    strings = subprocess.run(["strings", hf.lib_path()], capture_output=True, text=True).stdout
+    for knob in ("HFDL_GPU_FFT_STREAM", "HFDL_GPU_DECODE_STREAM", "HFDL_GPU_FOLD_TILE", "HFDL_GPU_FOLD_MFMA", "HFDL_GPU_PROBE_VERBOSE"):
+        assert knob not in strings, knob
+    for knob in ("HFDL_GPU_FOLD_BATCH", "HFDL_GPU_DEMOD_BATCH", "HFDL_GPU_HOST_THREADS", "HFDL_GPU_PDU_RING"):      # the documented create-time configuration
+        assert knob in strings, knob
+    lab_path = hf.frontend.lab_lib_path()
+    if os.path.exists(lab_path):
+        assert dyn(lab_path) == pub | lab and set(hf.frontend.LAB_EXPORTS) == lab
+    # and INTEGRATION.md names no entry point the header does not declare
+    named = set(re.findall(r"\b(hfdl_gpu_[a-z0-9_]+)\b", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    named -= {"hfdl_gpu_frontend", "hfdl_gpu_geometry", "hfdl_gpu_pdu", "hfdl_gpu_channel_stats", "hfdl_gpu_lab"}
+    assert not [n for n in named if n not in pub and n not in lab and not n.startswith("hfdl_gpu_lab")], sorted(named - pub - lab)
+
+
 def test_no_cpu_fallback_without_device():
     if hf.device_count() > 0:
         pytest.skip("a GPU is present")
