@@ -56,6 +56,7 @@ WORKLOADS = {
                  name="8 Msps cf32, 32 HFDL channels (BASELINE.json configs[1])"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (v_mfma_f32_*_f32: f32 in, f32 accumulate), same guide
 NBITS = [540, 1080, 2160, 3240, 1260, 2520, 5040, 7560]      # decoded bits = trellis steps per frame, mode 0..7 (src/hfdl.c:81-138)
 
 
@@ -792,6 +793,7 @@ def main():
     if rank == 0:
         samples = total_samples
         achieved = alg_bytes / (fold_avg_ms * 1e-3) / 1e9 if fold_n else None
+        fold_flops = 8.0 * geom["channels"] * geom["fft_size"] * fold_nb
         traffic, traffic_src = traffic_record(args.workload, [nb for nb, cnt in sorted(shapes.items()) for _ in range(cnt)], fold_n)
         par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, geom["channels"])) if args.shard == "streams" else \
               ("ONE %d-channel stream, channels round-robin over %d GPUs (%d on rank 0), every GPU ingests the same block; no collectives"
@@ -834,17 +836,27 @@ def main():
             # who bounds a half: kernel time per stream and half of `fold_batch` blocks, summed from the dispatches'
             # own events over the timed region (streams overlap: the largest is the bound, the sum is not the step)
             "streams": stream_budget(stages, args.steps, fold_batch),
-            "roofline": {"bound": "hbm", "kernel": "fold_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fold_avg_ms, "launches": fold_n,
+            # The dominant kernel: the fold.  Since round 5 it multiplies ONE pass over the filter taps into the spectra of up to 16 queued
+            # blocks on the fp32 matrix pipe, all sixteen columns of the instruction always computed: its time does not move with the blocks
+            # in a launch (4.0 ms at 4, 8 or 16) -- the multiplies bound it, at the clock the board's power budget leaves beside 4.5 TB/s of
+            # HBM reads (PMC: profiles/r05_experiments.md) -- so the roofline is the matrix pipe's; the HBM side of the same launch is `hbm`.
+            "roofline": {"bound": "mfma", "kernel": "fold_mfma16_kernel (v_mfma_f32_16x16x1_4B_f32)",
+                         "achieved": (fold_flops / (fold_avg_ms * 1e-3) / 1e12) if fold_n else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (fold_flops / (fold_avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if fold_n else None,
+                         "algorithmic_flops_per_launch": fold_flops,
+                         "flops_model": "8 flops per complex multiply-accumulate x channels x fft_size x blocks_per_launch (src/fastddc.c:114-150 run for that many blocks)",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": fold_avg_ms, "launches": fold_n, "launch_shapes": {str(k): v for k, v in sorted(shapes.items())},
                          "blocks_per_launch": fold_nb, "fold_batch": fold_batch,
-                         "model": "8*NB*input_size + C*8*N + C*8*NB*outputs_per_block per launch: NB queued blocks share ONE pass over the C*N filter "
-                                  "taps (NB = blocks_per_launch; NB = 1 is SURVEY.md 8(d)'s per-block figure, algorithmic_bytes_per_block_unbatched)",
-                         "algorithmic_bytes_per_block": alg_bytes_block, "algorithmic_bytes_per_block_unbatched": alg_bytes_unbatched,
-                         "literal_bytes_per_launch": 16 * geom["fft_size"] * (geom["channels"] + fold_nb),      # SURVEY 8(d) secondary figure, NB spectra
-                         "stream_read_GBs": stream_gbs,
-                         "frac_of_stream_read": (achieved / stream_gbs) if (achieved and stream_gbs) else None,
-                         "whole_step_frac": (alg_bytes_block / (period_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if period_ms else None},
+                         "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                                 "algorithmic_bytes_per_launch": alg_bytes,
+                                 "model": "8*NB*input_size + C*8*N + C*8*NB*outputs_per_block per launch: NB queued blocks share ONE pass over the C*N filter "
+                                          "taps (NB = blocks_per_launch; NB = 1 is SURVEY.md 8(d)'s per-block figure, algorithmic_bytes_per_block_unbatched)",
+                                 "algorithmic_bytes_per_block": alg_bytes_block, "algorithmic_bytes_per_block_unbatched": alg_bytes_unbatched,
+                                 "literal_bytes_per_launch": 16 * geom["fft_size"] * (geom["channels"] + fold_nb),      # SURVEY 8(d) secondary figure, NB spectra
+                                 "stream_read_GBs": stream_gbs,
+                                 "frac_of_stream_read": (achieved / stream_gbs) if (achieved and stream_gbs) else None,
+                                 "whole_step_frac": (alg_bytes_block / (period_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if period_ms else None}},
             "setup_s": {"frontend_create": round(t_create, 2), "input_synthesis": round(t_gen, 2)},
         }
         out.update(extra)

@@ -8,8 +8,9 @@
 //      Y_c[(h0 + j) mod M] = sum_a  H_c[a*M + j] * X[a*M + j]
 // The taps are the same for every block, so one launch multiplies them into the spectra of up to 16 queued blocks -- and with more
 // than one block the fold IS a small dense contraction per bin j:  Y[j] (channels x blocks) = H[j] (channels x alias rows) . X[j]
-// (alias rows x blocks).  It runs on the fp32 matrix pipe (v_mfma_f32_4x4x1_16B_f32: sixteen independent 4x4 outer products per
-// instruction = sixteen bins), which takes the multiply-accumulates off the vector ALUs the demodulator kernel next door lives on.
+// (alias rows x blocks).  It runs on the fp32 matrix pipe -- v_mfma_f32_16x16x1_4B_f32: four independent 16 x 16 outer products per
+// instruction = four bins x eight channels' Re / Im rows x sixteen blocks -- which takes the multiply-accumulates off the vector ALUs
+// the demodulator kernel next door lives on.  Each product is one exact fmaf, applied in a fixed order (cmac_chain below).
 #include <hip/hip_ext.h>
 #include "kernels.h"
 #include "fft_core.h"

@@ -111,9 +111,9 @@ int HostFftPlan::build(int n)
 
 struct hfdl_gpu_frontend {
 	int device = 0;
-	hipStream_t stream = nullptr;       // A: ingest + forward FFT + fold + inverse FFT/NCO of block k
-	hipStream_t stream_b = nullptr;     // B: demodulator (+ burst decoder, unless it has its own stream) of block k-1, concurrent with the fold of block k
-	hipStream_t stream_d = nullptr;     // D: burst decoder + PDU snapshot when the demodulator bounds the block (few channels); else == stream_b
+	hipStream_t stream = nullptr;       // A: forward FFTs of the half being filled, then ONE fold and ONE inverse FFT / NCO launch per half
+	hipStream_t stream_b = nullptr;     // B: demodulator launches of half k-1, beside the forward FFTs and the fold of half k
+	hipStream_t stream_d = nullptr;     // D: burst decoders + PDU snapshots, off the demodulators' critical path (== stream_b only in a laboratory A/B run)
 	bool own_decode_stream = false;
 	static constexpr int MAX_HALF = FOLD_MAX_BLOCKS;      // blocks per half at most: what one fold launch can take (16)
 	static constexpr int MAX_STAGE = MAX_HALF + 2;        // staging buffers for host input at most
@@ -127,7 +127,7 @@ struct hfdl_gpu_frontend {
 	hipEvent_t ev_fft_cur = nullptr;                        // what the held-back demodulators wait for: ev_fft, or the stop event of a timed forward FFT
 	double demod_ms = 0;
 	int64_t demod_launches = 0, demod_timed_blocks = 0;
-	hipStream_t stream_c = nullptr;     // C: host -> device copies of block k+1 into the other staging buffer
+	hipStream_t stream_c = nullptr;     // C: host -> device copies into the staging ring, up to a half ahead of the blocks that compute
 	hipStream_t stream_f = nullptr;     // F: forward FFTs of the half being filled, beside the fold of the half before (== stream when HFDL_GPU_FFT_STREAM=0)
 	bool fft_own_stream = false;
 	hipEvent_t ev_spec[2] = { nullptr, nullptr };    // newest forward FFT of the half in spectrum set 0 / 1 done (rides on its last pass)
