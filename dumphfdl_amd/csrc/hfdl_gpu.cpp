@@ -287,9 +287,12 @@ static int pick_demod_batch(const hfdl_gpu_frontend *fe)
 // catching up, the bench) the spectra of up to `fold_nb` consecutive blocks are folded in ONE pass over the taps on the matrix pipe
 // (fold_kernels.hip).  Every block's sums are bit-identical to a launch of its own (fixed FMA chain per bin); a caller that polls
 // or syncs after every block (live input) still gets one launch per block: a sync / poll closes the half as it is.
-static int pick_fold_batch()
+static int pick_fold_batch(const hfdl_gpu_frontend *fe)
 {
-	return (int)env_long("HFDL_GPU_FOLD_BATCH", 1, hfdl_gpu_frontend::MAX_HALF, 16);       // 1 = a pass over the taps per block
+	// 16 = the columns of the matrix instruction, where the fold bounds the block.  Where the demodulator does (fewer than 128
+	// channels: the taps are a few hundred MiB and a fold launch takes 0.2 ms whatever it folds) a half of 16 only adds fill,
+	// drain and latency: 8, as in round 4 (cfg2: 0.1545 against 0.1595 ms per block over 256 blocks)
+	return (int)env_long("HFDL_GPU_FOLD_BATCH", 1, hfdl_gpu_frontend::MAX_HALF, fe->fold_bound ? 16 : 8);       // 1 = a pass over the taps per block
 }
 
 static int build_taps(hfdl_gpu_frontend *fe)
@@ -466,7 +469,7 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	float resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)fe->decimation);
 	if ((rc = fe->demod.init(nch, g.outs, resamp_rate, fe->freqs.data(), fe->stream, pick_demod_batch(fe)))) { frontend_free(fe); return rc; }
 	fe->batch = fe->demod.batch;        // what fits the demodulator's LDS
-	fe->fold_nb = pick_fold_batch();
+	fe->fold_nb = pick_fold_batch(fe);
 	fe->half_blocks = std::min((int)hfdl_gpu_frontend::MAX_HALF, ((std::max(fe->fold_nb, fe->batch) + fe->fold_nb - 1) / fe->fold_nb) * fe->fold_nb);
 	fe->n_stage = fe->half_blocks + 2;
 	for (int i = 0; i < fe->n_stage; i++) {

@@ -78,7 +78,7 @@ typedef struct {
 	                                    they are pushed faster than they are collected (src/fastddc.c:123-150 run for that many blocks; the taps are
 	                                    > 99 % of a block's bytes on the 256-channel geometries).  Every block's result is bit-identical to a launch
 	                                    of its own; a poll / sync always folds what has been pushed.  HFDL_GPU_FOLD_BATCH=1..16 overrides the default
-	                                    of 16 at create time.  0 from hfdl_gpu_plan_geometry() */
+	                                    (16 from 128 channels up, where the fold bounds the block; 8 below) at create time.  0 from hfdl_gpu_plan_geometry() */
 	int32_t prefetch_depth;          /* host blocks whose upload hfdl_gpu_frontend_prefetch_block_raw() may queue ahead of their push
 	                                    (fold_batch + 1: a staging ring of fold_batch + 2 buffers in HBM); at most HFDL_GPU_PREFETCH_MAX.
 	                                    0 from hfdl_gpu_plan_geometry() */

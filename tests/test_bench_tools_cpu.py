@@ -52,7 +52,10 @@ def test_committed_traffic_records_match_the_committed_kernels():
             "`gpurun -- bash profiles/pmc_passes.sh %s gpurun_out/final <commit>` and copy the record into profiles/" % (wl, wl, wl)
         assert set(rec["per_shape"]) >= {"16", "4"}            # the driver's --steps 20 = 16 + 4
     r3 = json.load(open(os.path.join(bench.ROOT, "profiles", "fold_traffic_cfg3.json")))
-    assert r3["per_shape"]["16"]["traffic_over_algorithmic"] <= 1.05          # no wasted re-reads on the roofline kernel
+    # no wasted re-reads on the roofline kernel: reads = the algorithmic bytes; the excess is the partial sums of 16 blocks (0.54 GB,
+    # not in the model, written in 32-byte pieces: 1.1 GB measured) -- 3 - 7 % of a launch whose bound is the matrix pipe, not HBM
+    assert r3["per_shape"]["16"]["traffic_over_algorithmic"] <= 1.10
+    assert r3["per_shape"]["16"]["hbm_read_bytes_per_launch"] <= 1.02 * r3["per_shape"]["16"]["algorithmic_bytes_per_launch"]
 
 
 def test_xcd_aware_tile_placement_is_a_bijection():

@@ -759,7 +759,7 @@ def test_prefetched_uploads_same_pdus(gpu, oracle):
     n = fe.input_size
     nb = len(x) // n
     depth = fe.geometry.prefetch_depth
-    assert depth == fe.geometry.fold_batch + 1 and nb > 3 * depth
+    assert depth == fe.geometry.fold_batch + 1 == 9 and nb > 3 * depth          # 4 channels: halves of 8 blocks, a staging ring of 10
     hbuf = gpu.host_alloc(raw.nbytes)
     ctypes.memmove(hbuf, raw.ctypes.data, raw.nbytes)
     ptr = lambda b: hbuf + 4 * b * n
@@ -972,6 +972,7 @@ def test_fold_mfma_equals_fma_chain(gpu, monkeypatch, fs, nch, family):
     lab = F.load_lab()
     monkeypatch.setenv("HFDL_GPU_FOLD_MFMA", str(family))
     freqs = [int(cf + (i - nch // 2) * (15_000 if nch > 5 else 40_000) + 4_000) for i in range(nch)]
+    monkeypatch.setenv("HFDL_GPU_FOLD_BATCH", "16")
     fe = gpu.Frontend(fs, cf, freqs, lib=lab)
     g = fe.geometry
     assert g.fold_batch == 16
