@@ -253,6 +253,11 @@ def parity_gate(w, x, input_size, hf, dev_index, cores, max_seconds=25.0):
     want = sorted(pdu_key(p) for p in ora.pdus)
     fe.close()
     ora.close()
+    # the same comparison with the detection sample allowed to differ by <= 3 (of 5400 per second): after tens of seconds of noise only
+    # -- cfg1's 32 s between bursts -- the two implementations' timing loops have random-walked with different last-ulp roundings and
+    # can find the same frame, octet for octet, a sample or two apart (tests/test_gpu_parity.py::test_long_idle_then_burst)
+    loose = lambda ks: sorted((k[0], k[2], k[3], k[1]) for k in ks)
+    near = len(got) == len(want) and all(a[:3] == b[:3] and abs(a[3] - b[3]) <= 3 for a, b in zip(loose(got), loose(want)))
     # ... and where "identical" stops: the same comparison on traffic binned by in-channel SNR (64 channels at 1 Msps, 128 bursts per
     # bin, all eight modes; the full sweep -8 .. +10 dB is tests/test_gpu_low_snr.py)
     low = None
@@ -268,6 +273,7 @@ def parity_gate(w, x, input_size, hf, dev_index, cores, max_seconds=25.0):
                 low_snr_bins=low,
                 chan_out_rel_rms=worst, chan_out_rel_rms_limit=1e-4, chan_out_within_limit=bool(worst <= 1e-4),
                 gpu_pdus=len(got), cpu_pdus=len(want), pdu_multisets_identical=bool(got == want),
+                pdu_multisets_identical_up_to_3_samples_of_detection=bool(near),
                 compared="(freq, sample_index, mode, octets) of every PDU both sides dispatched on these channels and blocks")
 
 

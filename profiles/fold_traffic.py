@@ -84,7 +84,7 @@ out.update({
     "measured_at_commit": commit,
     "csrc_sha16": csrc_now,
     "command": "profiles/pmc_passes.sh %s (rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --workload %s --steps 36 --warmup 8 "
-               "--no-cpu-baseline --no-extra-legs: fold launches of %s blocks; second pass --pmc WRITE_SIZE; third --pmc TCC_HIT_sum TCC_MISS_sum)" % (wl, wl, shapes_arg),
+               "--no-cpu-baseline --no-extra-legs: fold launches of %s blocks in that order; second pass --pmc WRITE_SIZE; third --pmc TCC_HIT_sum TCC_MISS_sum)" % (wl, wl, shapes_arg),
     "gfx950_fetch_correction": round(corr, 4),
     "correction_calibration": "same run: stream_read_kernel reads exactly %d bytes and reports FETCH_SIZE = %.1f KB (x %.3f); "
                               "WRITE_SIZE uncorrected (fft passes write 8 N bytes and report that)" % (probe_bytes, sum(probe) / max(len(probe), 1), corr),

@@ -7,6 +7,9 @@
 WL=${1:-cfg3}
 OUT=${2:-/root/repo/gpurun_out/pmc_$WL}
 COMMIT=${3:-unknown}
+# fold launches of the profiled command in launch order: the warm-up's 8 blocks (closed by a poll), then the 36 timed ones in halves of
+# 16 (cfg3 / cfg4: the fold bounds the block) or 8 (cfg2: the demodulator does)
+if [ "$WL" = "cfg2" ]; then SHAPES=8,8,8,8,8,4; else SHAPES=8,16,16,4; fi
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_${WL}_*
@@ -22,5 +25,5 @@ DBS=$(find /tmp/pmc_${WL}_* -name "*.db" | sort)
 	echo
 	python /root/repo/profiles/pmc_summary.py $DBS
 } > $OUT/${WL}_pmc_counters.md
-python /root/repo/profiles/fold_traffic.py $WL $COMMIT 8,16,16,4 $DBS > $OUT/fold_traffic_${WL}.json || { echo "fold_traffic refused"; rm -f $OUT/fold_traffic_${WL}.json; }
+python /root/repo/profiles/fold_traffic.py $WL $COMMIT $SHAPES $DBS > $OUT/fold_traffic_${WL}.json || { echo "fold_traffic refused"; rm -f $OUT/fold_traffic_${WL}.json; }
 cat $OUT/fold_traffic_${WL}.json

@@ -50,7 +50,7 @@ def test_committed_traffic_records_match_the_committed_kernels():
         assert rec["csrc_sha16"] == bench.csrc_hash(), \
             "%s: dumphfdl_amd/csrc changed since profiles/fold_traffic_%s.json was measured -- commit, run profiles/stamp.sh, then " \
             "`gpurun -- bash profiles/pmc_passes.sh %s gpurun_out/final <commit>` and copy the record into profiles/" % (wl, wl, wl)
-        assert set(rec["per_shape"]) >= {"16", "4"}            # the driver's --steps 20 = 16 + 4
+        assert set(rec["per_shape"]) >= ({"8", "4"} if wl == "cfg2" else {"16", "4"})            # the driver's --steps 20 = 16 + 4 (cfg2: 8 + 8 + 4)
     r3 = json.load(open(os.path.join(bench.ROOT, "profiles", "fold_traffic_cfg3.json")))
     # no wasted re-reads on the roofline kernel: reads = the algorithmic bytes; the excess is the partial sums of 16 blocks (0.54 GB,
     # not in the model, written in 32-byte pieces: 1.1 GB measured) -- 3 - 7 % of a launch whose bound is the matrix pipe, not HBM
