@@ -639,6 +639,71 @@ def cfg2_leg(torch, hf, F, dev_index, steps=256, warmup=8):
                 value_host_ram=host["value"], host_ram_input=host)
 
 
+PRUNE_TOL = 3e-7          # what the skipped alias rows may hold of a filter's energy, as an amplitude ratio (the taps' own rounding noise: 2.1e-7)
+
+
+def pruned_fold_leg(torch, hf, F, w, freqs, x, dev_index, steps, warmup, ref_pdus):
+    """The OPT-IN pruned fold (HFDL_GPU_FOLD_PRUNE, include/hfdl_gpu.h) next to the headline: the same workload, the same blocks, the
+    same timed loop with a front end that folds only the alias rows around each channel's pass band.  `value` of the bench line is
+    NOT this figure: the default folds every row, as the reference does.  Checked here, in the same run: the channelizer output of
+    ten channels against a full-fold front end on the same block (relative RMS), and the PDUs of the timed region against those of
+    the headline run (ref_pdus: same blocks in the same order)."""
+    watch = [c for c in (0, 1, 7, 8, 100, 127, 128, 200, 254, 255) if c < len(freqs)]
+
+    def create(tol):
+        if tol:
+            os.environ["HFDL_GPU_FOLD_PRUNE"] = repr(tol)
+        try:
+            fe = hf.Frontend(w["fs"], w["centerfreq"], freqs, device=dev_index)
+        finally:
+            os.environ.pop("HFDL_GPU_FOLD_PRUNE", None)
+        return fe
+
+    fe = create(0)
+    g = fe.geometry
+    fe.channelize_block(x[:g.input_size])
+    full = [fe.read_tap(F.TAP_CHAN_OUT, c).astype(np.complex128) for c in watch]
+    fe.close()
+    fe = create(PRUNE_TOL)
+    g = fe.geometry
+    fe.channelize_block(x[:g.input_size])
+    err = max(float(np.sqrt(np.mean(np.abs(fe.read_tap(F.TAP_CHAN_OUT, c) - f) ** 2) / np.mean(np.abs(f) ** 2))) for c, f in zip(watch, full))
+    fe.close()
+    fe = create(PRUNE_TOL)
+    fe.enable_taps(False)
+    nblocks = len(x) // g.input_size
+    dev = torch.from_numpy(x.view(np.float32)).cuda()
+    ptrs = [dev.data_ptr() + 8 * b * g.input_size for b in range(nblocks)]
+    push = lambda i: fe.push_block(ptrs[i])
+    step = 0
+    for _ in range(warmup):
+        push(step % nblocks); step += 1
+    fe.poll_pdus()
+    fe.reset_timers(True)
+    torch.cuda.synchronize()
+    el, raw, step = timed_blocks(torch, fe, push, steps, step, nblocks)
+    pdus = [p for buf, n in raw for p in fe.pdus_to_dicts(buf, n)]
+    fold_ms, fold_n = fe.fold_time_ms()
+    dm_ms, dm_n, dm_blk = fe.demod_time_ms()
+    period = fe.step_period_ms()
+    stages = fe.stage_times()
+    fe.reset_timers(False)
+    fe.close()
+    del dev
+    key = lambda p: (p["freq"], p["mode"], p["octets"], p["fcs_status"])
+    a = sorted(ref_pdus, key=lambda p: (p["freq"], p["sample_index"]))
+    b = sorted(pdus, key=lambda p: (p["freq"], p["sample_index"]))
+    same = len(a) == len(b) and [key(p) for p in a] == [key(p) for p in b]
+    return dict(what="opt-in (HFDL_GPU_FOLD_PRUNE=%g): only the alias rows outside which a channel's filter holds < tol^2 of its energy are folded; "
+                     "NOT the headline -- `value` folds every row, as src/fastddc.c:123-150 does" % PRUNE_TOL,
+                tolerance=PRUNE_TOL, fold_rows=g.fold_rows, of_rows=g.pre_decimation,
+                value=steps * g.input_size / el / 1e6, unit="Msamples/s", steps=steps, ms_per_step=el / steps * 1e3, steady_state_ms_per_step=period,
+                fold_kernel_avg_ms=(fold_ms / fold_n) if fold_n else None, demod_kernel_ms_per_block=(dm_ms / dm_blk) if dm_blk else None,
+                streams=stream_budget(stages, steps, g.fold_batch),
+                chan_out_rel_rms_vs_full_fold=err, pdus=len(pdus), pdus_same_as_full_fold=same,
+                detection_sample_max_abs_diff=(max([abs(p["sample_index"] - q["sample_index"]) for p, q in zip(a, b)] or [0]) if same else None))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -873,6 +938,11 @@ def main():
                     out["cfg2"] = cfg2_leg(torch, hf, F, dev_index)
                 except Exception as e:                  # noqa: BLE001 -- a secondary leg never takes the headline line down
                     out["cfg2"] = dict(error="%s: %s" % (type(e).__name__, e))
+            if args.workload in ("cfg3", "cfg4") and not args.host_input:
+                try:
+                    out["pruned_fold"] = pruned_fold_leg(torch, hf, F, w, freqs, x, dev_index, args.steps, args.warmup, pdus)
+                except Exception as e:                  # noqa: BLE001
+                    out["pruned_fold"] = dict(error="%s: %s" % (type(e).__name__, e))
         if solo and not args.no_cpu_baseline:
             cores = max(1, min(os.cpu_count() or 1, 64))
             out["parity"] = parity_gate(w, x, geom["input_size"], hf, dev_index, cores)

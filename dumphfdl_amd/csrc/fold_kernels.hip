@@ -86,11 +86,15 @@ constexpr int fold16_waves(int p, int w, int d)
 // of block n), written to LDS and read from there by all waves.  Per alias row and wave: P tap loads of 1 KiB (non-temporal), two LDS
 // reads, 4 P vector instructions (the rotated operand) and 8 P matrix instructions: first every accumulator's Re(X) product, then every
 // Im(X) product.  Loads run D rows ahead, the spectrum tile one row ahead through two LDS stages, one barrier per row.
-template <int P, int W, int D>
+// WIN (the pruned fold, hfdl_gpu.h HFDL_GPU_FOLD_PRUNE): a workgroup folds only the window of alias rows `win[group]` = (first row,
+// count) around its channels' pass bands -- circular, one slice, rows = all alias rows -- instead of a slice of all of them.
+template <int P, int W, int D, bool WIN = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_waves(P, W, D), fold16_waves(P, W, D)))) void fold_mfma16_kernel(
 		const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
-		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int octet_base, int nch, int nb)
+		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int octet_base, int nch, int nb,
+		const int2 *__restrict__ win = nullptr)
 {
+	static_assert(!WIN || W == 1, "windows are per wave: no spectrum tile is shared");
 	static_assert(D == 2 || D == 4, "the LDS stage of a trip is a compile-time constant for even D");
 	// a row's spectrum tile = 4 pieces of 512 B (bin-set v = 0 .. 3: lane n + 16 blk <- bin 4 v + blk of block n).  EVERY wave fetches
 	// MINE of them -- with more than four waves the upper ones fetch (and store) what the lower ones do -- so that all waves issue the
@@ -115,6 +119,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 	const int n = lane & 15, blk = lane >> 4;
 	const int octet0 = octet_base + (grp * W + wave) * P;
 	const int sign_mask = (lane & 1) ? 0 : (int)0x80000000;
+	int next_row = 0, trips = rows;                           // WIN: the next row to ask for (circular), rows in the window
+	if constexpr (WIN) {
+		const int2 wn = win[(octet0 - octet_base) / P];
+		next_row = __builtin_amdgcn_readfirstlane(wn.x);
+		trips = __builtin_amdgcn_readfirstlane(wn.y);
+	}
 	const char *tb = (const char *)(taps + (size_t)s * rows * row_stride_f + (size_t)octet0 * 16 * m + (size_t)g * 256) + lane * 16;
 	const size_t rs_b = row_stride_f * 4, os_b = (size_t)m * 64, xrow_b = (size_t)m * 8;
 	const int v0 = (wave * MINE) & 3;                         // this wave's first piece
@@ -123,6 +133,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 		const int bi = n < nb ? n : nb - 1;                   // columns past the last block repeat it; they are never stored
 		xp = (const char *)(spec + (size_t)bi * spec_stride + (size_t)s * rows * (size_t)m + g * 16 + 4 * v0 + blk);
 	}
+	const char *const tb0 = tb, *const xp0 = xp;
 	v16f acc[P][4];
 #pragma unroll
 	for (int p = 0; p < P; p++)
@@ -133,12 +144,19 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 	v4f h[D][P];
 	v2f xs[D][MINE];
 	auto issue = [&](int slot) {               // the loads of the next row not yet asked for: spectrum share first, then the taps
+		if constexpr (WIN) {                   // no branch: the row index wraps by a scalar select
+			tb = tb0 + (size_t)next_row * rs_b;
+			xp = xp0 + (size_t)next_row * xrow_b;
+			next_row = next_row + 1 == rows ? 0 : next_row + 1;
+		}
 #pragma unroll
 		for (int i = 0; i < MINE; i++) xs[slot][i] = *(const v2f *)(xp + 32 * i);       // consecutive bin-sets: four bins apart
-		xp += xrow_b;
 #pragma unroll
 		for (int p = 0; p < P; p++) h[slot][p] = __builtin_nontemporal_load((const v4f *)(tb + (size_t)p * os_b));
-		tb += rs_b;
+		if constexpr (!WIN) {
+			xp += xrow_b;
+			tb += rs_b;
+		}
 	};
 	auto stash = [&](int slot, int stage) {
 #pragma unroll
@@ -167,7 +185,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 	}
 	stash(0, 0);
 	__syncthreads();
-	for (int r = 0; r < rows - D; r += D) {
+	for (int r = 0; r < trips - D; r += D) {
 #pragma unroll
 		for (int d = 0; d < D; d++) {
 			multiply(d, d & 1);
@@ -417,12 +435,32 @@ static int fold16_go(const FoldArgs &a)
 	int launches = 0;
 	if (groups > 0) {
 		hipExtLaunchKernelGGL((fold_mfma16_kernel<P, W, D>), dim3((unsigned)(groups * ntile)), dim3(64 * W), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
-			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, 0, a.nch, a.nb);
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, 0, a.nch, a.nb, (const int2 *)nullptr);
 		launches++;
 	}
 	if (rest > 0) {
 		hipExtLaunchKernelGGL((fold_mfma16_kernel<1, 1, D>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
-			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, groups * P * W, a.nch, a.nb);
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, groups * P * W, a.nch, a.nb, (const int2 *)nullptr);
+		launches++;
+	}
+	return launches;
+}
+
+// the pruned fold: single-wave workgroups of two octets (their row window: win2), a left-over octet with its own (win1); one slice
+template <int D>
+static int fold16_go_win(const FoldArgs &a, const int2 *win2, const int2 *win1)
+{
+	const int ntile = a.m >> 4;
+	const int groups = a.ngroups / 2, rest = a.ngroups - groups * 2;
+	int launches = 0;
+	if (groups > 0) {
+		hipExtLaunchKernelGGL((fold_mfma16_kernel<2, 1, D, true>), dim3((unsigned)(groups * ntile)), dim3(64), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, 1, a.rows, 0, a.nch, a.nb, win2);
+		launches++;
+	}
+	if (rest > 0) {
+		hipExtLaunchKernelGGL((fold_mfma16_kernel<1, 1, D, true>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, 1, a.rows, groups * 2, a.nch, a.nb, win1);
 		launches++;
 	}
 	return launches;
@@ -532,11 +570,33 @@ int launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, s
 		const float2 *sp = spectrum + (size_t)done * spec_stride;
 		float2 *pp = partial + (size_t)done * partial_stride;
 		const FoldVariant *f = pick_variant(g, take);
-		if (f) launches += f->go(fold_args(g, taps, sp, spec_stride, pp, partial_stride, take, st, first ? start : nullptr, last ? stop : nullptr));
+		if (g.fold_win2 && g.tap_layout == TAPL_OCTET) launches += fold16_go_win<4>(fold_args(g, taps, sp, spec_stride, pp, partial_stride, take, st, first ? start : nullptr, last ? stop : nullptr), g.fold_win2, g.fold_win1);
+		else if (f) launches += f->go(fold_args(g, taps, sp, spec_stride, pp, partial_stride, take, st, first ? start : nullptr, last ? stop : nullptr));
 		else { launch_fold_ref(g, taps, sp, spec_stride, pp, partial_stride, take, st, first ? start : nullptr, last ? stop : nullptr); launches++; }
 		done += take;
 	}
 	return launches;
+}
+
+// energy of every (alias row, channel) of the octet-interleaved taps: one workgroup per (row, octet) walks the row's M / 16 chunks of
+// 1 KiB (lane = 2 (c % 8) + comp + 16 blk: the eight lanes of a channel add into one cell)
+__global__ __launch_bounds__(FOLD_THREADS) void tap_row_energy_kernel(const float *__restrict__ taps, float *__restrict__ energy, size_t row_stride_f, int m, int noct, int nch_pad)
+{
+	const int oct = blockIdx.x % noct, row = blockIdx.x / noct;
+	const v4f *base = (const v4f *)(taps + (size_t)row * row_stride_f + (size_t)oct * 16 * m);
+	float acc = 0.f;
+	for (int e = threadIdx.x; e < (m >> 4) * 64; e += FOLD_THREADS) {       // float4 index: chunk * 64 + lane
+		const v4f v = base[e];
+		acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+	}
+	const int lane = threadIdx.x & 63;            // FOLD_THREADS is a multiple of 64: a thread keeps its lane position over the chunks
+	atomicAdd(energy + (size_t)row * nch_pad + oct * 8 + ((lane & 15) >> 1), acc);
+}
+
+void launch_tap_row_energy(const float2 *taps, const Geometry &g, float *energy, hipStream_t st)
+{
+	const int noct = g.nch_pad / 8;
+	hipLaunchKernelGGL(tap_row_energy_kernel, dim3((unsigned)(g.pre * noct)), dim3(FOLD_THREADS), 0, st, (const float *)taps, energy, (size_t)g.tap_row_stride * 2, g.m, noct, g.nch_pad);
 }
 
 // filter taps of one channel back in plain order (HFDL_GPU_TAP_FILTER): dst[N] cf32

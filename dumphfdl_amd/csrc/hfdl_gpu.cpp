@@ -176,6 +176,9 @@ struct hfdl_gpu_frontend {
 	size_t partial_stride() const { return (size_t)geo.nch * (size_t)geo.slices * (size_t)geo.m; }
 	size_t ph_stride() const { return (size_t)geo.nch * (size_t)geo.outs; }
 	ChanConst *d_cc = nullptr;
+	int2 *d_win2 = nullptr, *d_win1 = nullptr;       // pruned fold: row windows per pair of octets / per octet (kernels.h Geometry::fold_win*)
+	double prune_tol = 0.0;             // HFDL_GPU_FOLD_PRUNE: share of a filter's energy (as an amplitude ratio) the skipped alias rows may hold; 0 = fold every row
+	int fold_rows_max = 0;              // the longest row window (0: every row is folded)
 	NcoState *d_nco = nullptr;          // [nch] carried NCO state, owned by the forward FFT's rider workgroups (kernels.h NcoJob)
 	NcoState *d_nco_snap = nullptr;     // [half_blocks][nch] the state each block of the half starts from
 	float2 *d_ph = nullptr, *d_ph_cont = nullptr;      // [half_blocks] NCO phasor tables [outs][nch] and the riders' segment hand-over [nch]
@@ -226,7 +229,7 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	fe->demod.release();
 	fe->fft.release();
 	void *ptrs[] = { fe->d_hist[0], fe->d_hist[1], fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_all, fe->d_tw_m,
-		fe->d_cc, fe->d_nco, fe->d_nco_snap, fe->d_ph, fe->d_ph_cont, fe->d_cnt_all };
+		fe->d_cc, fe->d_nco, fe->d_nco_snap, fe->d_ph, fe->d_ph_cont, fe->d_cnt_all, fe->d_win2, fe->d_win1 };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (float2 *p : fe->d_stage) if (p) (void)hipFree(p);
 	if (fe->stream) (void)hipStreamDestroy(fe->stream);
@@ -293,6 +296,79 @@ static int pick_fold_batch(const hfdl_gpu_frontend *fe)
 	// channels: the taps are a few hundred MiB and a fold launch takes 0.2 ms whatever it folds) a half of 16 only adds fill,
 	// drain and latency: 8, as in round 4 (cfg2: 0.1545 against 0.1595 ms per block over 256 blocks)
 	return (int)env_long("HFDL_GPU_FOLD_BATCH", 1, hfdl_gpu_frontend::MAX_HALF, fe->fold_bound ? 16 : 8);       // 1 = a pass over the taps per block
+}
+
+static double env_double(const char *name, double lo, double hi, double otherwise)
+{
+	const char *e = getenv(name);
+	if (!e || !*e) return otherwise;
+	char *end = nullptr;
+	const double v = strtod(e, &end);
+	return (end != e && v >= lo && v <= hi) ? v : otherwise;
+}
+
+// The pruned fold (HFDL_GPU_FOLD_PRUNE = tolerance).  A channel's filter is a band-pass M / 2 bins wide with a Hamming-window stop band:
+// of the p = N / M alias rows the fold adds up, all but the few around the pass band hold taps below fp32 resolution of the sum (cfg3:
+// rows 32 or more from the pass band hold 3.7e-8 of the filter's energy as an amplitude ratio -- less than half an ulp; DESIGN.md section
+// 9).  From the taps themselves: per channel the smallest window of rows around the pass band outside which less than tol^2 of the
+// filter's energy lies; a workgroup of two octets (or the left-over octet) folds the circular hull of its channels' windows, rounded
+// up to whole look-ahead groups of 4 rows.
+static int build_fold_windows(hfdl_gpu_frontend *fe)
+{
+	Geometry &g = fe->geo;
+	const int p = g.pre, npad = g.nch_pad, nch = g.nch;
+	DevBuf d_en;
+	HIP_TRY(d_en.alloc(sizeof(float) * (size_t)p * (size_t)npad));
+	HIP_TRY(hipMemsetAsync(d_en.p, 0, sizeof(float) * (size_t)p * (size_t)npad, fe->stream));
+	launch_tap_row_energy(fe->d_taps, g, d_en.as<float>(), fe->stream);
+	std::vector<float> en((size_t)p * (size_t)npad);
+	HIP_TRY(hipMemcpyAsync(en.data(), d_en.p, sizeof(float) * en.size(), hipMemcpyDeviceToHost, fe->stream));
+	HIP_TRY(hipStreamSynchronize(fe->stream));
+	// per channel: the window grows from the row that holds the most energy, towards the richer neighbour, until the rows outside
+	// hold less than tol^2 of the total (rows picked by energy alone would scatter: the fp32 transform that made the taps left its
+	// rounding noise in every row, and the largest noise rows lie anywhere)
+	std::vector<std::vector<char>> keep((size_t)npad, std::vector<char>((size_t)p, 0));
+	for (int c = 0; c < nch; c++) {
+		double tot = 0;
+		int peak = 0;
+		for (int r = 0; r < p; r++) { tot += en[(size_t)r * npad + c]; if (en[(size_t)r * npad + c] > en[(size_t)peak * npad + c]) peak = r; }
+		auto e_at = [&](int r) { return (double)en[(size_t)((r % p + p) % p) * npad + c]; };
+		int lo = peak, hi = peak;                         // window [lo, hi], indices unwrapped
+		double left = tot - e_at(peak);
+		while (hi - lo + 1 < p && left > fe->prune_tol * fe->prune_tol * tot) {
+			if (e_at(lo - 1) > e_at(hi + 1)) left -= e_at(--lo); else left -= e_at(++hi);
+		}
+		for (int r = lo; r <= hi; r++) keep[(size_t)c][(size_t)((r % p + p) % p)] = 1;
+	}
+	auto hull = [&](int c0, int c1) {                   // circular hull of the rows kept by channels [c0, c1)
+		std::vector<char> any((size_t)p, 0);
+		int kept = 0;
+		for (int c = c0; c < c1; c++) for (int r = 0; r < p; r++) if (keep[(size_t)c][(size_t)r] && !any[(size_t)r]) { any[(size_t)r] = 1; kept++; }
+		if (kept == 0) return make_int2(0, 4);           // channels that only fill the octet up: zero taps, any four rows
+		int best_len = 0, best_end = 0;                  // the longest circular run of rows nobody keeps
+		for (int r = 0; r < p; r++) {
+			if (any[(size_t)r] || !any[(size_t)((r + p - 1) % p)]) continue;      // r = first row of a gap
+			int len = 0;
+			while (len < p && !any[(size_t)((r + len) % p)]) len++;
+			if (len > best_len) { best_len = len; best_end = (r + len) % p; }
+		}
+		int count = p - best_len;
+		count = std::min(p, (count + 3) & ~3);
+		return make_int2(best_len ? best_end : 0, count);
+	};
+	const int noct = npad / 8, npair = noct / 2;
+	std::vector<int2> w2((size_t)std::max(npair, 1)), w1((size_t)std::max(noct, 1));
+	fe->fold_rows_max = 0;
+	for (int i = 0; i < npair; i++) { w2[(size_t)i] = hull(16 * i, 16 * i + 16); fe->fold_rows_max = std::max(fe->fold_rows_max, w2[(size_t)i].y); }
+	for (int i = 0; i < noct; i++) w1[(size_t)i] = hull(8 * i, 8 * i + 8);
+	if (noct & 1) fe->fold_rows_max = std::max(fe->fold_rows_max, w1[(size_t)(noct - 1)].y);
+	// fold_mfma16_kernel<1, 1, D, true> indexes win1 from ITS first octet: the left-over octet is entry 0 of what it is given
+	HIP_TRY(hipMalloc(&fe->d_win2, sizeof(int2) * w2.size()));
+	HIP_TRY(hipMalloc(&fe->d_win1, sizeof(int2) * 1));
+	HIP_TRY(hipMemcpy(fe->d_win2, w2.data(), sizeof(int2) * w2.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(fe->d_win1, &w1[(size_t)(noct - 1)], sizeof(int2), hipMemcpyHostToDevice));
+	g.fold_win2 = fe->d_win2; g.fold_win1 = fe->d_win1;
+	return 0;
 }
 
 static int build_taps(hfdl_gpu_frontend *fe)
@@ -396,6 +472,10 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	fe->tap_layout.kind = g.tap_layout;
 	fe->tap_layout.row_log = ilog2(pl.m); fe->tap_layout.row_stride = g.tap_row_stride;
 	g.slices = pick_slices(nch, pl.pre);
+	// HFDL_GPU_FOLD_PRUNE=tol (0 < tol <= 1e-3; unset: every alias row is folded, the reference's sum term for term): fold only the
+	// rows around each channel's pass band (build_fold_windows) -- one slice, the windows are the parallelism
+	fe->prune_tol = (pl.m % 16) == 0 && pl.pre >= 8 ? env_double("HFDL_GPU_FOLD_PRUNE", 1e-12, 1e-3, 0.0) : 0.0;
+	if (fe->prune_tol > 0) g.slices = 1;
 	g.rows_per_slice = pl.pre / g.slices;
 	if (pl.m > 8192 || pl.m < 16) { delete fe; return fail(HFDL_GPU_ERANGE, "inverse FFT size %d unsupported", pl.m); }
 
@@ -431,6 +511,7 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 		fe->fold_bound = nch >= 128;
 		fe->own_decode_stream = true;
 #ifdef HFDL_LAB
+		fe->fold_bound = env_long("HFDL_GPU_FOLD_BOUND", 0, 1, fe->fold_bound ? 1 : 0) != 0;
 		fe->own_decode_stream = env_long("HFDL_GPU_DECODE_STREAM", 0, 1, 1) != 0;
 #endif
 		if (fe->own_decode_stream) FE_TRY(hipStreamCreateWithFlags(&fe->stream_d, hipStreamNonBlocking));
@@ -465,6 +546,7 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 		return rc;
 	}
 	if ((rc = build_taps(fe))) { frontend_free(fe); return rc; }
+	if (fe->prune_tol > 0 && g.tap_layout == TAPL_OCTET && (rc = build_fold_windows(fe))) { frontend_free(fe); return rc; }
 	FE_TRY(hipMemcpy(fe->d_cc, fe->cc.data(), sizeof(ChanConst) * (size_t)nch, hipMemcpyHostToDevice));
 	float resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)fe->decimation);
 	if ((rc = fe->demod.init(nch, g.outs, resamp_rate, fe->freqs.data(), fe->stream, pick_demod_batch(fe)))) { frontend_free(fe); return rc; }
@@ -505,6 +587,7 @@ extern "C" int hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_
 	g->demod_batch = fe->batch;
 	g->fold_batch = fe->fold_nb;
 	g->prefetch_depth = fe->n_stage - 1;
+	g->fold_rows = fe->fold_rows_max ? fe->fold_rows_max : p.pre;
 	g->transition_bw = fe->tbw;
 	g->resamp_rate = (float)(1800 * 3) / ((float)fe->sample_rate / (float)fe->decimation);
 	return 0;

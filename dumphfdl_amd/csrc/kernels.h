@@ -40,6 +40,10 @@ struct Geometry {
 	// an alias row of ALL channels is tap_row_stride cf32 long (nch_pad * M); inside it, TAPL_PLAIN: channel c at c*tap_chan_stride,
 	// bins in order; the interleaved layouts: tap_offset_f()
 	int64_t tap_chan_stride, tap_row_stride;
+	// The pruned fold (include/hfdl_gpu.h, HFDL_GPU_FOLD_PRUNE): per pair of channel octets / per octet the window of alias rows
+	// (first row, count; circular) outside which the filters of those channels hold less than the tolerated share of their energy.
+	// Null: every row is folded.  With windows the geometry has one slice.
+	const int2 *fold_win2 = nullptr, *fold_win1 = nullptr;
 };
 
 // Filter-tap layouts.  The fold runs on the fp32 matrix pipe: one wave load of 1 KiB (16 bytes per lane) must yield, register by
@@ -111,6 +115,9 @@ int fold_variant_describe(int variant, int desc[6]);            // P, Q, W, D, m
 int launch_fold_variant(int variant, const Geometry &g, const float2 *taps, const float2 *spectrum, size_t spec_stride, float2 *partial,
 		size_t partial_stride, int nb, hipStream_t st, hipEvent_t start, hipEvent_t stop);
 void launch_tap_extract(const float2 *taps, const Geometry &g, int channel, float2 *dst, hipStream_t st);      // one channel's taps back in plain order
+// energy[row * nch_pad + c] += sum over the row's M bins of |H_c|^2 (TAPL_OCTET; `energy` zeroed by the caller): what the pruned fold's
+// row windows are chosen from
+void launch_tap_row_energy(const float2 *taps, const Geometry &g, float *energy, hipStream_t st);
 hipError_t prepare_ifft_nco(int m);     // LDS attribute of the inverse-FFT kernel for this size (checked at create time)
 // `nb` blocks in one launch (grid nch x nb): partial sums, carried-state snapshots, phasor tables [outs][nch], outputs and counts of
 // consecutive blocks lie `partial_stride` / nch / `ph_stride` / nch * outs / nch apart

@@ -24,7 +24,7 @@ class Geometry(C.Structure):
         "sample_rate", "decimation", "pre_decimation", "post_decimation", "taps_length", "overlap_length",
         "fft_size", "fft_inv_size", "input_size", "post_input_size", "scrap", "outputs_per_block",
         "channels", "fold_slices")] + [("transition_bw", C.c_float), ("resamp_rate", C.c_float), ("max_outputs_per_block", C.c_int32), ("demod_batch", C.c_int32), ("fold_batch", C.c_int32),
-                                       ("prefetch_depth", C.c_int32)]
+                                       ("prefetch_depth", C.c_int32), ("fold_rows", C.c_int32)]
 
 
 class Pdu(C.Structure):

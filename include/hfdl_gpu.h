@@ -82,6 +82,8 @@ typedef struct {
 	int32_t prefetch_depth;          /* host blocks whose upload hfdl_gpu_frontend_prefetch_block_raw() may queue ahead of their push
 	                                    (fold_batch + 1: a staging ring of fold_batch + 2 buffers in HBM); at most HFDL_GPU_PREFETCH_MAX.
 	                                    0 from hfdl_gpu_plan_geometry() */
+	int32_t fold_rows;               /* alias rows a fold workgroup adds up at most: pre_decimation (all of them, the reference's sum term for
+	                                    term) unless HFDL_GPU_FOLD_PRUNE is set.  0 from hfdl_gpu_plan_geometry() */
 } hfdl_gpu_geometry;
 #define HFDL_GPU_PREFETCH_MAX 17
 
@@ -91,6 +93,14 @@ typedef struct {
  *   HFDL_GPU_HOST_THREADS >= 1   host threads that design the filter taps (default: one per core; set to cores / processes when several
  *                                front ends are created at once on one host)
  *   HFDL_GPU_PDU_RING     >= 1   capacity of the device PDU ring (default max(4096, 64 per channel))
+ *   HFDL_GPU_FOLD_PRUNE   tol    (default unset: off) the pruned fold: a channel's filter is a band-pass with a windowed-sinc stop band, and
+ *                                of the N / M alias rows the reference adds up (src/fastddc.c:123-150) all but the few around the pass band hold
+ *                                taps at the level of their own rounding noise.  With tol set (1e-12 .. 1e-3) a workgroup folds only
+ *                                the rows outside which its channels' filters hold less than tol^2 of their energy (geometry.fold_rows of
+ *                                pre_decimation): the channelizer output moves by ~tol relative RMS and the fold's time by the ratio of the
+ *                                rows.  The stored taps carry the rounding noise of the fp32 transform that made them (2.1e-7 of their energy
+ *                                as an amplitude ratio at N = 2^23) in EVERY row: a tolerance below that keeps every row.  Off, every row is
+ *                                folded -- the reference's sum, term for term
  * The A/B switches of the measurement scripts (stream placement, tiling sweeps, probes) are in the laboratory build only:
  * include/hfdl_gpu_lab.h, libhfdl_gpu_lab.so. */
 

@@ -127,6 +127,75 @@ def test_full_size_cfg4_burst_dense(gpu, oracle):
     fe.close()
 
 
+def test_pruned_fold_is_opt_in_and_within_an_ulp(gpu, oracle, monkeypatch):
+    """HFDL_GPU_FOLD_PRUNE (include/hfdl_gpu.h): off by default -- geometry.fold_rows = pre_decimation, every alias row is folded, the
+    reference's sum term for term (src/fastddc.c:123-150).  With a tolerance of 3e-7 (the taps' own rounding noise is 2.1e-7) at the cfg4 workload's full
+    size (256 channels x 40 Msps, every channel busy in all eight modes) a workgroup folds under a sixth of the 2048 rows; the
+    channelizer output of every channel watched moves by < 1.5e-6 relative RMS against the full fold (folding ALL rows in one slice
+    instead of four moves it by 5e-7 already: a 2048-term fp32 sum; the distance to the float64 oracle is 1e-6 and does not grow) and stays within the oracle gate, and the PDUs -- (freq, mode, octets, FCS) -- are those of the full fold, the
+    detection sample within the +-3 samples two timing loops with different last-ulp roundings are allowed.  A second geometry with a
+    left-over octet (2.4 Msps x 132 channels = 16 pairs of octets + one octet) covers the single-octet window."""
+    sys.path.insert(0, ROOT)
+    import bench
+    w = dict(bench.WORKLOADS["cfg4"])
+    freqs = bench.channel_plan(w)
+    watch = [0, 1, 7, 8, 100, 127, 128, 200, 254, 255]
+
+    def run(tol, fs, cf, fr, xs, nblk_out=(0, 5)):
+        if tol:
+            monkeypatch.setenv("HFDL_GPU_FOLD_PRUNE", repr(tol))
+        else:
+            monkeypatch.delenv("HFDL_GPU_FOLD_PRUNE", raising=False)
+        fe = gpu.Frontend(fs, cf, fr)
+        g = fe.geometry
+        n = g.input_size
+        outs = {}
+        for b in range(len(xs) // n):
+            fe.push_block(xs[b * n:(b + 1) * n])
+            if b in nblk_out:
+                outs[b] = [fe.read_tap(F.TAP_CHAN_OUT, c).copy() for c in watch if c < len(fr)]
+        pdus = fe.poll_pdus()
+        rows = (g.fold_rows, g.pre_decimation)
+        fe.close()
+        return outs, pdus, rows
+
+    g = F.plan_geometry(4096, 250 / w["fs"])
+    assert g.input_size == 7340032
+    x, bursts = bench.make_input(w, g.input_size, 0, 1)
+    full, pdus_full, rows_full = run(0, w["fs"], w["centerfreq"], freqs, x, (0, 9, 31))
+    pruned, pdus_pruned, rows_pruned = run(3e-7, w["fs"], w["centerfreq"], freqs, x, (0, 9, 31))
+    assert rows_full == (2048, 2048) and rows_pruned[1] == 2048 and 16 <= rows_pruned[0] <= 320, (rows_full, rows_pruned)
+    worst = max(rel_rms(a, b) for blk in full for a, b in zip(pruned[blk], full[blk]))
+    assert 0 < worst < 1.5e-6, worst
+    key = lambda p: (p["freq"], p["mode"], p["octets"], p["fcs_status"], p["lpdus"])
+    a, b = sorted(pdus_full, key=lambda p: (p["freq"], p["sample_index"])), sorted(pdus_pruned, key=lambda p: (p["freq"], p["sample_index"]))
+    assert len(a) >= 300 and [key(p) for p in a] == [key(p) for p in b]
+    assert all(abs(p["sample_index"] - q["sample_index"]) <= 3 for p, q in zip(a, b))
+    # against the oracle, like every other channelizer gate
+    sub = [0, 127, 128, 255]
+    ora = oracle.Frontend(w["fs"], w["centerfreq"], [freqs[c] for c in sub], nthreads=8)
+    ora.push_block(x[:g.input_size], nthreads=8)
+    for i, c in enumerate(sub):
+        assert rel_rms(pruned[0][watch.index(c)], ora.channel_view(i)["chan_out"]) < RMS_TOL
+    ora.close()
+    # a left-over octet, small geometry
+    fs, cf, nch = 2_400_000, 10_000_000, 132
+    fr = [int(cf + (i - nch // 2) * 15_000 + 4_000) for i in range(nch)]
+    rng = np.random.default_rng(5)
+    bl = [dict(freq=fr[c], mode=int(rng.integers(0, 4)), octets=b"", t0=float(rng.uniform(0.1, 0.5)), amp=0.03, cfo=float(rng.uniform(-10, 10)))
+          for c in (0, 64, 127, 128, 131)]
+    for q in bl:
+        q["octets"] = synth.make_pdu(rng, q["mode"])
+    xs = synth.synth_wideband(fs, cf, int(3.4 * fs), bl, noise_sigma=0.012, seed=5)
+    watch = [0, 64, 127, 128, 129, 131]
+    full, pf, r0 = run(0, fs, cf, fr, xs, (0, 3))
+    pruned, pp, r1 = run(3e-7, fs, cf, fr, xs, (0, 3))
+    assert r0[0] == r0[1] and r1[0] < r1[1], (r0, r1)
+    worst = max(rel_rms(a, b) for blk in full for a, b in zip(pruned[blk], full[blk]))
+    assert 0 < worst < 1.5e-6, worst
+    assert len(pf) == len(bl) and sorted(key(p) for p in pf) == sorted(key(p) for p in pp)
+
+
 def test_two_rank_bench_on_one_gpu():
     """The `bench.py --gpus N` launch path exactly as the driver starts it (torch.distributed.run, one process per rank),
     with N = 2 on the single GPU of the test box: ranks take stream seeds 5 and 6 (BASELINE.json configs[4]), rank 0 prints
