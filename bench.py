@@ -819,7 +819,8 @@ def main():
     fold_blk = fe.fold_blocks()
     dm_ms, dm_n, dm_blk = fe.demod_time_ms()
     period_ms = fe.step_period_ms()
-    shapes = fe.fold_launch_shapes()                       # {blocks per launch: timed launches}
+    shape_times = fe.fold_launch_times()                   # {blocks per launch: (timed launches, their kernel ms)}
+    shapes = {nb: c for nb, (c, _) in shape_times.items()}
     stages = fe.stage_times()                              # kernel time by stage, from the dispatches' own events
     barrier()
     fe.reset_timers(False)
@@ -849,7 +850,11 @@ def main():
         extra["fec"] = fec_capacity(hf, dev_index)
     geom = dict(channels=g.channels, fft_size=g.fft_size, fft_inv_size=g.fft_inv_size, input_size=g.input_size)
     demod_batch = g.demod_batch
-    fold_nb = (fold_blk / fold_n) if fold_n else 1.0           # blocks per fold launch in the timed region (geometry.fold_batch when every half was full)
+    # the roofline is priced on ONE launch shape: the one the run spent most of its fold time in (the full halves; the ragged end of a
+    # run is a launch of its own -- up to 4 blocks: the four-column form of the kernel -- and listed beside it)
+    dom = max(shape_times, key=lambda nb: shape_times[nb][1]) if shape_times else 0
+    dom_n, dom_ms = (shape_times[dom][0], shape_times[dom][1] / shape_times[dom][0]) if dom else (0, None)
+    fold_nb = float(dom) if dom else 1.0
     alg_bytes = alg_bytes_per_launch(g, fold_nb)
     alg_bytes_block = alg_bytes / fold_nb
     alg_bytes_unbatched = alg_bytes_per_block(g)
@@ -863,9 +868,12 @@ def main():
 
     if rank == 0:
         samples = total_samples
-        achieved = alg_bytes / (fold_avg_ms * 1e-3) / 1e9 if fold_n else None
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom else None
         fold_flops = 8.0 * geom["channels"] * geom["fft_size"] * fold_nb
-        traffic, traffic_src = traffic_record(args.workload, [nb for nb, cnt in sorted(shapes.items()) for _ in range(cnt)], fold_n)
+        tflops = (fold_flops / (dom_ms * 1e-3) / 1e12) if dom else None
+        wide = dom >= 5                                       # the sixteen-column form: bound by the multiplies; up to 4 blocks: by the HBM reads of the taps
+        traffic, traffic_src = traffic_record(args.workload, [dom] * dom_n, dom_n) if dom else (None, None)
+        fold_total_ms = sum(ms for _, ms in shape_times.values())
         par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, geom["channels"])) if args.shard == "streams" else \
               ("ONE %d-channel stream, channels round-robin over %d GPUs (%d on rank 0), every GPU ingests the same block; no collectives"
                % (len(all_freqs), world, geom["channels"]))
@@ -911,14 +919,19 @@ def main():
             # blocks on the fp32 matrix pipe, all sixteen columns of the instruction always computed: its time does not move with the blocks
             # in a launch (4.0 ms at 4, 8 or 16) -- the multiplies bound it, at the clock the board's power budget leaves beside 4.5 TB/s of
             # HBM reads (PMC: profiles/r05_experiments.md) -- so the roofline is the matrix pipe's; the HBM side of the same launch is `hbm`.
-            "roofline": {"bound": "mfma", "kernel": "fold_mfma16_kernel (v_mfma_f32_16x16x1_4B_f32)",
-                         "achieved": (fold_flops / (fold_avg_ms * 1e-3) / 1e12) if fold_n else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (fold_flops / (fold_avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if fold_n else None,
+            "roofline": {"bound": "mfma" if wide else "hbm",
+                         "kernel": "fold_mfma16_kernel (v_mfma_f32_16x16x1_4B_f32)" if wide else "fold_mfma16_kernel, four-column form (v_mfma_f32_4x4x1_16B_f32)",
+                         "achieved": tflops if wide else achieved, "peak": FP32_MFMA_PEAK_TFLOPS if wide else HBM_PEAK_GBS, "unit": "TFLOP/s" if wide else "GB/s",
+                         "frac": ((tflops / FP32_MFMA_PEAK_TFLOPS) if wide else (achieved / HBM_PEAK_GBS)) if dom else None,
+                         "priced_on": ("the %d-block launches: %d of the timed region's %d fold launches, %.0f %% of its fold kernel time"
+                                       % (dom, dom_n, fold_n, 100.0 * dom_ms * dom_n / max(fold_total_ms, 1e-9))) if dom else None,
                          "algorithmic_flops_per_launch": fold_flops,
                          "flops_model": "8 flops per complex multiply-accumulate x channels x fft_size x blocks_per_launch (src/fastddc.c:114-150 run for that many blocks)",
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": fold_avg_ms, "launches": fold_n, "launch_shapes": {str(k): v for k, v in sorted(shapes.items())},
-                         "blocks_per_launch": fold_nb, "fold_batch": fold_batch,
+                         "avg_launch_ms": dom_ms, "launches": dom_n, "blocks_per_launch": dom, "fold_batch": fold_batch,
+                         "launch_shapes": {str(nb): {"launches": c, "avg_ms": ms / c, "form": "16 columns (16x16x1_4B)" if nb >= 5 else "4 columns (4x4x1_16B)"}
+                                           for nb, (c, ms) in sorted(shape_times.items())},
+                         "mfma": {"achieved": tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (tflops / FP32_MFMA_PEAK_TFLOPS) if tflops else None},
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                                  "algorithmic_bytes_per_launch": alg_bytes,
                                  "model": "8*NB*input_size + C*8*N + C*8*NB*outputs_per_block per launch: NB queued blocks share ONE pass over the C*N filter "

@@ -12,6 +12,7 @@
 // instruction = four bins x eight channels' Re / Im rows x sixteen blocks -- which takes the multiply-accumulates off the vector ALUs
 // the demodulator kernel next door lives on.  Each product is one exact fmaf, applied in a fixed order (cmac_chain below).
 #include <hip/hip_ext.h>
+#include <type_traits>
 #include "kernels.h"
 #include "fft_core.h"
 
@@ -70,10 +71,10 @@ __device__ __forceinline__ float rot90(float a, int sign_mask)
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int fold16_waves(int p, int w, int d)
+constexpr int fold16_waves(int p, int w, int d, bool small = false)
 {
 	const int mine = (2 + w - 1) / w;
-	const int regs = 64 * p + 4 * p * d + 4 * mine * d + 8 + 4 * p + 28;
+	const int regs = (small ? 16 : 64) * p + 4 * p * d + 4 * mine * d + 8 + 4 * p + 28;
 	return regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
 }
 
@@ -88,13 +89,20 @@ constexpr int fold16_waves(int p, int w, int d)
 // Im(X) product.  Loads run D rows ahead, the spectrum tile one row ahead through two LDS stages, one barrier per row.
 // WIN (the pruned fold, hfdl_gpu.h HFDL_GPU_FOLD_PRUNE): a workgroup folds only the window of alias rows `win[group]` = (first row,
 // count) around its channels' pass bands -- circular, one slice, rows = all alias rows -- instead of a slice of all of them.
-template <int P, int W, int D, bool WIN = false>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_waves(P, W, D), fold16_waves(P, W, D)))) void fold_mfma16_kernel(
+// SMALL (launches of at most FOUR blocks: the ragged end of a run, a live receiver's block at a time): the same taps, the same loop,
+// v_mfma_f32_4x4x1_16B_f32 instead -- sixteen 4 x 4 products per instruction: lane 4 q + i of operand A = row i of (bin-set register v,
+// bin 4 v + (lane >> 4), channel pair (lane >> 2) & 3) -- the octet layout as it lies -- and lane 4 q + j of operand B = block j of
+// that bin.  The sixteen-column form computes all sixteen columns whatever the block count (4.0 ms per cfg3 launch at 1 ... 16 blocks);
+// this one leaves the matrix pipe three quarters idle and the launch to the HBM reads of the taps.  Same FMA chain per sum: same bits.
+template <int P, int W, int D, bool WIN = false, int FORM = 0>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_waves(P, W, D, FORM != 0), fold16_waves(P, W, D, FORM != 0)))) void fold_mfma16_kernel(
 		const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
 		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int octet_base, int nch, int nb,
 		const int2 *__restrict__ win = nullptr)
 {
 	static_assert(!WIN || W == 1, "windows are per wave: no spectrum tile is shared");
+	constexpr bool SMALL = FORM == 1;          // FORM 0: sixteen columns (16x16x1_4B); 1: four columns (4x4x1_16B); 2 (laboratory): a TIMING probe, see fold_variants[]
+	constexpr bool K4PROBE = FORM == 2;
 	static_assert(D == 2 || D == 4, "the LDS stage of a trip is a compile-time constant for even D");
 	// a row's spectrum tile = 4 pieces of 512 B (bin-set v = 0 .. 3: lane n + 16 blk <- bin 4 v + blk of block n).  EVERY wave fetches
 	// MINE of them -- with more than four waves the upper ones fetch (and store) what the lower ones do -- so that all waves issue the
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 	}
 	const int g = tile_id % ngrp, s = tile_id / ngrp;
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
-	const int n = lane & 15, blk = lane >> 4;
+	const int n = FORM == 1 ? lane & 3 : lane & 15, blk = lane >> 4;
 	const int octet0 = octet_base + (grp * W + wave) * P;
 	const int sign_mask = (lane & 1) ? 0 : (int)0x80000000;
 	int next_row = 0, trips = rows;                           // WIN: the next row to ask for (circular), rows in the window
@@ -134,13 +142,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 		xp = (const char *)(spec + (size_t)bi * spec_stride + (size_t)s * rows * (size_t)m + g * 16 + 4 * v0 + blk);
 	}
 	const char *const tb0 = tb, *const xp0 = xp;
-	v16f acc[P][4];
+	typedef typename std::conditional<FORM != 0, v4f, v16f>::type Acc;
+	Acc acc[P][4];
 #pragma unroll
 	for (int p = 0; p < P; p++)
 #pragma unroll
 		for (int v = 0; v < 4; v++)
 #pragma unroll
-			for (int e = 0; e < 16; e++) acc[p][v][e] = 0.f;
+			for (int e = 0; e < (FORM != 0 ? 4 : 16); e++) acc[p][v][e] = 0.f;
 	v4f h[D][P];
 	v2f xs[D][MINE];
 	auto issue = [&](int slot) {               // the loads of the next row not yet asked for: spectrum share first, then the taps
@@ -169,13 +178,19 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 #pragma unroll
 		for (int p = 0; p < P; p++)
 #pragma unroll
-			for (int v = 0; v < 4; v++)
-				acc[p][v] = __builtin_amdgcn_mfma_f32_16x16x1f32(h[slot][p][v], x[v].x, acc[p][v], 0, 0, 0);
+			for (int v = 0; v < 4; v++) {
+				if constexpr (SMALL) acc[p][v] = __builtin_amdgcn_mfma_f32_4x4x1f32(h[slot][p][v], x[v].x, acc[p][v], 0, 0, 0);
+				else if constexpr (K4PROBE) acc[p][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[slot][p][v], x[v].x, acc[p][v], 0, 0, 0);
+				else acc[p][v] = __builtin_amdgcn_mfma_f32_16x16x1f32(h[slot][p][v], x[v].x, acc[p][v], 0, 0, 0);
+			}
 #pragma unroll
 		for (int p = 0; p < P; p++)
 #pragma unroll
-			for (int v = 0; v < 4; v++)
-				acc[p][v] = __builtin_amdgcn_mfma_f32_16x16x1f32(rot90(h[slot][p][v], sign_mask), x[v].y, acc[p][v], 0, 0, 0);
+			for (int v = 0; v < 4; v++) {
+				if constexpr (SMALL) acc[p][v] = __builtin_amdgcn_mfma_f32_4x4x1f32(rot90(h[slot][p][v], sign_mask), x[v].y, acc[p][v], 0, 0, 0);
+				else if constexpr (K4PROBE) acc[p][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(rot90(h[slot][p][v], sign_mask), x[v].y, acc[p][v], 0, 0, 0);
+				else acc[p][v] = __builtin_amdgcn_mfma_f32_16x16x1f32(rot90(h[slot][p][v], sign_mask), x[v].y, acc[p][v], 0, 0, 0);
+			}
 	};
 	// loads of different rows must stay in program order (see fold_mfma_kernel): scheduling barriers between the rows
 #pragma unroll
@@ -204,6 +219,24 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 			__syncthreads();
 		}
 	}
+	if constexpr (FORM != 0) {
+		// (the probe form stores through the same code: its numbers mean nothing)
+		// D[q][row i][block j] sits in register i of lane 4 q + j: this lane holds block n = lane & 3, the channel pair (lane >> 2) & 3 of
+		// each octet (Re, Im of its two channels in registers 0 .. 3) and bin 4 v + (lane >> 4) of bin-set register v
+		if (n < nb) {
+			const int cpq = (lane >> 2) & 3;
+#pragma unroll
+			for (int p = 0; p < P; p++)
+#pragma unroll
+				for (int cp = 0; cp < 2; cp++) {
+					const int c = 8 * (octet0 + p) + 2 * cpq + cp;
+					if (c >= nch) continue;
+					float2 *po = partial + (size_t)n * partial_stride + ((size_t)c * slices + s) * (size_t)m + g * 16 + blk;
+#pragma unroll
+					for (int v = 0; v < 4; v++) po[4 * v] = make_float2(acc[p][v][2 * cp], acc[p][v][2 * cp + 1]);
+				}
+		}
+	} else
 	// D[bin blk][row i][block n] sits in register 4 blk + (i & 3) of lane 16 (i >> 2) + n: this lane holds block n, channels
 	// 2 (lane >> 4) and + 1 of each octet (Re, Im in adjacent registers), bins 4 v + (0 .. 3): 32 contiguous bytes per channel and v
 	if (n < nb) {
@@ -216,7 +249,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 				float2 *po = partial + (size_t)n * partial_stride + ((size_t)c * slices + s) * (size_t)m + g * 16;
 #pragma unroll
 				for (int v = 0; v < 4; v++) {
-					const v16f a = acc[p][v];
+					const Acc a = acc[p][v];
 					((v4f *)(po + 4 * v))[0] = v4f{ a[2 * cp], a[2 * cp + 1], a[4 + 2 * cp], a[4 + 2 * cp + 1] };
 					((v4f *)(po + 4 * v))[1] = v4f{ a[8 + 2 * cp], a[8 + 2 * cp + 1], a[12 + 2 * cp], a[12 + 2 * cp + 1] };
 				}
@@ -427,19 +460,19 @@ struct FoldArgs {
 };
 
 // workgroups of 8 P W channels first; the octets left over get single-wave workgroups in a launch of their own
-template <int P, int W, int D>
+template <int P, int W, int D, int FORM = 0>
 static int fold16_go(const FoldArgs &a)
 {
 	const int ntile = (a.m >> 4) * a.slices;
 	const int groups = a.ngroups / (P * W), rest = a.ngroups - groups * P * W;
 	int launches = 0;
 	if (groups > 0) {
-		hipExtLaunchKernelGGL((fold_mfma16_kernel<P, W, D>), dim3((unsigned)(groups * ntile)), dim3(64 * W), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
+		hipExtLaunchKernelGGL((fold_mfma16_kernel<P, W, D, false, FORM>), dim3((unsigned)(groups * ntile)), dim3(64 * W), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
 			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, 0, a.nch, a.nb, (const int2 *)nullptr);
 		launches++;
 	}
 	if (rest > 0) {
-		hipExtLaunchKernelGGL((fold_mfma16_kernel<1, 1, D>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+		hipExtLaunchKernelGGL((fold_mfma16_kernel<1, 1, D, false, FORM>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
 			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, groups * P * W, a.nch, a.nb, (const int2 *)nullptr);
 		launches++;
 	}
@@ -489,14 +522,21 @@ static int fold_go(const FoldArgs &a)
 #endif
 
 // layout: the tap layout the tiling reads; q: groups of four blocks it takes (4x4x1 family; 4 = any count up to 16 for the 16x16x1 family)
-struct FoldVariant { int layout, p, q, w, d; int (*go)(const FoldArgs &); };
+struct FoldVariant { int layout, p, q, w, d; int (*go)(const FoldArgs &); bool probe; };       // probe: times, does not fold (never picked)
 #define F16(P, W, D) { TAPL_OCTET, P, 4, W, D, fold16_go<P, W, D> }
+#define F4(P, W, D) { TAPL_OCTET, P, 1, W, D, fold16_go<P, W, D, 1> }
+// laboratory, TIMING ONLY (the sums are wrong): the sixteen-column loop with v_mfma_f32_16x16x4_f32 in the place of 16x16x1_4B -- the same
+// loads, LDS traffic and instruction count, a quarter of the accumulator traffic: what a K = 4 fold could gain
+#define FK4(P, W, D) { TAPL_OCTET, P, 4, W, D, fold16_go<P, W, D, 2>, true }
 #define FM(P, Q, W, D) { TAPL_PAIR, P, Q, W, D, fold_go<P, Q, W, D> }
 // The first entry whose layout is the geometry's and whose row look-ahead D divides the slice is the one used.
 // Measured on cfg3 (M = 4096, 512 rows per slice) with profiles/fold_variants.py: profiles/r05/fold_variants_cfg3.md.
 static const FoldVariant fold_variants[] = {
 	F16(2, 4, 4), F16(2, 4, 2),
+	F4(4, 4, 4), F4(4, 4, 2),                  // launches of at most four blocks
 #ifdef HFDL_LAB
+	F4(2, 4, 4), F4(2, 4, 2), F4(2, 8, 4), F4(1, 4, 4), F4(4, 2, 4), F4(1, 8, 4),
+	FK4(2, 4, 4), FK4(4, 4, 4), FK4(4, 4, 2), FK4(2, 8, 4),
 	F16(1, 4, 4), F16(1, 4, 2), F16(1, 8, 4), F16(1, 8, 2), F16(2, 2, 4), F16(1, 2, 4), F16(2, 8, 2),
 	// the 4x4x1 family of the first matrix-pipe build (HFDL_GPU_FOLD_MFMA=4 at create): measured, kept for the record
 	FM(2, 1, 4, 4), FM(2, 1, 4, 2), FM(4, 1, 4, 4),
@@ -505,6 +545,8 @@ static const FoldVariant fold_variants[] = {
 #endif
 };
 #undef FM
+#undef FK4
+#undef F4
 #undef F16
 constexpr int N_FOLD_VARIANTS = (int)(sizeof(fold_variants) / sizeof(fold_variants[0]));
 
@@ -514,7 +556,7 @@ int fold_variant_describe(int v, int desc[6])
 {
 	if (v < 0 || v >= N_FOLD_VARIANTS) return -1;
 	const FoldVariant &f = fold_variants[v];
-	desc[0] = f.p; desc[1] = f.q; desc[2] = f.w; desc[3] = f.d; desc[4] = 4 * f.q; desc[5] = f.layout;
+	desc[0] = f.p; desc[1] = f.q; desc[2] = f.w; desc[3] = f.d; desc[4] = 4 * f.q; desc[5] = f.probe ? -f.layout : f.layout;
 	return 0;
 }
 
@@ -526,9 +568,12 @@ static bool variant_fits(const FoldVariant &f, const Geometry &g)
 // the tiling used for `nb` blocks of this geometry: the first entry of the list that fits
 static const FoldVariant *pick_variant(const Geometry &g, int nb)
 {
-	const int q = nb <= 4 ? 1 : nb <= 8 ? 2 : 4;
+	// octet layout: the four-column form up to four blocks, the sixteen-column form beyond; pair layout (laboratory): 4, 8 or 16 columns
+	const int q = nb <= 4 ? 1 : (nb <= 8 && g.tap_layout != TAPL_OCTET) ? 2 : 4;
 	for (const FoldVariant &f : fold_variants)
-		if ((f.layout == TAPL_OCTET || f.q == q) && variant_fits(f, g)) return &f;
+		if (f.q == q && !f.probe && variant_fits(f, g)) return &f;
+	for (const FoldVariant &f : fold_variants)
+		if (4 * f.q >= nb && !f.probe && variant_fits(f, g)) return &f;
 	return nullptr;
 }
 

@@ -193,6 +193,7 @@ struct hfdl_gpu_frontend {
 	double fold_ms = 0;
 	int64_t fold_launches = 0, fold_timed_blocks = 0, fold_last_blocks = 0;
 	int64_t fold_shapes[FOLD_MAX_BLOCKS + 1] = {};   // timed fold launches by block count
+	double fold_shape_ms[FOLD_MAX_BLOCKS + 1] = {};  // ... and their kernel time
 	hipEvent_t ev_first_fold = nullptr;  // start of the first timed fold since reset_timers: anchor of the steady-state step period
 	double span_ms = 0;                 // first timed fold start -> last timed fold start
 	uint64_t blocks = 0;
@@ -934,7 +935,7 @@ static int drain_events(hfdl_gpu_frontend *fe)
 		fe->fold_launches++;
 		fe->fold_timed_blocks += fe->ev_blocks[i];
 		fe->fold_last_blocks = fe->ev_blocks[i];
-		if (fe->ev_blocks[i] >= 1 && fe->ev_blocks[i] <= FOLD_MAX_BLOCKS) fe->fold_shapes[fe->ev_blocks[i]]++;
+		if (fe->ev_blocks[i] >= 1 && fe->ev_blocks[i] <= FOLD_MAX_BLOCKS) { fe->fold_shapes[fe->ev_blocks[i]]++; fe->fold_shape_ms[fe->ev_blocks[i]] += ms; }
 		if (!fe->ev_first_fold) {
 			fe->ev_first_fold = e.first;            // kept until the next reset
 			HIP_TRY(hipEventCreate(&e.first));
@@ -1059,6 +1060,7 @@ extern "C" int hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable)
 	if (rc) return rc;
 	fe->fold_ms = 0; fe->fold_launches = 0; fe->fold_timed_blocks = 0; fe->fold_last_blocks = 0; fe->timing = enable != 0;
 	for (auto &c : fe->fold_shapes) c = 0;
+	for (auto &c : fe->fold_shape_ms) c = 0;
 	fe->demod_ms = 0; fe->demod_launches = 0; fe->demod_timed_blocks = 0;
 	fe->fft_ms = fe->ifft_ms = fe->decode_ms = 0; fe->fft_timed = fe->ifft_timed = fe->decode_timed = 0;
 	if (fe->ev_first_fold) { (void)hipEventDestroy(fe->ev_first_fold); fe->ev_first_fold = nullptr; }
@@ -1083,12 +1085,13 @@ extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *tot
 	return 0;
 }
 
-extern "C" int hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[17])
+extern "C" int hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[17], double ms[17])
 {
 	if (!fe || !counts) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);
 	if (rc) return rc;
 	for (int i = 0; i <= FOLD_MAX_BLOCKS; i++) counts[i] = fe->fold_shapes[i];
+	if (ms) for (int i = 0; i <= FOLD_MAX_BLOCKS; i++) ms[i] = fe->fold_shape_ms[i];
 	return 0;
 }
 

@@ -267,8 +267,9 @@ int  hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what, int32_t c
 int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
 int  hfdl_gpu_frontend_fold_blocks(hfdl_gpu_frontend *fe, int64_t *blocks);
 /* timed fold launches by block count: counts[nb] = launches that folded nb blocks (nb = 1 .. 16; counts[0] unused) since the timers
- * were reset -- what a caller needs to price the launches it timed (a launch of 4 blocks moves other bytes than one of 16) */
-int  hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[17]);
+ * were reset, ms[nb] (may be NULL) = their kernel time -- what a caller needs to price the launches it timed (a launch of up to 4
+ * blocks runs the four-column form of the kernel and is bound by the HBM reads of the taps, one of 5 .. 16 the sixteen-column form) */
+int  hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[17], double ms[17]);
 int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
 /* the same for the demodulator kernel (the kernel that bounds the small geometries), from its dispatch's own start / stop events;
  * *blocks = the blocks those launches covered (a launch takes up to geometry.demod_batch blocks) */

@@ -8,6 +8,12 @@ OUT=/root/repo/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd /root/repo
 echo "commit $C" > $OUT/README.txt
+# the PMC passes first: the traffic records they leave under profiles/ are what the bench lines below quote (roofline.traffic)
+( cd /tmp && export TMPDIR=/tmp
+for wl in cfg3 cfg2 cfg4; do
+	bash /root/repo/profiles/pmc_passes.sh $wl $OUT $C > $OUT/pmc_$wl.log 2>&1
+	cp $OUT/fold_traffic_$wl.json /root/repo/profiles/fold_traffic_$wl.json
+done )
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 timeout 1800 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "rc=$?" >> $OUT/pytest_gpu.log
 tail -3 $OUT/pytest_gpu.log
@@ -39,7 +45,7 @@ for name in ("cfg3", "cfg2"):
     out[name] = {fmt: [bench.host_path_leg(w, x, bench.channel_plan(w), fmt) for _ in range(2)] for fmt in ("CS16", "CF32")}
 print(json.dumps(out))
 PY
-timeout 300 python profiles/fold_variants.py cfg3 3 4,8,16 > $OUT/fold_variants_cfg3.md 2>> $OUT/bench.err
+timeout 300 python profiles/fold_variants.py cfg3 3 1,2,4,8,16 > $OUT/fold_variants_cfg3.md 2>> $OUT/bench.err
 HFDL_GPU_FOLD_MFMA=4 timeout 300 python profiles/fold_variants.py cfg3 3 4,8,16 > $OUT/fold_variants_cfg3_4x4x1.md 2>> $OUT/bench.err
 timeout 300 python profiles/fft_accuracy.py > $OUT/fft_accuracy.txt 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
@@ -49,6 +55,8 @@ for wl in cfg3 cfg2 cfg4; do
 	DB=$(find /tmp/kt_$wl -name "*.db" | head -1)
 	python /root/repo/profiles/summarize_rocpd.py $DB "$wl -- rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --no-cpu-baseline --no-extra-legs (256 timed blocks + 8 warm-up, 16 blocks per fold launch; the fft passes also run once per channel at create for the filter taps, and once more for the stream-read probe's laboratory front end; commit $C)" > $OUT/${wl}_kernel_stats.md
 	python /root/repo/profiles/timeline_rocpd.py $DB 1 > $OUT/${wl}_timeline.md
-	bash /root/repo/profiles/pmc_passes.sh $wl $OUT $C > $OUT/pmc_$wl.log 2>&1
 done
+rm -rf /tmp/kt20
+rocprofv3 --kernel-trace --stats -d /tmp/kt20 -- python /root/repo/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $OUT/bench_cfg3_driver_line_under_rocprof.json 2>/dev/null
+python /root/repo/profiles/timeline_tail.py $(find /tmp/kt20 -name "*.db" | head -1) -56 > $OUT/cfg3_driver_line_timeline.md
 ls -la $OUT
