@@ -920,7 +920,7 @@ def main():
             # in a launch (4.0 ms at 4, 8 or 16) -- the multiplies bound it, at the clock the board's power budget leaves beside 4.5 TB/s of
             # HBM reads (PMC: profiles/r05_experiments.md) -- so the roofline is the matrix pipe's; the HBM side of the same launch is `hbm`.
             "roofline": {"bound": "mfma" if wide else "hbm",
-                         "kernel": "fold_mfma16_kernel (v_mfma_f32_16x16x1_4B_f32)" if wide else "fold_mfma16_kernel, four-column form (v_mfma_f32_4x4x1_16B_f32)",
+                         "kernel": "fold_mfma16_kernel (v_mfma_f32_16x16x4_f32: four alias rows per instruction)" if wide else "fold_mfma16_kernel, four-column form (v_mfma_f32_4x4x1_16B_f32)",
                          "achieved": tflops if wide else achieved, "peak": FP32_MFMA_PEAK_TFLOPS if wide else HBM_PEAK_GBS, "unit": "TFLOP/s" if wide else "GB/s",
                          "frac": ((tflops / FP32_MFMA_PEAK_TFLOPS) if wide else (achieved / HBM_PEAK_GBS)) if dom else None,
                          "priced_on": ("the %d-block launches: %d of the timed region's %d fold launches, %.0f %% of its fold kernel time"
@@ -929,7 +929,7 @@ def main():
                          "flops_model": "8 flops per complex multiply-accumulate x channels x fft_size x blocks_per_launch (src/fastddc.c:114-150 run for that many blocks)",
                          "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": dom_ms, "launches": dom_n, "blocks_per_launch": dom, "fold_batch": fold_batch,
-                         "launch_shapes": {str(nb): {"launches": c, "avg_ms": ms / c, "form": "16 columns (16x16x1_4B)" if nb >= 5 else "4 columns (4x4x1_16B)"}
+                         "launch_shapes": {str(nb): {"launches": c, "avg_ms": ms / c, "form": "16 columns (16x16x4)" if nb >= 5 else "4 columns (4x4x1_16B)"}
                                            for nb, (c, ms) in sorted(shape_times.items())},
                          "mfma": {"achieved": tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (tflops / FP32_MFMA_PEAK_TFLOPS) if tflops else None},
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,

@@ -33,8 +33,7 @@ __device__ __forceinline__ float2 load_sample(const void *__restrict__ raw, int 
 __device__ __forceinline__ void store_out(float2 *out, const FftOutLayout &lay, unsigned i, size_t at, float2 v)
 {
 	if (lay.kind == TAPL_PLAIN) { out[at] = v; return; }
-	float *o = (float *)out + (size_t)(i >> lay.row_log) * (size_t)(2 * lay.row_stride)
-			+ tap_offset_f(lay.kind, 1 << lay.row_log, lay.chan, (int)(i & ((1u << lay.row_log) - 1u)), 0);
+	float *o = (float *)out + tap_index_f(lay.kind, 1 << lay.row_log, (size_t)(2 * lay.row_stride), lay.chan, (int)(i >> lay.row_log), (int)(i & ((1u << lay.row_log) - 1u)), 0);
 	o[0] = v.x;
 	o[4] = v.y;              // Im sits one lane on: four floats
 }

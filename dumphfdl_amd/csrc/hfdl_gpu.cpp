@@ -176,7 +176,7 @@ struct hfdl_gpu_frontend {
 	size_t partial_stride() const { return (size_t)geo.nch * (size_t)geo.slices * (size_t)geo.m; }
 	size_t ph_stride() const { return (size_t)geo.nch * (size_t)geo.outs; }
 	ChanConst *d_cc = nullptr;
-	int2 *d_win2 = nullptr, *d_win1 = nullptr;       // pruned fold: row windows per pair of octets / per octet (kernels.h Geometry::fold_win*)
+	int2 *d_win = nullptr;              // pruned fold: window of quads of alias rows per octet (kernels.h Geometry::fold_win)
 	double prune_tol = 0.0;             // HFDL_GPU_FOLD_PRUNE: share of a filter's energy (as an amplitude ratio) the skipped alias rows may hold; 0 = fold every row
 	int fold_rows_max = 0;              // the longest row window (0: every row is folded)
 	NcoState *d_nco = nullptr;          // [nch] carried NCO state, owned by the forward FFT's rider workgroups (kernels.h NcoJob)
@@ -230,7 +230,7 @@ static void frontend_free(hfdl_gpu_frontend *fe)
 	fe->demod.release();
 	fe->fft.release();
 	void *ptrs[] = { fe->d_hist[0], fe->d_hist[1], fe->d_work, fe->d_spec, fe->d_taps, fe->d_partial, fe->d_chan_all, fe->d_tw_m,
-		fe->d_cc, fe->d_nco, fe->d_nco_snap, fe->d_ph, fe->d_ph_cont, fe->d_cnt_all, fe->d_win2, fe->d_win1 };
+		fe->d_cc, fe->d_nco, fe->d_nco_snap, fe->d_ph, fe->d_ph_cont, fe->d_cnt_all, fe->d_win };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (float2 *p : fe->d_stage) if (p) (void)hipFree(p);
 	if (fe->stream) (void)hipStreamDestroy(fe->stream);
@@ -312,8 +312,8 @@ static double env_double(const char *name, double lo, double hi, double otherwis
 // of the p = N / M alias rows the fold adds up, all but the few around the pass band hold taps below fp32 resolution of the sum (cfg3:
 // rows 32 or more from the pass band hold 3.7e-8 of the filter's energy as an amplitude ratio -- less than half an ulp; DESIGN.md section
 // 9).  From the taps themselves: per channel the smallest window of rows around the pass band outside which less than tol^2 of the
-// filter's energy lies; a workgroup of two octets (or the left-over octet) folds the circular hull of its channels' windows, rounded
-// up to whole look-ahead groups of 4 rows.
+// filter's energy lies; the workgroup of an octet folds the circular hull of its eight channels' windows in quads of rows (what one
+// matrix instruction takes), rounded up to whole look-ahead groups of two quads.
 static int build_fold_windows(hfdl_gpu_frontend *fe)
 {
 	Geometry &g = fe->geo;
@@ -341,34 +341,30 @@ static int build_fold_windows(hfdl_gpu_frontend *fe)
 		}
 		for (int r = lo; r <= hi; r++) keep[(size_t)c][(size_t)((r % p + p) % p)] = 1;
 	}
-	auto hull = [&](int c0, int c1) {                   // circular hull of the rows kept by channels [c0, c1)
-		std::vector<char> any((size_t)p, 0);
+	auto hull = [&](int c0, int c1) {                   // circular hull of the rows kept by channels [c0, c1), in QUADS of rows (first quad, count)
+		const int nq = p / 4;
+		std::vector<char> any((size_t)nq, 0);
 		int kept = 0;
-		for (int c = c0; c < c1; c++) for (int r = 0; r < p; r++) if (keep[(size_t)c][(size_t)r] && !any[(size_t)r]) { any[(size_t)r] = 1; kept++; }
-		if (kept == 0) return make_int2(0, 4);           // channels that only fill the octet up: zero taps, any four rows
-		int best_len = 0, best_end = 0;                  // the longest circular run of rows nobody keeps
-		for (int r = 0; r < p; r++) {
-			if (any[(size_t)r] || !any[(size_t)((r + p - 1) % p)]) continue;      // r = first row of a gap
+		for (int c = c0; c < c1; c++) for (int r = 0; r < p; r++) if (keep[(size_t)c][(size_t)r] && !any[(size_t)(r >> 2)]) { any[(size_t)(r >> 2)] = 1; kept++; }
+		if (kept == 0) return make_int2(0, 2);           // channels that only fill the octet up: zero taps, any two quads
+		int best_len = 0, best_end = 0;                  // the longest circular run of quads nobody keeps
+		for (int q = 0; q < nq; q++) {
+			if (any[(size_t)q] || !any[(size_t)((q + nq - 1) % nq)]) continue;      // q = first quad of a gap
 			int len = 0;
-			while (len < p && !any[(size_t)((r + len) % p)]) len++;
-			if (len > best_len) { best_len = len; best_end = (r + len) % p; }
+			while (len < nq && !any[(size_t)((q + len) % nq)]) len++;
+			if (len > best_len) { best_len = len; best_end = (q + len) % nq; }
 		}
-		int count = p - best_len;
-		count = std::min(p, (count + 3) & ~3);
+		int count = nq - best_len;
+		count = std::min(nq, (count + 1) & ~1);          // whole look-ahead groups of two quads
 		return make_int2(best_len ? best_end : 0, count);
 	};
-	const int noct = npad / 8, npair = noct / 2;
-	std::vector<int2> w2((size_t)std::max(npair, 1)), w1((size_t)std::max(noct, 1));
+	const int noct = npad / 8;
+	std::vector<int2> w((size_t)noct);
 	fe->fold_rows_max = 0;
-	for (int i = 0; i < npair; i++) { w2[(size_t)i] = hull(16 * i, 16 * i + 16); fe->fold_rows_max = std::max(fe->fold_rows_max, w2[(size_t)i].y); }
-	for (int i = 0; i < noct; i++) w1[(size_t)i] = hull(8 * i, 8 * i + 8);
-	if (noct & 1) fe->fold_rows_max = std::max(fe->fold_rows_max, w1[(size_t)(noct - 1)].y);
-	// fold_mfma16_kernel<1, 1, D, true> indexes win1 from ITS first octet: the left-over octet is entry 0 of what it is given
-	HIP_TRY(hipMalloc(&fe->d_win2, sizeof(int2) * w2.size()));
-	HIP_TRY(hipMalloc(&fe->d_win1, sizeof(int2) * 1));
-	HIP_TRY(hipMemcpy(fe->d_win2, w2.data(), sizeof(int2) * w2.size(), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(fe->d_win1, &w1[(size_t)(noct - 1)], sizeof(int2), hipMemcpyHostToDevice));
-	g.fold_win2 = fe->d_win2; g.fold_win1 = fe->d_win1;
+	for (int i = 0; i < noct; i++) { w[(size_t)i] = hull(8 * i, 8 * i + 8); fe->fold_rows_max = std::max(fe->fold_rows_max, 4 * w[(size_t)i].y); }
+	HIP_TRY(hipMalloc(&fe->d_win, sizeof(int2) * w.size()));
+	HIP_TRY(hipMemcpy(fe->d_win, w.data(), sizeof(int2) * w.size(), hipMemcpyHostToDevice));
+	g.fold_win = fe->d_win;
 	return 0;
 }
 
@@ -461,10 +457,7 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	// Filter taps row-major over channels: alias row r of every channel sits in one nch*M run, so the workgroups of all
 	// channels, which walk the rows together, stream through a few moving windows of HBM instead of nch windows 8N bytes
 	// apart (fold kernel 2.58 -> 2.48 ms on cfg3 and a tighter run-to-run spread, profiles/r01_experiments.md)
-	g.tap_layout = (pl.m % 16) == 0 ? TAPL_OCTET : TAPL_PLAIN;
-#ifdef HFDL_LAB
-	if (env_long("HFDL_GPU_FOLD_MFMA", 4, 16, 16) == 4 && (pl.m % 64) == 0) g.tap_layout = TAPL_PAIR;      // the 4x4x1 family of the first matrix-pipe build
-#endif
+	g.tap_layout = (pl.m % 16) == 0 && (pl.pre % 8) == 0 ? TAPL_OCTET : TAPL_PLAIN;       // the matrix-pipe fold walks the alias rows four at a time, two such quads in flight
 	{
 		const int grp = tap_layout_group(g.tap_layout);
 		g.nch_pad = (nch + grp - 1) / grp * grp;
@@ -475,7 +468,10 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	g.slices = pick_slices(nch, pl.pre);
 	// HFDL_GPU_FOLD_PRUNE=tol (0 < tol <= 1e-3; unset: every alias row is folded, the reference's sum term for term): fold only the
 	// rows around each channel's pass band (build_fold_windows) -- one slice, the windows are the parallelism
-	fe->prune_tol = (pl.m % 16) == 0 && pl.pre >= 8 ? env_double("HFDL_GPU_FOLD_PRUNE", 1e-12, 1e-3, 0.0) : 0.0;
+#ifdef HFDL_LAB
+	g.fold_tile = (int32_t)env_long("HFDL_GPU_FOLD_TILE", 0, 63, -1);
+#endif
+	fe->prune_tol = g.tap_layout == TAPL_OCTET ? env_double("HFDL_GPU_FOLD_PRUNE", 1e-12, 1e-3, 0.0) : 0.0;
 	if (fe->prune_tol > 0) g.slices = 1;
 	g.rows_per_slice = pl.pre / g.slices;
 	if (pl.m > 8192 || pl.m < 16) { delete fe; return fail(HFDL_GPU_ERANGE, "inverse FFT size %d unsupported", pl.m); }
@@ -1246,7 +1242,7 @@ extern "C" int hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what,
 	switch (what) {
 	case HFDL_GPU_TAP_SPECTRUM: src = fe->spec_slot(fe->last_set, index); nf = 2 * (size_t)g.n; break;
 	case HFDL_GPU_TAP_FILTER: {
-		// the taps lie pair-interleaved, rows tap_row_stride apart (fold_kernels.hip): a kernel gathers the channel into plain cf32[N]
+		// the taps lie in matrix-operand order (kernels.h tap_index_f): a kernel gathers the channel into plain cf32[N]
 		if (2 * (size_t)g.n > cap) return fail(HFDL_GPU_ERANGE, "tap needs %zu floats, buffer holds %zu", 2 * (size_t)g.n, cap);
 		DevBuf plain;
 		HIP_TRY(plain.alloc(sizeof(float2) * (size_t)g.n));

@@ -37,31 +37,35 @@ struct Geometry {
 	int32_t slices, rows_per_slice, nch;
 	int32_t nch_pad;                   // channels the tap buffer holds: nch rounded up to a whole group of the tap layout (the extra ones all zero)
 	int32_t tap_layout;                // TAPL_*: how an alias row of the filter taps lies in HBM (fold_kernels.hip)
-	// an alias row of ALL channels is tap_row_stride cf32 long (nch_pad * M); inside it, TAPL_PLAIN: channel c at c*tap_chan_stride,
-	// bins in order; the interleaved layouts: tap_offset_f()
+	// an alias row of ALL channels is tap_row_stride cf32 long (nch_pad * M); TAPL_PLAIN: channel c at c*tap_chan_stride inside it,
+	// bins in order; TAPL_OCTET: tap_index_f()
 	int64_t tap_chan_stride, tap_row_stride;
-	// The pruned fold (include/hfdl_gpu.h, HFDL_GPU_FOLD_PRUNE): per pair of channel octets / per octet the window of alias rows
-	// (first row, count; circular) outside which the filters of those channels hold less than the tolerated share of their energy.
+	// The pruned fold (include/hfdl_gpu.h, HFDL_GPU_FOLD_PRUNE): per channel octet the window of alias rows, in quads of rows (first
+	// quad, count; circular), outside which the filters of those channels hold less than the tolerated share of their energy.
 	// Null: every row is folded.  With windows the geometry has one slice.
-	const int2 *fold_win2 = nullptr, *fold_win1 = nullptr;
+	const int2 *fold_win = nullptr;
+	int32_t fold_tile = -1;            // laboratory (HFDL_GPU_FOLD_TILE): index of the tiling to use instead of the first that fits
 };
 
-// Filter-tap layouts.  The fold runs on the fp32 matrix pipe: one wave load of 1 KiB (16 bytes per lane) must yield, register by
-// register, operand A of an instruction -- so the taps are stored in operand order (the forward FFT that makes them writes it directly).
-//   TAPL_OCTET (default; v_mfma_f32_16x16x1_4B_f32): 8 channels x 16 bins per KiB.  lane = 2 (c % 8) + comp + 16 (j % 4), register (j / 4) % 4
-//   TAPL_PAIR  (laboratory; v_mfma_f32_4x4x1_16B_f32): 2 channels x 64 bins per KiB. lane = 4 (j % 16) + 2 (c % 2) + comp, register (j / 16) % 4
-//   TAPL_PLAIN: rows of M cf32 per channel (geometries whose M is no multiple of 16: none that create accepts)
-enum { TAPL_PLAIN = 0, TAPL_PAIR = 1, TAPL_OCTET = 2 };
-// float index of (channel c, bin j, comp 0 = Re / 1 = Im) inside an alias row of 2 * tap_row_stride floats
-__host__ __device__ inline size_t tap_offset_f(int layout, int m, int c, int j, int comp)
+// Filter-tap layouts.  The fold runs on the fp32 matrix pipe -- v_mfma_f32_16x16x4_f32: D (16 x 16) += A (16 x 4) . B (4 x 16) with
+// the 16 rows = Re / Im of eight channels, the 4 inner indices = four consecutive alias rows, the 16 columns = sixteen blocks, for ONE
+// bin -- and one wave load of 1 KiB (16 bytes per lane) must yield, register by register, operand A of an instruction: the taps are
+// stored in operand order (the forward FFT that makes them writes it directly).
+//   TAPL_OCTET: 1 KiB = 4 alias rows x 8 channels x 4 bins: lane = 16 (row % 4) + 2 (c % 8) + comp, register j % 4; the bin quads of an
+//               octet follow each other (M / 4 KiB), then the octets, then the next four rows
+//   TAPL_PLAIN: rows of M cf32 per channel (geometries whose M is no multiple of 16 or whose row count is no multiple of 4)
+enum { TAPL_PLAIN = 0, TAPL_OCTET = 2 };
+// float index of (alias row, channel c, bin j, comp 0 = Re / 1 = Im) in the tap buffer; rs_f = floats per alias row of ALL channels
+// (2 * tap_row_stride), chan_stride_f = floats between channels of a row (TAPL_PLAIN)
+__host__ __device__ inline size_t tap_index_f(int layout, int m, size_t rs_f, int c, int row, int j, int comp)
 {
-	if (layout == TAPL_OCTET) return (size_t)(c >> 3) * 16 * m + (size_t)(j >> 4) * 256 + (size_t)(16 * (j & 3) + 2 * (c & 7) + comp) * 4 + ((j >> 2) & 3);
-	if (layout == TAPL_PAIR) return (size_t)(c >> 1) * 4 * m + (size_t)(j >> 6) * 256 + (size_t)(4 * (j & 15) + 2 * (c & 1) + comp) * 4 + ((j >> 4) & 3);
-	return ((size_t)c * m + j) * 2 + comp;
+	if (layout == TAPL_OCTET)
+		return (size_t)(row >> 2) * 4 * rs_f + (size_t)(c >> 3) * 64 * m + (size_t)(j >> 2) * 256 + (size_t)(16 * (row & 3) + 2 * (c & 7) + comp) * 4 + (j & 3);
+	return (size_t)row * rs_f + ((size_t)c * m + j) * 2 + comp;
 }
-inline int tap_layout_group(int layout) { return layout == TAPL_OCTET ? 8 : layout == TAPL_PAIR ? 2 : 1; }
+inline int tap_layout_group(int layout) { return layout == TAPL_OCTET ? 8 : 1; }
 
-constexpr int FOLD_MAX_BLOCKS = 16;         // blocks one fold launch can take (four groups of four columns of the 4x4x1 matrix instruction)
+constexpr int FOLD_MAX_BLOCKS = 16;         // blocks one fold launch can take: the sixteen columns of the matrix instruction
 
 // The NCO phasor table of a block, made while that block's forward FFT runs.  decimating_shift_addition_cc's phasor recurrence
 // (src/libcsdr_gpl.c:48-66) is 1792 strictly serial fp32 steps per channel at cfg3 -- 47 us for a lone lane, which used to be the
@@ -97,7 +101,7 @@ struct DevBuf {
 enum { SFMT_CF32 = 0, SFMT_CS16 = 1, SFMT_CU8 = 2 };
 // output index i of the transform is stored at (i >> row_log) * row_stride + (i & (2^row_log - 1)); row_log = 0: contiguous.
 // kind != TAPL_PLAIN: the transform is the filter of channel `chan`, `out` is the tap buffer, and element (row i >> row_log, bin) goes
-// to row * 2 * row_stride + tap_offset_f(kind, 2^row_log, chan, bin, comp) floats
+// to tap_index_f(kind, 2^row_log, 2 * row_stride, chan, row, bin, comp) floats
 struct FftOutLayout { int row_log = 0; int64_t row_stride = 0; int kind = 0; int chan = 0; };
 void launch_fft_forward(const FftPlan &p, const float2 *hist, const void *fresh, int fmt, int split, float2 *hist_next,
 		float2 *work, float2 *out, bool shifted, hipStream_t st, FftOutLayout lay = FftOutLayout(), hipEvent_t done = nullptr,

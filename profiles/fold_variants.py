@@ -43,7 +43,7 @@ for v, (p, q, wv, d, nbmax, layout) in enumerate(F.fold_variants()):
     if only is not None and v not in only:
         continue
     for nb in nbs:
-        if nb > nbmax or (layout == 1 and nb <= nbmax // 2 and nbmax > 4) or (layout == 2 and q == 4 and nb < 5 and os.environ.get('FOLD_SKIP_WIDE_SMALL')):        # a 4x4x1 tiling serves nb in (2 Q, 4 Q]; a 16x16x1 tiling any nb <= 16
+        if nb > nbmax:        # a 4x4x1 tiling serves nb in (2 Q, 4 Q]; a 16x16x1 tiling any nb <= 16
             continue
         try:
             avg, best, chk = fe.fold_variant_probe(v, nb, reps)
@@ -51,13 +51,13 @@ for v, (p, q, wv, d, nbmax, layout) in enumerate(F.fold_variants()):
             print("variant %d skipped: %s" % (v, e), file=sys.stderr)
             continue
         byt = bench.alg_bytes_per_launch(g, nb)
-        rows.append(dict(variant=v, family=("16x16x1_4B" if q == 4 else "4x4x1_16B, octet taps") if layout == 2 else "16x16x4 TIMING PROBE (sums wrong)" if layout < 0 else "4x4x1_16B, pair taps", P=p, Q=q, W=wv, D=d, NB=nb, avg_ms=avg, best_ms=best, ms_per_block=avg / nb, GBs=byt / (avg * 1e-3) / 1e9,
+        rows.append(dict(variant=v, family="16x16x4", P=p, Q=q, W=wv, D=d, NB=nb, avg_ms=avg, best_ms=best, ms_per_block=avg / nb, GBs=byt / (avg * 1e-3) / 1e9,
                          frac=byt / (avg * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, checksum=chk,
                          bit_identical_to_fma_reference=(chk == ref[nb][2]) if nb in ref else None))
 print("# matrix-pipe fold tilings on %s (M = %d, %d channels, %d slices x %d alias rows; %d launches each after one untimed)" %
       (wl, g.fft_inv_size, g.channels, g.fold_slices, g.pre_decimation // g.fold_slices, reps))
 print()
-print("P = channel groups (octets / pairs) per wave, Q = groups of four blocks, W = waves per workgroup, D = rows of loads in flight.  FMA-chain reference kernel: "
+print("P = channel octets per wave, W = waves per workgroup, D = quads of alias rows of loads in flight (Q = 4: up to 16 blocks).  FMA-chain reference kernel: "
       + ", ".join("%d blocks %.1f ms" % (nb, r[0]) for nb, r in sorted(ref.items())))
 print()
 print("| MFMA | P | Q | W | D | NB | ms / launch (avg) | best | ms / block | algorithmic GB/s | of 8 TB/s | same bits as the FMA-chain reference |")

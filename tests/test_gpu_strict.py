@@ -24,8 +24,11 @@ pytestmark = pytest.mark.gpu
 def test_strict_build_is_the_oracle_and_the_shipped_pipeline_is_strict_plus_four_fast_forms(gpu):
     import subprocess
     import strict_study as S
-    if not all(os.path.exists(os.path.join(ROOT, "build", "strict", "libhfdl_gpu_strict_%d.so" % f)) for f in (0, 15)):
-        # test-only libraries, built where the test runs (hipcc cross-compiles gfx950 anywhere): never part of the product build
+    libs = [os.path.join(ROOT, "build", "strict", "libhfdl_gpu_strict_%d.so" % f) for f in (0, 15)]
+    product = os.path.join(ROOT, "dumphfdl_amd", "libhfdl_gpu.so")
+    if not all(os.path.exists(l) and os.path.getmtime(l) >= os.path.getmtime(product) for l in libs):
+        # test-only libraries, built where the test runs (hipcc cross-compiles gfx950 anywhere): never part of the product build.  They
+        # link the product build's channelizer objects: one that is older than the product library carries another channelizer
         subprocess.check_call(["bash", os.path.join(ROOT, "dumphfdl_amd", "csrc", "build_strict.sh"), "0", "15"], stdout=subprocess.DEVNULL)
     out = S.run_study([-6, -2, 2], bursts_per_channel=2, builds=("shipped", "strict_0", "strict_15"))
     rows = out["rows"]

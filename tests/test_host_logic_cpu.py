@@ -85,7 +85,7 @@ def test_product_library_exports_exactly_the_public_header():
     assert not [s for s in prod if "probe" in s or "variant" in s or "_lab_" in s]
     assert os.path.getsize(hf.lib_path()) < 700 * 1024
     strings = subprocess.run(["strings", hf.lib_path()], capture_output=True, text=True).stdout
-    for knob in ("HFDL_GPU_FFT_STREAM", "HFDL_GPU_DECODE_STREAM", "HFDL_GPU_FOLD_TILE", "HFDL_GPU_FOLD_MFMA", "HFDL_GPU_PROBE_VERBOSE"):
+    for knob in ("HFDL_GPU_FFT_STREAM", "HFDL_GPU_DECODE_STREAM", "HFDL_GPU_FOLD_TILE", "HFDL_GPU_FOLD_BOUND", "HFDL_GPU_PROBE_VERBOSE"):
         assert knob not in strings, knob
     for knob in ("HFDL_GPU_FOLD_BATCH", "HFDL_GPU_DEMOD_BATCH", "HFDL_GPU_HOST_THREADS", "HFDL_GPU_PDU_RING"):      # the documented create-time configuration
         assert knob in strings, knob
