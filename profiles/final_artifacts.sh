@@ -46,7 +46,6 @@ for name in ("cfg3", "cfg2"):
 print(json.dumps(out))
 PY
 timeout 300 python profiles/fold_variants.py cfg3 3 1,2,4,8,16 > $OUT/fold_variants_cfg3.md 2>> $OUT/bench.err
-HFDL_GPU_FOLD_MFMA=4 timeout 300 python profiles/fold_variants.py cfg3 3 4,8,16 > $OUT/fold_variants_cfg3_4x4x1.md 2>> $OUT/bench.err
 timeout 300 python profiles/fft_accuracy.py > $OUT/fft_accuracy.txt 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg3 cfg2 cfg4; do
