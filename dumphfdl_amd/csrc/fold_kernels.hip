@@ -82,6 +82,9 @@ constexpr int fold16_waves(int p, int w, int d, bool small = false)
 {
 	const int mine = w >= 8 ? 1 : 8 / w;
 	const int regs = (small ? 16 : 64) * p + 16 * p * d + 4 * mine * d + 4 * mine + 8 + 28;
+	// the four-column form never takes more than two waves of a SIMD: it is bound by the HBM reads, and a third wave would take the
+	// registers the demodulator's waves need beside it (a 2-block demodulator launch beside a 3-wave 4-block fold: 1.7 ms instead of 0.5)
+	if (small) return regs <= 168 ? 2 : 1;
 	return regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : regs <= 256 ? 2 : 1;
 }
 
