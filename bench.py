@@ -917,8 +917,9 @@ def main():
             "streams": stream_budget(stages, args.steps, fold_batch),
             # The dominant kernel: the fold.  Since round 5 it multiplies ONE pass over the filter taps into the spectra of up to 16 queued
             # blocks on the fp32 matrix pipe, all sixteen columns of the instruction always computed: its time does not move with the blocks
-            # in a launch (4.0 ms at 4, 8 or 16) -- the multiplies bound it, at the clock the board's power budget leaves beside 4.5 TB/s of
-            # HBM reads (PMC: profiles/r05_experiments.md) -- so the roofline is the matrix pipe's; the HBM side of the same launch is `hbm`.
+            # in a launch (3.9 - 4.2 ms at 5 .. 16) -- the multiplies bound it, at the clock the board's power budget leaves beside 4.6 TB/s
+            # of HBM reads (PMC: profiles/r05_experiments.md) -- so the roofline is the matrix pipe's; the HBM side of the same launch is
+            # `hbm`.  Launches of at most four blocks run the four-column form, bound by the HBM reads: priced as such when they dominate.
             "roofline": {"bound": "mfma" if wide else "hbm",
                          "kernel": "fold_mfma16_kernel (v_mfma_f32_16x16x4_f32: four alias rows per instruction)" if wide else "fold_mfma16_kernel, four-column form (v_mfma_f32_4x4x1_16B_f32)",
                          "achieved": tflops if wide else achieved, "peak": FP32_MFMA_PEAK_TFLOPS if wide else HBM_PEAK_GBS, "unit": "TFLOP/s" if wide else "GB/s",

@@ -416,7 +416,7 @@ static int build_taps(hfdl_gpu_frontend *fe)
 	for (int c = 0; c < nch; c++) {
 		HIP_TRY(hipMemcpyAsync(d_pad, host.data() + (size_t)c * pl.taps_length, sizeof(float2) * (size_t)pl.taps_length,
 				hipMemcpyHostToDevice, fe->stream));
-		// the last pass writes the channel's filter straight into the matrix-operand layout (kernels.h tap_offset_f)
+		// the last pass writes the channel's filter straight into the matrix-operand layout (kernels.h tap_index_f)
 		FftOutLayout lay = fe->tap_layout;
 		lay.chan = c;
 		float2 *dst = lay.kind == TAPL_PLAIN ? fe->d_taps + (size_t)c * (size_t)fe->geo.tap_chan_stride : fe->d_taps;

@@ -80,7 +80,7 @@ LAB_EXPORTS = ["hfdl_gpu_lab_fold_variant_count", "hfdl_gpu_lab_fold_variant_des
 
 
 def fold_variants():
-    """The compiled tilings of the matrix-pipe fold kernel in the laboratory build: [(P, Q, W, D, max blocks, 0)]."""
+    """The compiled tilings of the matrix-pipe fold kernel in the laboratory build: [(P, Q, W, D, max blocks, tap layout)]."""
     L = load_lab()
     out = []
     for v in range(L.hfdl_gpu_lab_fold_variant_count()):

@@ -17,8 +17,8 @@
 extern "C" {
 #endif
 
-/* the compiled tilings of the matrix-pipe fold kernel: desc = { channel pairs per wave, groups of four blocks, waves per workgroup,
- * rows of loads in flight, max blocks per launch, 0 } */
+/* the compiled tilings of the matrix-pipe fold kernel: desc = { channel octets per wave, groups of four blocks (4: the sixteen-column
+ * form, 1: the four-column form), waves per workgroup, quads of alias rows of loads in flight, max blocks per launch, tap layout } */
 int  hfdl_gpu_lab_fold_variant_count(void);
 int  hfdl_gpu_lab_fold_variant_describe(int variant, int32_t desc[6]);
 /* `reps` timed launches of one tiling (variant -1: the plain-VALU FMA-chain reference kernel) folding `nb` blocks over the front end's

@@ -43,7 +43,7 @@ for v, (p, q, wv, d, nbmax, layout) in enumerate(F.fold_variants()):
     if only is not None and v not in only:
         continue
     for nb in nbs:
-        if nb > nbmax:        # a 4x4x1 tiling serves nb in (2 Q, 4 Q]; a 16x16x1 tiling any nb <= 16
+        if nb > nbmax:        # the four-column form takes at most 4 blocks, the sixteen-column form any count up to 16
             continue
         try:
             avg, best, chk = fe.fold_variant_probe(v, nb, reps)
