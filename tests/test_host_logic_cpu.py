@@ -450,3 +450,15 @@ def test_abi_argument_checks_need_no_device():
     assert b"null" in L.hfdl_gpu_last_error()
     L.hfdl_gpu_frontend_destroy(None)                      # like free(NULL)
     assert L.hfdl_gpu_frontend_stream(None) is None
+
+
+def test_tap_layout_is_the_matrix_operand_order(tmp_path):
+    """kernels.h tap_index_f (TAPL_OCTET) on the host: a bijection; one KiB = four alias rows x eight channels x four bins with lane =
+    16 (row % 4) + 2 (c % 8) + comp and register = bin % 4 -- operand A of v_mfma_f32_16x16x4_f32 for one bin, register by register;
+    the bin quads of an octet, the octets and the quads of rows in that order (tests/hostsim/tap_layout_check.cpp; the device side of
+    the same contract is tests/test_gpu_parity.py::test_fold_mfma_equals_fma_chain and the channelizer's parity with the oracle)."""
+    exe = str(tmp_path / "tap_layout_check")
+    subprocess.check_call(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "dumphfdl_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "hostsim", "tap_layout_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
