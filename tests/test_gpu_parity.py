@@ -902,11 +902,12 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
     """One fold launch multiplies the spectra of up to geometry.fold_batch (16) queued blocks against ONE pass over the filter taps on
     the matrix pipe (fold_kernels.hip; src/fastddc.c:123-150 run for that many blocks).  Every bin's sum is the same FMA chain whatever
     the company, so the channelizer output of EVERY block -- read back per block, compared as uint32 -- and every PDU equal those of a
-    pass over the taps per block (HFDL_GPU_FOLD_BATCH=1), for full batches of 16 / 8 / 4 / 2 and the ragged batches that draining
-    polls / syncs cut (13, 7, 5, 3, 1 blocks: columns of the 4x4 tiles left empty).  5 channels: demodulator-bound geometry (several
-    blocks per demodulator launch, an odd channel padded to a pair, only the single-wave workgroups of the left-over pairs run);
-    130 channels: fold-bound shape (eight 16-channel workgroups + one left-over pair; demodulator launches held back behind the next
-    half's forward FFTs)."""
+    pass over the taps per block (HFDL_GPU_FOLD_BATCH=1: the four-column form of the kernel, K = 1 products in the order of the K = 4
+    instruction), for full batches of 16 / 8 (the sixteen-column form) / 4 / 2 and the ragged batches that draining polls / syncs
+    cut (13, 7, 5: columns past the last block computed and dropped; 3, 1: the four-column form).  5 channels: demodulator-bound
+    geometry (several blocks per demodulator launch, five channels padded to an octet, only the single-wave workgroups of the
+    left-over octets run); 130 channels: fold-bound shape (two 64-channel workgroups + one left-over octet; demodulator launches
+    held back behind the next half's forward FFTs)."""
     cf = 10_000_000
     rng = np.random.default_rng(nch)
     if nch == 5:
