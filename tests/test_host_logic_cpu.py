@@ -87,7 +87,7 @@ def test_product_library_exports_exactly_the_public_header():
     strings = subprocess.run(["strings", hf.lib_path()], capture_output=True, text=True).stdout
     for knob in ("HFDL_GPU_FFT_STREAM", "HFDL_GPU_DECODE_STREAM", "HFDL_GPU_FOLD_TILE", "HFDL_GPU_FOLD_BOUND", "HFDL_GPU_PROBE_VERBOSE"):
         assert knob not in strings, knob
-    for knob in ("HFDL_GPU_FOLD_BATCH", "HFDL_GPU_DEMOD_BATCH", "HFDL_GPU_HOST_THREADS", "HFDL_GPU_PDU_RING"):      # the documented create-time configuration
+    for knob in ("HFDL_GPU_FOLD_BATCH", "HFDL_GPU_DEMOD_BATCH", "HFDL_GPU_HOST_THREADS", "HFDL_GPU_PDU_RING", "HFDL_GPU_FOLD_PRUNE"):      # the documented create-time configuration
         assert knob in strings, knob
     lab_path = hf.frontend.lab_lib_path()
     if os.path.exists(lab_path):
