@@ -488,6 +488,16 @@ def traffic_record(workload, shapes=None, launches=None):
         return None, None
 
 
+def dominant_shape(shape_times):
+    """{blocks per launch: (launches, kernel ms)} -> (blocks, launches, average ms) of the launch shape the run spent most of its fold
+    time in -- what `roofline` is priced on -- or (0, 0, None) when nothing was timed.  Ties go to the larger shape."""
+    if not shape_times:
+        return 0, 0, None
+    nb = max(shape_times, key=lambda k: (shape_times[k][1], k))
+    n, ms = shape_times[nb]
+    return nb, n, ms / n
+
+
 def alg_bytes_per_block(g):
     """B = 8*input_size + C*8*N + C*8*(post_input_size/post_decimation) algorithmic bytes per block."""
     return 8 * g.input_size + g.channels * 8 * g.fft_size + g.channels * 8 * (g.post_input_size // g.post_decimation)
@@ -852,8 +862,7 @@ def main():
     demod_batch = g.demod_batch
     # the roofline is priced on ONE launch shape: the one the run spent most of its fold time in (the full halves; the ragged end of a
     # run is a launch of its own -- up to 4 blocks: the four-column form of the kernel -- and listed beside it)
-    dom = max(shape_times, key=lambda nb: shape_times[nb][1]) if shape_times else 0
-    dom_n, dom_ms = (shape_times[dom][0], shape_times[dom][1] / shape_times[dom][0]) if dom else (0, None)
+    dom, dom_n, dom_ms = dominant_shape(shape_times)
     fold_nb = float(dom) if dom else 1.0
     alg_bytes = alg_bytes_per_launch(g, fold_nb)
     alg_bytes_block = alg_bytes / fold_nb

@@ -81,3 +81,14 @@ def test_xcd_aware_tile_placement_is_a_bijection():
             for x in range(8):
                 order = [place(b, ntile, groups)[0] for b in range(x, ntile * groups, 8)]         # this XCD's blocks in dispatch order
                 assert order == sorted(order) and all(order[i:i + groups] == [order[i]] * groups for i in range(0, len(order), groups))
+
+
+def test_roofline_is_priced_on_the_shape_that_dominates():
+    """bench.dominant_shape: the driver's 20 steps = one 16-block launch (sixteen-column form, ~4 ms) + one 4-block launch (four-column
+    form, ~2.7 ms): priced on the 16-block shape; HFDL_GPU_FOLD_BATCH=1 (256 one-block launches): on that one; nothing timed: nothing."""
+    assert bench.dominant_shape({16: (1, 3.99), 4: (1, 2.72)}) == (16, 1, 3.99)
+    assert bench.dominant_shape({1: (256, 256 * 2.6)})[:2] == (1, 256)
+    nb, n, avg = bench.dominant_shape({16: (16, 64.0), 8: (1, 3.5)})
+    assert (nb, n) == (16, 16) and abs(avg - 4.0) < 1e-12
+    assert bench.dominant_shape({4: (2, 5.0), 8: (1, 5.0)})[0] == 8          # a tie goes to the larger shape
+    assert bench.dominant_shape({}) == (0, 0, None)
