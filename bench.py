@@ -414,15 +414,20 @@ def host_path_leg(w, x, freqs, fmt="CF32", dev_index=0, seconds_cap=120):
             pass
 
 
+# the sources that decide the fold launch's memory traffic: the kernel and its launcher, the tap / spectrum layouts and the geometry
+FOLD_SOURCES = ("fold_kernels.hip", "kernels.h", "fft_core.h")
+
+
 def csrc_hash():
-    """sha256 (16 hex digits) over the device sources, dumphfdl_amd/csrc/*.{hip,h,cpp} in name order: identifies the kernels a
-    measurement was made with (profiles/fold_traffic.py stamps it into the traffic record; this run compares it with its own tree)."""
+    """sha256 (16 hex digits) over the sources of the ROOFLINE KERNEL -- dumphfdl_amd/csrc/{fold_kernels.hip, kernels.h, fft_core.h} in
+    that order: identifies the fold a traffic measurement was made with (profiles/fold_traffic.py stamps it into the traffic record; this
+    run compares it with its own tree).  Until round 6 the hash ran over every file of csrc/: an edit of the demodulator then withheld a
+    traffic figure it cannot have changed."""
     import hashlib
     d = os.path.join(ROOT, "dumphfdl_amd", "csrc")
     h = hashlib.sha256()
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):
-            h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read())
+    for name in FOLD_SOURCES:
+        h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -56,6 +56,7 @@ struct Demod {
 	int stats_all(hfdl_gpu_channel_stats *out, int n);
 	int tap(int what, int channel, const void **src, size_t *nfloats);
 	int stats(int channel, hfdl_gpu_channel_stats *out);
+	int read_constants(void *tables, size_t tables_bytes, void *constants, size_t constants_bytes);   // laboratory read-back: sizeof(DemodTables), sizeof(HfdlConstants)
 	void release();
 };
 

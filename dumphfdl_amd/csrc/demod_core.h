@@ -114,7 +114,7 @@ struct PipeProgress {
 __device__ __forceinline__ void agc_mf_chunk(float &g, float &y2, const ChanArrays &a, const DemodConst &T, const BlockIo &io, int a0, int a1, int lane)
 {
 	// agc_crcf_execute (src/hfdl.c:686): a per-sample gain recurrence, wave-uniform
-	const float alpha = 0.01f;
+	const float alpha = AGC_BANDWIDTH;
 	const cf xin = (a0 + lane < a1 && lane < DM_CHUNK) ? io.rs[a0 + lane] : cf{0.f, 0.f};      // the chunk, one sample per lane
 	for (int k = a0; k < a1; k++) {
 		cf x; x.x = lane_value(xin.x, k - a0); x.y = lane_value(xin.y, k - a0);
@@ -377,17 +377,17 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 	auto catch_up = [&](int upto) {
 		if (s.fr_state == FR_A1) {
 			const uint32_t d = (uint32_t)(upto + 1 - kdone), c0 = s.nf_clk;
-			uint32_t first = (0xFFu - c0) & 0xFFu;          // ticks until the low byte reads 0xFF (0: a whole turn)
-			if (first == 0) first = 256;
+			uint32_t first = (NF_CLK_MASK - c0) & NF_CLK_MASK;          // ticks until the low byte reads 0xFF (0: a whole turn)
+			if (first == 0) first = NF_CLK_MASK + 1;
 			s.nf_clk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 + d));
 			if (first <= d) {                                // at most once: d <= 64
 				const float level = lane_value(lv_l, kdone + (int)first - 1);
-				s.noise_floor = 0.65f * s.noise_floor + 0.35f * fminf(s.noise_floor, level) + 1e-6f;
+				s.noise_floor = NF_KEEP * s.noise_floor + NF_TAKE * fminf(s.noise_floor, level) + NF_BIAS;
 			}
 		}
 		kdone = upto + 1;
 	};
-	bool runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
+	bool runaway = fabsf(s.dphi) > COSTAS_RUNAWAY_DPHI && s.fr_state == FR_A1;
 	const int pair_sel = (lane & 1) << 2;        // byte offset of the pair's second output in a lane permute
 	for (int j = jbase; j < jstop;) {
 #ifdef HFDL_DM_PROBE
@@ -491,8 +491,8 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 					const float er = tv - y.x, ei = -(0.0f - y.y);
 					const float bx = row1 ? -c.ev : c.eu, by = row1 ? c.eu : c.ev;       // the window sample (x, y) in either row
 					const float pr = er * bx - ei * by, pi = er * by + ei * bx;
-					c.ewx = c.ewx + 0.1f * pr / s.eq_x2sum;
-					c.ewy = c.ewy + 0.1f * pi / s.eq_x2sum;
+					c.ewx = c.ewx + EQ_STEP * pr / s.eq_x2sum;
+					c.ewy = c.ewy + EQ_STEP * pi / s.eq_x2sum;
 				}
 				s.T_idx++;
 			}
@@ -511,15 +511,15 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				const uint64_t nhi = ((s.bits_hi << 1) | (s.bits_lo >> 63)) & 0x7FFFFFFFFFFFFFFFull, nlo = (s.bits_lo << 1) | bit;
 				const int m = bits_correlate(nhi, nlo, T.a_hi, T.a_lo);
 				if (__builtin_expect(m > T.a1_lo && m < T.a1_hi && s.s_state == SAMPLER_BITS && s.cur_arity == 1 && s.symbols_wanted <= 1
-						&& s.symbol_cnt + 1 < (uint64_t)(13 * SINGLE_SLOT_FRAME_LEN), 1)) {
+						&& s.symbol_cnt + 1 < (uint64_t)(NO_FRAME_TIMEOUT_FRAMES * SINGLE_SLOT_FRAME_LEN), 1)) {
 					const float perr = y.y * (neg ? -1.0f : 1.0f) - y.x * 0.0f;      // modem phase error against (+-1, 0), as LaneSlicer writes it
-					const float e = 0.5f * (fabsf(perr + 1.0f) - fabsf(perr - 1.0f));      // costas_cccf_adjust, :276-281
+					const float e = 0.5f * (fabsf(perr + COSTAS_ERR_LIMIT) - fabsf(perr - COSTAS_ERR_LIMIT));      // costas_cccf_adjust, :276-281
 					s.err = e;
-					s.phi += 0.1f * e;
-					s.dphi += (0.047f * 0.1f * 0.1f) * e;
+					s.phi += COSTAS_ALPHA * e;
+					s.dphi += COSTAS_BETA * e;
 					s.symbol_cnt++;
 					s.bits_hi = nhi; s.bits_lo = nlo;
-					runaway = fabsf(s.dphi) > 0.25f;
+					runaway = fabsf(s.dphi) > COSTAS_RUNAWAY_DPHI;
 					plain = true;
 				}
 			}
@@ -533,10 +533,10 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				const float level = lane_value(lv_l, ki);
 				float perr;
 				uint32_t bits = LaneSlicer{c.px, c.py, lane}(s.cur_arity, y, &perr);
-				const float e = 0.5f * (fabsf(perr + 1.0f) - fabsf(perr - 1.0f));      // costas_cccf_adjust, :276-281
+				const float e = 0.5f * (fabsf(perr + COSTAS_ERR_LIMIT) - fabsf(perr - COSTAS_ERR_LIMIT));      // costas_cccf_adjust, :276-281
 				s.err = e;
-				s.phi += 0.1f * e;
-				s.dphi += (0.047f * 0.1f * 0.1f) * e;
+				s.phi += COSTAS_ALPHA * e;
+				s.dphi += COSTAS_BETA * e;
 				s.symbol_cnt++;
 				if (s.s_state == SAMPLER_SYMBOLS) {
 					if (s.use_data) {
@@ -570,7 +570,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 				const float level = lane_value(lv_l, ki);
 				s.sample_cnt = cnt0 + (uint64_t)ki;
 				on_symbol(s, *sh.S, a, T, io, y, level, LaneSlicer{c.px, c.py, lane});
-				runaway = fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1;
+				runaway = fabsf(s.dphi) > COSTAS_RUNAWAY_DPHI && s.fr_state == FR_A1;
 			}
 		}
 #if defined(HFDL_DM_PROBE) && HFDL_DM_PROBE >= 2

@@ -533,6 +533,17 @@ __global__ void lpdu_walk_kernel(const uint8_t *__restrict__ octets, const int32
 	o[0] = c.processed; o[1] = c.good; o[2] = c.bad_fcs; o[3] = c.too_short; o[4] = c.truncated;
 }
 
+// read-back of the named constants and the tables computed from them AS THE DEVICE SEES THEM (laboratory entry point
+// hfdl_gpu_lab_read_constants; compared with the reference's text in tests/test_gpu_constants.py)
+__global__ void constants_kernel(HfdlConstants *out)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		HfdlConstants k;
+		hfdl_constants(k);
+		*out = k;
+	}
+}
+
 // ---------------------------------------------------------------- host side
 
 #define D_TRY(expr) do { if ((expr) != hipSuccess) return HFDL_GPU_EHIP; } while (0)
@@ -794,6 +805,21 @@ void Demod::release()
 	d_tap_rs = d_tap_mf = d_tap_sym = nullptr; d_tap_lvl = nullptr; d_tap_counts = nullptr;
 	delete (DemodPriv *)priv;
 	priv = nullptr;
+}
+
+// the DemodTables image resident on the device and the device's own evaluation of hfdl_constants()
+int Demod::read_constants(void *tables, size_t tables_bytes, void *constants, size_t constants_bytes)
+{
+	if (tables_bytes != sizeof(DemodTables) || constants_bytes != sizeof(HfdlConstants) || !d_tables) return HFDL_GPU_EINVAL;
+	DevBuf d_k;
+	D_TRY(d_k.alloc(sizeof(HfdlConstants)));
+	D_TRY(hipMemset(d_k.p, 0xff, sizeof(HfdlConstants)));
+	hipLaunchKernelGGL(constants_kernel, dim3(1), dim3(64), 0, nullptr, d_k.as<HfdlConstants>());
+	D_TRY(hipDeviceSynchronize());
+	D_TRY(hipGetLastError());
+	D_TRY(hipMemcpy(constants, d_k.p, sizeof(HfdlConstants), hipMemcpyDeviceToHost));
+	D_TRY(hipMemcpy(tables, d_tables, sizeof(DemodTables), hipMemcpyDeviceToHost));
+	return 0;
 }
 
 int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out, double *kernel_ms)

@@ -24,8 +24,20 @@ constexpr int D_RS_NPFB = 256, D_RS_TAPS = 14, D_SS_NPFB = 16, D_SS_TAPS = 18, D
 constexpr int MAX_DATA_SYMBOLS = 168 * 30;
 
 // framer constants, src/hfdl.c:29-46
-constexpr int A_LEN = 127, M1_LEN = 127, M2_LEN = 15, T_LEN = 15, DATA_FRAME_LEN = 30;
-constexpr int SINGLE_SLOT_FRAME_LEN = 448 + (2 * 127 + 127 + 15 + 9 * 15) + 72 * 45;
+constexpr int PREKEY_LEN = 448, A_LEN = 127, M1_LEN = 127, M2_LEN = 15, T_LEN = 15, DATA_FRAME_LEN = 30, PREAMBLE_T_SEQS = 9;
+constexpr int SINGLE_SLOT_FRAME_LEN = PREKEY_LEN + (2 * A_LEN + M1_LEN + M2_LEN + PREAMBLE_T_SEQS * T_LEN) + 72 * (DATA_FRAME_LEN + T_LEN);
+// The numeric constants of the reference's hot path this file and demod_core.h use, BY NAME, so that they can be read back and compared
+// with the reference's own text: tests/golden/hfdl_constants.json (parsed from src/hfdl.c by tests/golden/make_constants.py) meets them
+// through tests/hostsim on the CPU and through a read-back kernel on the device (hfdl_constants() below).
+constexpr float CORR_THRESHOLD_A1 = 0.36f, CORR_THRESHOLD_A2 = 0.3f, CORR_THRESHOLD_M1 = 0.3f;      // src/hfdl.c:42-44
+constexpr int MAX_SEARCH_RETRIES = 3, NO_FRAME_TIMEOUT_FRAMES = 13;                                  // :45, :613
+constexpr int HFDL_SYMBOL_RATE = 1800, HFDL_SPS = 3;                                                 // src/hfdl.h:6-7
+constexpr float COSTAS_ALPHA = 0.1f, COSTAS_BETA = 0.047f * COSTAS_ALPHA * COSTAS_ALPHA;            // costas_cccf_create, :252-253
+constexpr float COSTAS_ERR_LIMIT = 1.0f, COSTAS_RUNAWAY_DPHI = 0.25f;                                // :276, :709
+constexpr float AGC_BANDWIDTH = 0.01f, EQ_STEP = 0.1f;                                               // agc_crcf_set_bandwidth :487, eqlms_cccf_set_bw :496
+constexpr float NF_KEEP = 0.65f, NF_TAKE = 0.35f, NF_BIAS = 1e-6f;                                   // noise-floor estimator, :700-701
+constexpr uint32_t NF_CLK_MASK = 0xFFu;                                                              // ... sampled when the low byte of its clock reads 0xFF, :699
+constexpr uint32_t T_SEQ_BITS = 0x9AFu;                                                              // T_seq[0], :157-160: bit 14 first, 0 -> +1
 enum { SAMPLER_BITS = 1, SAMPLER_SYMBOLS = 2, SAMPLER_SKIP = 3 };
 enum { FR_A1 = 1, FR_A2, FR_M1, FR_M2_SKIP, FR_EQ_TRAIN, FR_DATA_1, FR_DATA_2 };
 
@@ -363,10 +375,10 @@ HFDL_FN int bits_correlate(uint64_t hi, uint64_t lo, uint64_t thi, uint64_t tlo)
 	return 127 - __popcll((hi ^ thi) & 0x7FFFFFFFFFFFFFFFull) - __popcll(lo ^ tlo);
 }
 
-HFDL_FN float t_symbol(int idx)          // T = 0x9AF, bit 14 first; BPSK 0 -> +1
+HFDL_HD float t_symbol(int idx)          // T = 0x9AF, bit 14 first; BPSK 0 -> +1
 {
-	if (idx > 14) idx = 14;
-	return ((0x9AFu >> (14 - idx)) & 1u) ? -1.0f : 1.0f;
+	if (idx > T_LEN - 1) idx = T_LEN - 1;
+	return ((T_SEQ_BITS >> (T_LEN - 1 - idx)) & 1u) ? -1.0f : 1.0f;
 }
 
 // everything after the equaliser for one on-time symbol: src/hfdl.c:737-891
@@ -382,13 +394,13 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 	float perr;
 	uint32_t bits = slice(s.cur_arity, sym, &perr);
 	{   // costas_cccf_adjust, :276-281
-		const float e = 0.5f * (fabsf(perr + 1.0f) - fabsf(perr - 1.0f));
+		const float e = 0.5f * (fabsf(perr + COSTAS_ERR_LIMIT) - fabsf(perr - COSTAS_ERR_LIMIT));
 		s.err = e;
-		s.phi += 0.1f * e;
-		s.dphi += (0.047f * 0.1f * 0.1f) * e;
+		s.phi += COSTAS_ALPHA * e;
+		s.dphi += COSTAS_BETA * e;
 	}
 	s.symbol_cnt++;
-	if (s.symbol_cnt >= (uint64_t)(13 * SINGLE_SLOT_FRAME_LEN) && s.fr_state == FR_A1) {
+	if (s.symbol_cnt >= (uint64_t)(NO_FRAME_TIMEOUT_FRAMES * SINGLE_SLOT_FRAME_LEN) && s.fr_state == FR_A1) {
 		s.symbol_cnt = 0;
 		s.dphi = s.phi = 0.0f;
 		symsync_reset(s, a);
@@ -437,11 +449,11 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 			c.cnt_a2_found++;                    // statsd "demod.preamble.A2_found"
 			c.sum_a2_dev += (uint32_t)(2 * m > 127 ? 2 * m - 127 : 127 - 2 * m);
 			c.pdu_sample_index = s.sample_cnt;
-			c.freq_err_hz = (float)((double)(s.dphi * 1800) / (2.0 * M_PI));
+			c.freq_err_hz = (float)((double)(s.dphi * HFDL_SYMBOL_RATE) / (2.0 * M_PI));
 			s.symbols_wanted = M1_LEN;
 			c.search_retries = 0;
 			s.fr_state = FR_M1;
-		} else if (++c.search_retries >= 3) {
+		} else if (++c.search_retries >= MAX_SEARCH_RETRIES) {
 			framer_reset(s, c, a, T.eq_h0);
 		}
 		break; }
@@ -453,7 +465,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 			const float corr = fabsf(T.corr_tab[cnt]);
 			if (corr > best) { best = corr; best_idx = m; best_cnt = cnt; }
 		}
-		if (fabsf(best) > 0.3f) {
+		if (fabsf(best) > CORR_THRESHOLD_M1) {
 			const ModeParams mp = mode_params(best_idx);
 			c.cnt_m1_found++;                    // "demod.preamble.M1_found"
 			c.sum_m1_dev += (uint32_t)(2 * best_cnt > 127 ? 2 * best_cnt - 127 : 127 - 2 * best_cnt);
@@ -472,7 +484,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 	case FR_M2_SKIP:
 		s.training_n = 0;
 		s.symbols_wanted = T_LEN;
-		c.eq_train_seq_cnt = 9;
+		c.eq_train_seq_cnt = PREAMBLE_T_SEQS;
 		s.fr_state = FR_EQ_TRAIN;
 		s.s_state = SAMPLER_SYMBOLS;
 		break;
@@ -484,7 +496,7 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 			bit ^= (s.bitmask & 1u);
 			seq = (seq << 1) | bit;
 		}
-		const int train_err = __popc(0x9AFu ^ seq);
+		const int train_err = __popc(T_SEQ_BITS ^ seq);
 		c.train_total += T_LEN;
 		c.train_bad += train_err;
 		c.cum_train_total += T_LEN;              // S.train_bits_total / S.train_bits_bad, :962-963
@@ -532,6 +544,38 @@ HFDL_FN void on_symbol(ChanScalars &s, ChanScalars &c, ChanArrays &a, const Demo
 		s.T_idx = 0;
 		break;
 	}
+}
+
+// The constants above and the tables this file computes from them (mode table, training sequence), gathered for a read-back: the same
+// function runs on the host (tests/hostsim) and on the device (constants_kernel, laboratory entry point hfdl_gpu_lab_read_constants),
+// and both are compared with the reference's text (tests/golden/hfdl_constants.json).
+struct HfdlConstants {
+	int32_t prekey_len, a_len, m1_len, m2_len, t_len, data_frame_len, preamble_t_seqs, single_slot_frame_len, max_data_symbols;
+	int32_t max_search_retries, no_frame_timeout_frames, symbol_rate, sps, eq_len, mf_taps, ss_npfb, nf_clk_mask;
+	int32_t sampler_states[3], framer_states[7];
+	int32_t modes[8][4];                   // mode_params(m): bits per symbol, data segments, code rate, interleaver column shift
+	float corr_a1, corr_a2, corr_m1, costas_alpha, costas_beta, costas_err_limit, costas_runaway_dphi, agc_bandwidth, eq_step;
+	float nf_keep, nf_take, nf_bias;
+	float t_seq[15];                       // t_symbol(i): T_seq[0]
+};
+HFDL_HD void hfdl_constants(HfdlConstants &k)
+{
+	k.prekey_len = PREKEY_LEN; k.a_len = A_LEN; k.m1_len = M1_LEN; k.m2_len = M2_LEN; k.t_len = T_LEN; k.data_frame_len = DATA_FRAME_LEN;
+	k.preamble_t_seqs = PREAMBLE_T_SEQS; k.single_slot_frame_len = SINGLE_SLOT_FRAME_LEN; k.max_data_symbols = MAX_DATA_SYMBOLS;
+	k.max_search_retries = MAX_SEARCH_RETRIES; k.no_frame_timeout_frames = NO_FRAME_TIMEOUT_FRAMES; k.symbol_rate = HFDL_SYMBOL_RATE; k.sps = HFDL_SPS;
+	k.eq_len = D_EQ; k.mf_taps = D_MF; k.ss_npfb = D_SS_NPFB; k.nf_clk_mask = (int32_t)NF_CLK_MASK;
+	k.sampler_states[0] = SAMPLER_BITS; k.sampler_states[1] = SAMPLER_SYMBOLS; k.sampler_states[2] = SAMPLER_SKIP;
+	k.framer_states[0] = FR_A1; k.framer_states[1] = FR_A2; k.framer_states[2] = FR_M1; k.framer_states[3] = FR_M2_SKIP;
+	k.framer_states[4] = FR_EQ_TRAIN; k.framer_states[5] = FR_DATA_1; k.framer_states[6] = FR_DATA_2;
+	for (int m = 0; m < 8; m++) {
+		const ModeParams p = mode_params(m);
+		k.modes[m][0] = p.arity; k.modes[m][1] = p.segments; k.modes[m][2] = p.code_rate; k.modes[m][3] = p.col_shift;
+	}
+	k.corr_a1 = CORR_THRESHOLD_A1; k.corr_a2 = CORR_THRESHOLD_A2; k.corr_m1 = CORR_THRESHOLD_M1;
+	k.costas_alpha = COSTAS_ALPHA; k.costas_beta = COSTAS_BETA; k.costas_err_limit = COSTAS_ERR_LIMIT; k.costas_runaway_dphi = COSTAS_RUNAWAY_DPHI;
+	k.agc_bandwidth = AGC_BANDWIDTH; k.eq_step = EQ_STEP;
+	k.nf_keep = NF_KEEP; k.nf_take = NF_TAKE; k.nf_bias = NF_BIAS;
+	for (int i = 0; i < 15; i++) k.t_seq[i] = t_symbol(i);
 }
 
 }  // namespace hfdl

@@ -8,6 +8,7 @@
 //   eqlms_cccf_create_lowpass(15, 0.45), bw 0.1           src/hfdl.c:495-496
 //   bsequence A / M1[8], descrambler LFSR                 src/hfdl.c:300-347,419-459
 #pragma once
+#include "demod_logic.h"       // the named constants of src/hfdl.c (thresholds, lengths); every user includes it first anyway
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -162,8 +163,8 @@ inline void build_demod_tables(DemodTables &t, float resamp_rate)
 	t.a1_lo = t.a2_lo = -1; t.a1_hi = t.a2_hi = t.pos_min = 128; t.thr_pad = 0;
 	for (int m = 0; m < 128; m++) {
 		const float c = t.corr_tab[m];
-		if (std::fabs(c) > 0.36f) { if (c < 0.f) t.a1_lo = m; else if (m < t.a1_hi) t.a1_hi = m; }
-		if (std::fabs(c) > 0.3f) { if (c < 0.f) t.a2_lo = m; else if (m < t.a2_hi) t.a2_hi = m; }
+		if (std::fabs(c) > CORR_THRESHOLD_A1) { if (c < 0.f) t.a1_lo = m; else if (m < t.a1_hi) t.a1_hi = m; }
+		if (std::fabs(c) > CORR_THRESHOLD_A2) { if (c < 0.f) t.a2_lo = m; else if (m < t.a2_hi) t.a2_hi = m; }
 		if (c > 0.f && m < t.pos_min) t.pos_min = m;
 	}
 	// --- PSK constellations, in the modem's own fp32 expressions (alpha = pi / M as float, angle = s * 2 * alpha)

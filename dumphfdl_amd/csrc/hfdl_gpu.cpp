@@ -206,6 +206,20 @@ struct hfdl_gpu_frontend {
 	int prev_demod_buf = -1;            // ... and of the one before it
 };
 
+// a start / stop event pair for a timed launch: from the pool reset_timers() filled (no event creation between the timed launches of a
+// bench run), made on demand when a long run without a draining call has used the pool up -- a timed launch is never silently untimed
+static bool take_timer_pair(hfdl_gpu_frontend *fe, std::pair<hipEvent_t, hipEvent_t> &e)
+{
+	if (!fe->ev_pool.empty()) {
+		e = fe->ev_pool.back();
+		fe->ev_pool.pop_back();
+		return true;
+	}
+	if (hipEventCreate(&e.first) != hipSuccess) return false;
+	if (hipEventCreate(&e.second) != hipSuccess) { (void)hipEventDestroy(e.first); return false; }
+	return true;
+}
+
 static void frontend_free(hfdl_gpu_frontend *fe)
 {
 	if (!fe) return;
@@ -721,10 +735,9 @@ static int launch_demod(hfdl_gpu_frontend *fe, int buf, int nblk, bool after_fft
 		// the done event rides on the kernel's dispatch; with the decoder on its own stream the channelizer has already waited for the
 		// frame queue (close_half), so on the demodulator-bound geometries ONE barrier packet separates consecutive demodulators
 		hipEvent_t t_start = nullptr, done = fe->ev_dm[buf][l];
-		if (fe->timing && !fe->ev_pool.empty()) {
+		std::pair<hipEvent_t, hipEvent_t> e;
+		if (fe->timing && take_timer_pair(fe, e)) {
 			// the kernel's own start / stop events (no extra packet): the stop event doubles as this launch's "done" event
-			std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
-			fe->ev_pool.pop_back();
 			t_start = e.first; done = e.second;
 			fe->ev_dmt.push_back(e);
 			fe->demod_timed_blocks += take;
@@ -735,9 +748,7 @@ static int launch_demod(hfdl_gpu_frontend *fe, int buf, int nblk, bool after_fft
 		if (rc) return fail(rc, "demod enqueue failed: %s", hipGetErrorString(hipGetLastError()));
 		if (fe->own_decode_stream) HIP_TRY(hipStreamWaitEvent(fe->stream_d, done, 0));
 		hipEvent_t k5_start = nullptr, k5_stop = nullptr;
-		if (fe->timing && !fe->ev_pool.empty()) {
-			std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
-			fe->ev_pool.pop_back();
+		if (fe->timing && take_timer_pair(fe, e)) {
 			k5_start = e.first; k5_stop = e.second;
 			fe->ev_dect.push_back(e);
 		}
@@ -776,10 +787,9 @@ static int enqueue_fft(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int st
 	job.ph = fe->ph_slot(set, i); job.cont = fe->d_ph_cont;
 	job.nch = g.nch; job.outs = g.outs; job.post_input_size = g.post_input_size; job.post = g.post;
 	hipEvent_t fft_done = fe->fft_own_stream ? fe->ev_spec[set] : (pend ? fe->ev_fft : nullptr), fft_start = nullptr;
-	if (fe->timing && !fe->fft_own_stream && !fe->ev_pool.empty()) {
+	std::pair<hipEvent_t, hipEvent_t> e;
+	if (fe->timing && !fe->fft_own_stream && take_timer_pair(fe, e)) {
 		// the first pass' start and the last pass' stop ride on their dispatches; the stop event doubles as "this forward FFT is done"
-		std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
-		fe->ev_pool.pop_back();
 		fft_start = e.first; fft_done = e.second;
 		fe->ev_fftt.push_back(e);
 	}
@@ -809,20 +819,20 @@ static int close_half(hfdl_gpu_frontend *fe, bool launch_now, bool with_demod = 
 	const Geometry &g = fe->geo;
 	const int half = fe->cur_half;
 	if (fe->fft_own_stream) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_spec[half], 0));      // the newest forward FFT of this half (stream F)
-	if (fe->timing) {
-		std::pair<hipEvent_t, hipEvent_t> e;
-		if (!fe->ev_pool.empty()) {                 // made by reset_timers(): no event creation between the timed launches
-			e = fe->ev_pool.back();
-			fe->ev_pool.pop_back();
+	// one launch per `fold_nb` blocks (a half holds a whole number of them only when it is full), each timed and counted AS LAUNCHED: the
+	// shape the bench prices is a launch that happened
+	for (int done = 0; done < nblk; done += fe->fold_nb) {
+		const int take = std::min(fe->fold_nb, nblk - done);
+		float2 *pp = fe->d_partial + (size_t)done * fe->partial_stride();
+		if (fe->timing) {
+			std::pair<hipEvent_t, hipEvent_t> e;
+			if (!take_timer_pair(fe, e)) return fail(HFDL_GPU_EHIP, "hipEventCreate: %s", hipGetErrorString(hipGetLastError()));
+			launch_fold(g, fe->d_taps, fe->spec_slot(half, done), (size_t)g.n, pp, fe->partial_stride(), take, fe->fold_nb, fe->stream, e.first, e.second);
+			fe->ev.push_back(e);
+			fe->ev_blocks.push_back(take);
 		} else {
-			HIP_TRY(hipEventCreate(&e.first));
-			HIP_TRY(hipEventCreate(&e.second));
+			launch_fold(g, fe->d_taps, fe->spec_slot(half, done), (size_t)g.n, pp, fe->partial_stride(), take, fe->fold_nb, fe->stream);
 		}
-		launch_fold(g, fe->d_taps, fe->spec_slot(half, 0), (size_t)g.n, fe->d_partial, fe->partial_stride(), nblk, fe->fold_nb, fe->stream, e.first, e.second);
-		fe->ev.push_back(e);
-		fe->ev_blocks.push_back(nblk);
-	} else {
-		launch_fold(g, fe->d_taps, fe->spec_slot(half, 0), (size_t)g.n, fe->d_partial, fe->partial_stride(), nblk, fe->fold_nb, fe->stream);
 	}
 	// this half is free once the demodulator launches that read it last (two halves ago) are done
 	if (fe->ev_dm_cur[half]) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_dm_cur[half], 0));
@@ -837,9 +847,8 @@ static int close_half(hfdl_gpu_frontend *fe, bool launch_now, bool with_demod = 
 	}
 	const int slot0 = half * fe->half_blocks;
 	hipEvent_t ifft_start = nullptr, ifft_done = fe->ev_chan[half];
-	if (fe->timing && !fe->ev_pool.empty()) {
-		std::pair<hipEvent_t, hipEvent_t> e = fe->ev_pool.back();
-		fe->ev_pool.pop_back();
+	std::pair<hipEvent_t, hipEvent_t> e;
+	if (fe->timing && take_timer_pair(fe, e)) {
 		ifft_start = e.first; ifft_done = e.second;
 		fe->ev_ifftt.push_back(e);
 	}
@@ -1435,6 +1444,16 @@ extern "C" int hfdl_gpu_lab_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_
 		}
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	*gb_per_s = best;
+	return 0;
+}
+
+extern "C" int hfdl_gpu_lab_read_constants(hfdl_gpu_frontend *fe, void *tables, size_t tables_bytes, void *constants, size_t constants_bytes)
+{
+	if (!fe || !tables || !constants) return fail(HFDL_GPU_EINVAL, "null argument");
+	int rc = hfdl_gpu_frontend_sync(fe);
+	if (rc) return rc;
+	rc = fe->demod.read_constants(tables, tables_bytes, constants, constants_bytes);
+	if (rc) return fail(rc, "constants read-back failed (sizes %zu / %zu): %s", tables_bytes, constants_bytes, hipGetErrorString(hipGetLastError()));
 	return 0;
 }
 

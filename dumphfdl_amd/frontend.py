@@ -76,7 +76,8 @@ EXPORTS = [
 
 
 # what include/hfdl_gpu_lab.h adds in the laboratory build (libhfdl_gpu_lab.so)
-LAB_EXPORTS = ["hfdl_gpu_lab_fold_variant_count", "hfdl_gpu_lab_fold_variant_describe", "hfdl_gpu_lab_fold_variant_probe", "hfdl_gpu_lab_stream_read_probe"]
+LAB_EXPORTS = ["hfdl_gpu_lab_fold_variant_count", "hfdl_gpu_lab_fold_variant_describe", "hfdl_gpu_lab_fold_variant_probe", "hfdl_gpu_lab_stream_read_probe",
+               "hfdl_gpu_lab_read_constants"]
 
 
 def fold_variants():
@@ -121,6 +122,7 @@ def load_lab():
     L.hfdl_gpu_lab_fold_variant_describe.argtypes = [C.c_int, C.POINTER(C.c_int32 * 6)]
     L.hfdl_gpu_lab_fold_variant_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.hfdl_gpu_lab_stream_read_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.hfdl_gpu_lab_read_constants.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     _lab = L
     return L
 

@@ -80,7 +80,8 @@ typedef struct {
 	                                    of its own; a poll / sync always folds what has been pushed.  HFDL_GPU_FOLD_BATCH=1..16 overrides the default
 	                                    (16 from 128 channels up, where the fold bounds the block; 8 below) at create time.  0 from hfdl_gpu_plan_geometry() */
 	int32_t prefetch_depth;          /* host blocks whose upload hfdl_gpu_frontend_prefetch_block_raw() may queue ahead of their push
-	                                    (fold_batch + 1: a staging ring of fold_batch + 2 buffers in HBM); at most HFDL_GPU_PREFETCH_MAX.
+	                                    (half + 1, for a staging ring of half + 2 buffers in HBM, where a half = the blocks between two fold / inverse-FFT
+	                                    phases = fold_batch rounded up to hold at least demod_batch blocks); at most HFDL_GPU_PREFETCH_MAX.
 	                                    0 from hfdl_gpu_plan_geometry() */
 	int32_t fold_rows;               /* alias rows a fold workgroup adds up at most: pre_decimation (all of them, the reference's sum term for
 	                                    term) unless HFDL_GPU_FOLD_PRUNE is set.  0 from hfdl_gpu_plan_geometry() */
@@ -150,8 +151,8 @@ int  hfdl_gpu_frontend_geometry(const hfdl_gpu_frontend *fe, hfdl_gpu_geometry *
  * FFT is queued at once; fold, inverse FFT, demodulator and burst decoder follow when geometry.fold_batch blocks are waiting or the
  * caller syncs / polls, whichever comes first (the results do not depend on which).
  * on_device != 0: `iq` is a device pointer that stays valid until the next sync.
- * on_device == 0: the host -> device copy runs on its own stream into a ring of fold_batch + 2 staging buffers, so the copies
- *   run up to a whole fold batch ahead of the kernels.  A buffer from hfdl_gpu_host_alloc() (page-locked) is read by DMA after the call
+ * on_device == 0: the host -> device copy runs on its own stream into a ring of geometry.prefetch_depth + 1 staging buffers, so the copies
+ *   run up to a whole half (fold_batch blocks, or more where demod_batch is larger) ahead of the kernels.  A buffer from hfdl_gpu_host_alloc() (page-locked) is read by DMA after the call
  *   returns: reuse it only after hfdl_gpu_frontend_input_done() / _sync() / _poll_pdus().  Any other host buffer (pageable,
  *   or registered by the caller) is waited for inside the call and may be reused as soon as it returns. */
 int  hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device);

@@ -25,6 +25,11 @@ int  hfdl_gpu_lab_fold_variant_describe(int variant, int32_t desc[6]);
  * resident taps and the spectra of its newest half; *checksum sums the bit patterns of the partial sums (equal for bit-identical kernels
  * at the same nb) */
 int  hfdl_gpu_lab_fold_variant_probe(hfdl_gpu_frontend *fe, int variant, int nb, int reps, double *avg_ms, double *best_ms, uint64_t *checksum);
+/* The demodulator's constant tables as they lie in device memory (`tables`: struct DemodTables of csrc/demod_tables.h) and the named
+ * constants of the reference's hot path as the DEVICE evaluates them (`constants`: struct HfdlConstants of csrc/demod_logic.h): both are
+ * compared with the reference's own text, tests/golden/hfdl_constants.json.  The byte counts must equal the structs' sizes
+ * (tests/hostsim reports them). */
+int  hfdl_gpu_lab_read_constants(hfdl_gpu_frontend *fe, void *tables, size_t tables_bytes, void *constants, size_t constants_bytes);
 /* what the board's HBM delivers to a read-only streaming kernel with the fold's access pattern (reads the resident taps) */
 int  hfdl_gpu_lab_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_per_s);
 

@@ -17,6 +17,29 @@
 /* ======================= variant switches (hfdl_oracle.h) ======================= */
 
 #include "../tests/hostsim/shared_math.h"     /* orc_variant.shared_math: libm replaced by fixed fp32 sequences (test infrastructure, like this file) */
+
+/* the numeric constants of src/hfdl.c used below, by name, so that orc_constants() can hand them to the test that compares them with
+ * the reference's text (tests/golden/hfdl_constants.json, tests/test_constants_cpu.py) */
+#define CORR_THRESHOLD_A1 0.36f            /* src/hfdl.c:42-44 */
+#define CORR_THRESHOLD_A2 0.3f
+#define CORR_THRESHOLD_M1 0.3f
+#define MAX_SEARCH_RETRIES 3               /* :45 */
+#define NO_FRAME_TIMEOUT_FRAMES 13         /* :613 */
+#define HFDL_SYMBOL_RATE 1800              /* src/hfdl.h:6-7 */
+#define HFDL_SPS 3
+#define COSTAS_ALPHA 0.1f                  /* :252 */
+#define COSTAS_BETA_K 0.047f               /* :253: beta = 0.047 alpha^2 */
+#define COSTAS_ERR_LIMIT 1.0f              /* :276 */
+#define COSTAS_RUNAWAY_DPHI 0.25f          /* :709 */
+#define AGC_BANDWIDTH 0.01f                /* :487 */
+#define EQ_STEP 0.1f                       /* :496 */
+#define SYMSYNC_LF_BW 0.001f               /* :504 */
+#define NF_INIT 1.0f                       /* :490 */
+#define NF_KEEP 0.65f                      /* :700-701 */
+#define NF_TAKE 0.35f
+#define NF_BIAS 1e-6f
+#define NF_CLK_MASK 0xFFu                  /* :699 */
+#define T_SEQ_BITS 0x9AFu                  /* T_seq[0] as bits, MSB (bit 14) first, 0 -> +1: :157-160 */
 orc_variant orc_v = { .soft_dmin_init = 4.0f };
 void orc_variant_default(orc_variant *v) { memset(v, 0, sizeof(*v)); v->soft_dmin_init = 4.0f; }
 void orc_variant_set(const orc_variant *v) { orc_v = *v; }
@@ -387,7 +410,7 @@ static void eqlms_init(eqlms_t *e)
 	float h[EQ_LEN];
 	orc_eq_initial_taps(h);
 	for (int i = 0; i < EQ_LEN; i++) { e->h0[i].re = h[i]; e->h0[i].im = 0; }
-	e->mu = 0.1f;               /* eqlms_cccf_set_bw(0.1), src/hfdl.c:496 */
+	e->mu = EQ_STEP;              /* eqlms_cccf_set_bw(0.1), src/hfdl.c:496 */
 	eqlms_reset(e);
 }
 
@@ -554,7 +577,7 @@ orc_channel *orc_channel_create(int32_t sample_rate, int32_t decimation, float t
 	pthread_once(&seq_once, seq_init);
 	orc_channel *c = calloc(1, sizeof(*c));
 	c->chan_freq = frequency;
-	c->resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)decimation);
+	c->resamp_rate = (float)(HFDL_SYMBOL_RATE * HFDL_SPS) / ((float)sample_rate / (float)decimation);
 	resamp_init(&c->rs, c->resamp_rate);
 	float freq_shift = (float)(centerfreq - (frequency + 1440)) / (float)sample_rate;
 	if (orc_fastddc_init(&c->ddc, transition_bw, decimation, freq_shift)) { free(c); return NULL; }
@@ -565,12 +588,12 @@ orc_channel *orc_channel_create(int32_t sample_rate, int32_t decimation, float t
 		orc_channelizer_taps(&c->ddc, decimation, freq_shift, c->taps_fft, 0);
 	}
 	c->chan_out = malloc(sizeof(orc_cf) * (size_t)c->ddc.post_input_size);
-	c->agc.g = 1.0f; c->agc.y2 = orc_v.agc_y2_init > 0.f ? orc_v.agc_y2_init : 1.0f; c->agc.alpha = 0.01f;   /* src/hfdl.c:485-487 */
-	c->noise_floor = 1.0f;                                     /* :490 */
-	c->loop.alpha = 0.1f;
-	c->loop.beta = 0.047f * c->loop.alpha * c->loop.alpha;     /* :240-245 */
+	c->agc.g = 1.0f; c->agc.y2 = orc_v.agc_y2_init > 0.f ? orc_v.agc_y2_init : 1.0f; c->agc.alpha = AGC_BANDWIDTH;   /* src/hfdl.c:485-487 */
+	c->noise_floor = NF_INIT;                                  /* :490 */
+	c->loop.alpha = COSTAS_ALPHA;
+	c->loop.beta = COSTAS_BETA_K * c->loop.alpha * c->loop.alpha;     /* :240-245 */
 	eqlms_init(&c->eq);
-	symsync_init(&c->ss, 0.001f);                              /* :503-505 */
+	symsync_init(&c->ss, SYMSYNC_LF_BW);                              /* :503-505 */
 	framer_reset(c);
 	c->resampled_cap = c->ddc.post_input_size + 64;
 	c->resampled = malloc(sizeof(orc_cf) * (size_t)c->resampled_cap);
@@ -626,7 +649,7 @@ static void emit_pdu(orc_channel *c, orc_pdu_sink sink, void *ctx)   /* src/hfdl
 	p.rssi_db = 20.0f * log10f(c->signal_level);
 	p.noise_floor_db = 20.0f * log10f(c->noise_floor);
 	const orc_mode_params *m = &orc_modes[c->M1];
-	p.bit_rate = 1800 * m->arity / m->code_rate * DATA_FRAME_LEN / (DATA_FRAME_LEN + T_LEN);
+	p.bit_rate = HFDL_SYMBOL_RATE * m->arity / m->code_rate * DATA_FRAME_LEN / (DATA_FRAME_LEN + T_LEN);
 	p.slot = m->segments == 72 ? 'S' : 'D';
 	p.sample_index = c->pdu_sample_index;
 	p.train_bits_bad = c->train_bits_bad;
@@ -643,7 +666,7 @@ static void count_train_errors(orc_channel *c)
 		bit ^= (c->bitmask & 1);
 		seq = (seq << 1) | bit;
 	}
-	int err = __builtin_popcount(0x9AFu ^ seq);
+	int err = __builtin_popcount(T_SEQ_BITS ^ seq);
 	c->train_bits_total += T_LEN;
 	c->train_bits_bad += err;
 	c->cum_train_total += T_LEN;
@@ -658,13 +681,13 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 	/* costas_cccf_adjust, :276-281 */
 	{
 		float e = perr;
-		e = 0.5f * (fabsf(e + 1.0f) - fabsf(e - 1.0f));
+		e = 0.5f * (fabsf(e + COSTAS_ERR_LIMIT) - fabsf(e - COSTAS_ERR_LIMIT));
 		c->loop.err = e;
 		c->loop.phi += c->loop.alpha * e;
 		c->loop.dphi += c->loop.beta * e;
 	}
 	c->symbol_cnt++;
-	if (c->symbol_cnt >= (uint64_t)(13 * SINGLE_SLOT_FRAME_LEN) && c->fr_state == FR_A1) {
+	if (c->symbol_cnt >= (uint64_t)(NO_FRAME_TIMEOUT_FRAMES * SINGLE_SLOT_FRAME_LEN) && c->fr_state == FR_A1) {
 		c->symbol_cnt = 0;
 		c->loop.dphi = c->loop.phi = 0.0f;
 		symsync_reset(&c->ss);
@@ -686,7 +709,7 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 	switch (c->fr_state) {
 	case FR_A1: {
 		float corr = 2.0f * (float)bits_correlate(&seq_A, &c->bits) / (float)A_LEN - 1.0f;
-		if (fabsf(corr) > 0.36f) {
+		if (fabsf(corr) > CORR_THRESHOLD_A1) {
 			c->cnt_a1_found++;
 			c->corr_total[0] += fabsf(corr);
 			c->bitmask = corr > 0.f ? 0 : ~0u;
@@ -699,15 +722,15 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 		break; }
 	case FR_A2: {
 		float corr = 2.0f * (float)bits_correlate(&seq_A, &c->bits) / (float)A_LEN - 1.0f;
-		if (fabsf(corr) > 0.3f) {
+		if (fabsf(corr) > CORR_THRESHOLD_A2) {
 			c->cnt_a2_found++;
 			c->corr_total[1] += fabsf(corr);
 			c->pdu_sample_index = c->sample_cnt;   /* reference: wall clock, :808-809 */
-			c->freq_err_hz = (float)(c->loop.dphi * 1800 / (2.0 * M_PI));
+			c->freq_err_hz = (float)(c->loop.dphi * HFDL_SYMBOL_RATE / (2.0 * M_PI));
 			c->symbols_wanted = M1_LEN;
 			c->search_retries = 0;
 			c->fr_state = FR_M1;
-		} else if (++c->search_retries >= 3) {
+		} else if (++c->search_retries >= MAX_SEARCH_RETRIES) {
 			framer_reset(c);
 		}
 		break; }
@@ -717,7 +740,7 @@ static void on_symbol(orc_channel *c, orc_cf s, orc_pdu_sink sink, void *ctx)
 			float corr = fabsf(2.0f * (float)bits_correlate(&seq_M1[m], &c->bits) / 127.0f - 1.0f);
 			if (corr > best) { best = corr; best_idx = m; }
 		}
-		if (fabsf(best) > 0.3f) {
+		if (fabsf(best) > CORR_THRESHOLD_M1) {
 			c->cnt_m1_found++;
 			c->corr_total[2] += fabsf(best);
 			c->data_segment_cnt = orc_modes[best_idx].segments;
@@ -787,9 +810,9 @@ static void process_resampled(orc_channel *c, orc_pdu_sink sink, void *ctx)
 		c->mf_win[0] = r;
 		orc_cf s = dot_rc(MF_TAPS, c->mf_win, 19);
 		c->mf_out[k] = s;
-		if (c->fr_state == FR_A1 && (++c->nf_clk & 0xFFu) == 0xFFu) {
+		if (c->fr_state == FR_A1 && (++c->nf_clk & NF_CLK_MASK) == NF_CLK_MASK) {
 			float lvl = 1.0f / c->agc.g;
-			c->noise_floor = 0.65f * c->noise_floor + 0.35f * fminf(c->noise_floor, lvl) + 1e-6f;
+			c->noise_floor = NF_KEEP * c->noise_floor + NF_TAKE * fminf(c->noise_floor, lvl) + NF_BIAS;
 		}
 		orc_cf sym[4];
 		int32_t produced = symsync_step(&c->ss, s, sym);
@@ -803,7 +826,7 @@ static void process_resampled(orc_channel *c, orc_pdu_sink sink, void *ctx)
 			else { cp = cosf(c->loop.phi); sp = sinf(c->loop.phi); }
 			r.re = sym[i].re * cp + sym[i].im * sp;
 			r.im = sym[i].im * cp - sym[i].re * sp;
-			if (fabsf(c->loop.dphi) > 0.25f && c->fr_state == FR_A1) {
+			if (fabsf(c->loop.dphi) > COSTAS_RUNAWAY_DPHI && c->fr_state == FR_A1) {
 				c->loop.dphi = c->loop.phi = 0.f;
 				symsync_reset(&c->ss);
 			}
@@ -867,7 +890,7 @@ static void *creator_main(void *arg)
 orc_frontend *orc_frontend_create_mt(int32_t sample_rate, int32_t centerfreq, const int32_t *freqs, int32_t nch, int nthreads)
 {
 	orc_frontend *f = calloc(1, sizeof(*f));
-	int32_t decim = orc_compute_fft_decimation_rate(sample_rate, 1800 * 3);
+	int32_t decim = orc_compute_fft_decimation_rate(sample_rate, HFDL_SYMBOL_RATE * HFDL_SPS);
 	float tbw = orc_transition_bw(sample_rate, 250);
 	if (orc_fastddc_init(&f->ddc, tbw, decim, 0)) { free(f); return NULL; }
 	f->buf = calloc((size_t)f->ddc.fft_size, sizeof(orc_cf));
@@ -937,4 +960,19 @@ void orc_frontend_push_block(orc_frontend *f, const orc_cf *samples, int nthread
 		free(w[t].out);
 	}
 	free(w); free(th);
+}
+
+/* the constants and static tables of this restatement, for the comparison with the reference's text (tests/test_constants_cpu.py):
+ * ints[0..16], floats[0..12], mf[19], t_seq[15]; the orders are those of the test */
+void orc_constants(int32_t *ints, float *floats, float *mf, float *t_seq)
+{
+	const int32_t iv[] = { PREKEY_LEN, A_LEN, M1_LEN, M2_LEN, T_LEN, DATA_FRAME_LEN, PREAMBLE_LEN, SINGLE_SLOT_FRAME_LEN, MAX_DATA_SYMBOLS,
+		MAX_SEARCH_RETRIES, NO_FRAME_TIMEOUT_FRAMES, HFDL_SYMBOL_RATE, HFDL_SPS, EQ_LEN, 19, SS_NPFB, (int32_t)NF_CLK_MASK,
+		SAMPLER_BITS, SAMPLER_SYMBOLS, SAMPLER_SKIP, FR_A1, FR_A2, FR_M1, FR_M2_SKIP, FR_EQ_TRAIN, FR_DATA_1, FR_DATA_2, SS_K, SS_KOUT };
+	const float fv[] = { CORR_THRESHOLD_A1, CORR_THRESHOLD_A2, CORR_THRESHOLD_M1, COSTAS_ALPHA, COSTAS_BETA_K * COSTAS_ALPHA * COSTAS_ALPHA, COSTAS_ERR_LIMIT,
+		COSTAS_RUNAWAY_DPHI, AGC_BANDWIDTH, EQ_STEP, NF_KEEP, NF_TAKE, NF_BIAS, NF_INIT, SYMSYNC_LF_BW };
+	for (size_t i = 0; i < sizeof(iv) / sizeof(iv[0]); i++) ints[i] = iv[i];
+	for (size_t i = 0; i < sizeof(fv) / sizeof(fv[0]); i++) floats[i] = fv[i];
+	for (int i = 0; i < 19; i++) mf[i] = MF_TAPS[i];
+	for (int i = 0; i < 15; i++) t_seq[i] = T_BPSK[i];
 }

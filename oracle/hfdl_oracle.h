@@ -110,6 +110,10 @@ uint32_t orc_modem_demod_hard(int arity, orc_cf x, float *phase_error);
 uint32_t orc_modem_demod_hard(int arity, orc_cf x, float *phase_error);
 orc_cf  orc_modem_modulate(int arity, uint32_t sym);
 
+/* the numeric constants and static tables of the restatement (src/hfdl.c:29-46,147-160,252-253,485-505,613,699-709), for the comparison
+ * with the reference's text: ints[29], floats[14], mf[19], t_seq[15] in the order tests/test_constants_cpu.py names */
+void    orc_constants(int32_t *ints, float *floats, float *mf, float *t_seq);
+
 /* ---------------- variant switches: sensitivity of the result to the UNPINNED readings ----------------
  * liquid-dsp is absent here, so every choice below is a recollection or differs between liquid releases.  The defaults (all zero,
  * dmin 4.0) are the restatement every parity test uses and the GPU implements; profiles/variant_study.py decodes the same traffic

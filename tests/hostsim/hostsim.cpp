@@ -120,6 +120,8 @@ void sim_bandpass(float *out, int length, float lowcut, float highcut)
 	design_bandpass((std::complex<float> *)out, length, lowcut, highcut, lp, cut);
 }
 size_t sim_sizeof_tables(void) { return sizeof(DemodTables); }
+size_t sim_sizeof_constants(void) { return sizeof(HfdlConstants); }
+void sim_constants(HfdlConstants *out) { hfdl_constants(*out); }
 size_t sim_sizeof_framerec(void) { return sizeof(FrameRec); }
 
 }

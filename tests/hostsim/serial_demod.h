@@ -136,7 +136,7 @@ HFDL_FN int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodConst &
 	// ---- A: AGC (agc_crcf_execute, src/hfdl.c:686)
 	{
 		float g = s.agc_g, y2 = s.agc_y2;
-		const float alpha = 0.01f;
+		const float alpha = AGC_BANDWIDTH;
 		for (int k = 0; k < n_out; k++) {
 			const cf x = io.rs[k];
 			cf y; y.x = x.x * g; y.y = x.y * g;
@@ -186,8 +186,8 @@ HFDL_FN int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodConst &
 	for (int k = 0; k < n_out; k++, s.sample_cnt++) {
 		const cf mfo = io.mf[k];
 		const float level = io.lvl[k];
-		if (s.fr_state == FR_A1 && (++s.nf_clk & 0xFFu) == 0xFFu)
-			s.noise_floor = 0.65f * s.noise_floor + 0.35f * fminf(s.noise_floor, level) + 1e-6f;
+		if (s.fr_state == FR_A1 && (++s.nf_clk & NF_CLK_MASK) == NF_CLK_MASK)
+			s.noise_floor = NF_KEEP * s.noise_floor + NF_TAKE * fminf(s.noise_floor, level) + NF_BIAS;
 
 		// symsync_crcf_execute, one input sample
 		s.ss_head = s.ss_head + 1 == D_SS_TAPS ? 0 : s.ss_head + 1;
@@ -235,7 +235,7 @@ HFDL_FN int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodConst &
 			cf r;
 			r.x = out[i].x * cp + out[i].y * sp;
 			r.y = out[i].y * cp - out[i].x * sp;
-			if (fabsf(s.dphi) > 0.25f && s.fr_state == FR_A1) {
+			if (fabsf(s.dphi) > COSTAS_RUNAWAY_DPHI && s.fr_state == FR_A1) {
 				s.dphi = s.phi = 0.f;
 				symsync_reset(s, a);
 			}
@@ -283,8 +283,8 @@ HFDL_FN int demod_block_serial(ChanScalars &s, ChanArrays &a, const DemodConst &
 					for (int t = 0; t < D_EQ; t++) {
 						const cf x = a.eq_buf[idx];
 						const float pr = er * x.x - ei * x.y, pi = er * x.y + ei * x.x;
-						a.eq_w[t].x = a.eq_w[t].x + 0.1f * pr / s.eq_x2sum;
-						a.eq_w[t].y = a.eq_w[t].y + 0.1f * pi / s.eq_x2sum;
+						a.eq_w[t].x = a.eq_w[t].x + EQ_STEP * pr / s.eq_x2sum;
+						a.eq_w[t].y = a.eq_w[t].y + EQ_STEP * pi / s.eq_x2sum;
 						idx = idx + 1 == D_EQ ? 0 : idx + 1;
 					}
 				}

@@ -66,7 +66,7 @@ def test_cfg1_through_the_c_host_program(gpu, oracle, tmp_path):
 def test_full_size_cfg4_burst_dense(gpu, oracle):
     """BASELINE.json configs[3] as bench.py runs it: 256 channels x 40 Msps, every channel back-to-back bursts cycling all
     eight modes, 32 blocks (235 M samples).  Every PDU carries a sent payload with its mode and a good on-device FCS,
-    nothing is dropped, each channel delivers all of its bursts that end inside the stretch, and an 8-channel oracle
+    nothing is dropped, each channel delivers all of its bursts that end inside the stretch, and a 16-channel oracle
     subset yields the identical (freq, sample_index, mode, octets) set and channelizer output."""
     sys.path.insert(0, ROOT)
     import bench
@@ -78,14 +78,15 @@ def test_full_size_cfg4_burst_dense(gpu, oracle):
     x, bursts = bench.make_input(w, g.input_size, 0, 1)
     nblk = len(x) // g.input_size
     assert nblk >= 32 and {b["mode"] for b in bursts} == set(range(8))
-    sub = [0, 37, 90, 127, 128, 171, 222, 255]
-    ora = oracle.Frontend(w["fs"], w["centerfreq"], [freqs[c] for c in sub], nthreads=8)
+    sub = [0, 17, 37, 60, 90, 111, 127, 128, 150, 171, 190, 205, 222, 239, 254, 255]        # sixteen since round 6 (round 5: eight)
+    nthr = max(8, min(16, os.cpu_count() or 8))
+    ora = oracle.Frontend(w["fs"], w["centerfreq"], [freqs[c] for c in sub], nthreads=nthr)
     fe.enable_taps(False)
     pdus, worst = [], 0.0
     for b in range(nblk):
         blk = x[b * g.input_size:(b + 1) * g.input_size]
         fe.push_block(blk)
-        ora.push_block(blk, nthreads=8)
+        ora.push_block(blk, nthreads=nthr)
         if b in (0, 9, nblk - 1):
             for i, c in enumerate(sub):
                 worst = max(worst, rel_rms(fe.read_tap(F.TAP_CHAN_OUT, c), ora.channel_view(i)["chan_out"]))
@@ -119,8 +120,8 @@ def test_full_size_cfg4_burst_dense(gpu, oracle):
         assert per_chan[f] <= len(by_freq[f]), (f, per_chan[f])
     assert len(pdus) >= 0.97 * due and len(pdus) >= 300, (len(pdus), due)
     key = lambda p: (p["freq"], p["sample_index"], p["mode"], p["octets"])
-    got8 = sorted(key(p) for p in pdus if p["channel"] in sub)
-    assert got8 == sorted(key(p) for p in ora.pdus) and len(got8) >= 8
+    got16 = sorted(key(p) for p in pdus if p["channel"] in sub)
+    assert got16 == sorted(key(p) for p in ora.pdus) and len(got16) >= 16
     # trellis work of the run (decoded bits per frame x 64 ACS)
     steps = sum(synth.mode_sizes(p["mode"])["nbits"] for p in pdus)
     assert steps > 500_000
@@ -395,5 +396,26 @@ def test_eight_rank_rehearsal_one_stream_channel_sharded(tmp_path):
     fsets = [{k[0] for k in ks} for ks in k8]
     assert all(not (fsets[i] & fsets[j]) for i in range(8) for j in range(i))                      # channel partition
     assert sorted(k for ks in k8 for k in ks) == sorted(k1[0]) and len(k1[0]) >= 30
+    assert parts["pdus_in_timed_region"] == whole["pdus_in_timed_region"] == len(k1[0])
+    assert parts["pdus_matching_sent_payload"] == parts["pdus_in_timed_region"]
+
+
+def test_eight_rank_rehearsal_full_size_one_stream_channel_sharded(tmp_path):
+    """SURVEY.md 8(e) at the node's full width AND at the full size (round 6): the default workload -- ONE 40 Msps stream, 256 channels --
+    with `--shard channels` over eight ranks on the one GPU of the test box: every rank ingests the same blocks (its own forward FFT of
+    2^23 points) and folds / demodulates 32 of the channels.  The union of the eight shards' PDUs is the unsharded 256-channel run's set
+    -- same (freq, sample_index, mode, octets) -- no channel is decoded twice, and the stream's samples count once.  With the weak-scaling
+    rehearsal above, the first run on an 8-GPU node is then a measurement of both modes, not a debugging session."""
+    args = ["--steps", "16", "--warmup", "0", "--shard", "channels"]
+    whole, k1 = _run_bench(args, 1, 0, tmp_path, "whole256")
+    parts, k8 = _run_bench(args, 8, 29573, tmp_path, "parts256")
+    assert "configs[2]" in whole["config"]["workload"] and whole["config"]["channels"] == 256 and whole["config"]["fft_size"] == 1 << 23
+    assert parts["n_gpus"] == 8 and parts["scaling"] == "strong" and len(set(parts["config"]["stream_seeds"])) == 1
+    assert parts["config"]["channels"] == 256 and parts["config"]["channels_rank0"] == 32 and parts["config"]["fft_size"] == 1 << 23
+    assert [p["rank"] for p in parts["per_rank"]] == list(range(8)) and all(p["channels"] == 32 for p in parts["per_rank"])
+    assert abs(parts["value"] * 1e6 * parts["ms_per_step"] * 16e-3 - 16 * 7340032) < 250             # ONE stream's samples
+    fsets = [{k[0] for k in ks} for ks in k8]
+    assert all(not (fsets[i] & fsets[j]) for i in range(8) for j in range(i))                      # channel partition
+    assert sorted(k for ks in k8 for k in ks) == sorted(k1[0]) and len(k1[0]) >= 200
     assert parts["pdus_in_timed_region"] == whole["pdus_in_timed_region"] == len(k1[0])
     assert parts["pdus_matching_sent_payload"] == parts["pdus_in_timed_region"]

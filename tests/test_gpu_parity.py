@@ -518,7 +518,8 @@ def test_raw_ingest_converted_on_device(gpu, oracle, fmt):
 def test_full_size_cfg3_geometry(gpu, oracle):
     """BASELINE.json configs[2] geometry (40 Msps, N = 2^23, M = 4096) with all 256 channels resident.
     Size-independent properties over every channel: encode -> channel -> decode round trip (payload + FCS) and
-    linearity of the channelizer; plus oracle parity (channelizer RMS and PDUs) on a 4-channel subset."""
+    linearity of the channelizer; plus oracle parity (channelizer RMS, PDUs, preamble counters) on a 16-channel subset that holds
+    every channel whose burst the reference's preamble search loses."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -530,13 +531,19 @@ def test_full_size_cfg3_geometry(gpu, oracle):
     assert (g.fft_size, g.fft_inv_size, g.input_size, g.outputs_per_block) == (1 << 23, 4096, 7340032, 1792)
     x, bursts = bench.make_input(w, g.input_size, 0, 1)
     nblk = len(x) // g.input_size
-    sub = [3, 77, 128, 250]
-    ora = oracle.Frontend(w["fs"], w["centerfreq"], [freqs[c] for c in sub], nthreads=4)
+    import json
+    row = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_oracle_lost_bursts.json")))
+    # the oracle runs beside the device on SIXTEEN channels: the nine whose burst the reference's M1 search loses (the committed table)
+    # and seven that decode -- since round 6 (round 5: four channels, none of the nine)
+    sub = sorted(set(row["lost_burst_streams"]) | {3, 77, 128, 250, 31, 100, 201})
+    assert len(sub) == 16 and len(set(row["lost_burst_streams"])) == 9
+    nthr = max(4, min(16, os.cpu_count() or 4))
+    ora = oracle.Frontend(w["fs"], w["centerfreq"], [freqs[c] for c in sub], nthreads=nthr)
     worst = 0.0
     for b in range(nblk):
         blk = x[b * g.input_size:(b + 1) * g.input_size]
         fe.push_block(blk)
-        ora.push_block(blk, nthreads=4)
+        ora.push_block(blk, nthreads=nthr)
         if b in (0, 1, nblk - 1):
             for i, c in enumerate(sub):
                 worst = max(worst, rel_rms(fe.read_tap(F.TAP_CHAN_OUT, c), ora.channel_view(i)["chan_out"]))
@@ -545,8 +552,6 @@ def test_full_size_cfg3_geometry(gpu, oracle):
     sent = {b["freq"]: b for b in bursts}
     # 256 bursts sent; the oracle, run over ALL 256 channels of this very traffic (profiles/variant_study.py, committed table), loses
     # nine of them to the reference's own M1 search (A2_found + M1_not_found): the GPU must lose exactly those nine and no other
-    import json
-    row = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_oracle_lost_bursts.json")))
     lost = {freqs[i] for i in row["lost_burst_streams"]}
     assert len(lost) == row["m1_not_found"] == 256 - row["pdus"]
     assert {f for f in freqs if not any(p["freq"] == f for p in pdus)} == lost and len(pdus) == row["pdus"] == row["recovered"]
@@ -554,8 +559,15 @@ def test_full_size_cfg3_geometry(gpu, oracle):
         b = sent[p["freq"]]
         assert p["octets"][:len(b["octets"])] == b["octets"] and p["mode"] == b["mode"] and p["fcs_status"] == F.FCS_GOOD
         assert p["lpdus"] == ((0,) * 5 if b["lpdus"] is None else (b["lpdus"], b["lpdus"], 0, 0, 0))      # the device's LPDU walk = what was sent
-    got4 = sorted((p["freq"], p["sample_index"], p["octets"]) for p in pdus if p["channel"] in sub)
-    assert got4 == sorted((p["freq"], p["sample_index"], p["octets"]) for p in ora.pdus) and len(got4) == 4
+    got16 = sorted((p["freq"], p["sample_index"], p["octets"]) for p in pdus if p["channel"] in sub)
+    assert got16 == sorted((p["freq"], p["sample_index"], p["octets"]) for p in ora.pdus) and len(got16) == 7      # 16 channels, nine bursts lost by both
+    # ... and on the nine the oracle's counters say WHY, the same way the device's do: A2 found, M1 not found
+    for i, c in enumerate(sub):
+        oc = ora.channel_counters(i)
+        st = fe.channel_stats(c)
+        assert (st["a2_found"], st["m1_found"], st["m1_not_found"], st["frames"]) == (oc["a2_found"], oc["m1_found"], oc["m1_not_found"], oc["frames"]), (c, st, oc)
+        if c in row["lost_burst_streams"]:
+            assert st["m1_not_found"] >= 1 and st["frames"] == 0
     fe.close()
     # linearity of the whole channelizer at full size: C(a x + b y) = a C(x) + b C(y), fresh state each time
     rng = np.random.default_rng(9)
