@@ -78,13 +78,14 @@ __device__ __forceinline__ float rot90(float a, int sign_mask)
 
 // registers the tile asks for -> waves per SIMD told to the compiler (512 per lane and SIMD): left to itself it aims at 8 waves,
 // squeezes the loop into 64 registers and gets there by loading, waiting, multiplying, loading again
-constexpr int fold16_waves(int p, int w, int d, bool small = false)
+constexpr int fold16_waves(int p, int w, int d, bool small = false, int cg = 1)
 {
-	const int mine = w >= 8 ? 1 : 8 / w;
-	const int regs = (small ? 16 : 64) * p + 16 * p * d + 4 * mine * d + 4 * mine + 8 + 28;
+	const int loads = 8 * cg, mine = w >= loads ? 1 : loads / w;
+	const int regs = (small ? 16 : 64) * p * cg + 16 * p * d + 4 * mine * d + 4 * mine + 8 + 28;
 	// the four-column form never takes more than two waves of a SIMD: it is bound by the HBM reads, and a third wave would take the
 	// registers the demodulator's waves need beside it (a 2-block demodulator launch beside a 3-wave 4-block fold: 1.7 ms instead of 0.5)
 	if (small) return regs <= 168 ? 2 : 1;
+	if (cg > 1) return 1;                  // 128 accumulation registers per octet: one wave per SIMD, its software pipeline keeps the matrix pipe fed (two would spill)
 	return regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : regs <= 256 ? 2 : 1;
 }
 
@@ -109,23 +110,30 @@ constexpr int fold16_waves(int p, int w, int d, bool small = false)
 // 16-lane groups and the four bins in the four registers: two v_permlane32_swap + two v_permlane16_swap per KiB transpose groups
 // against registers, after which register k = alias row k and the lane group = the bin.  Then k = 0 .. 3 with Re(X), k = 0 .. 3 with
 // Im(X), one instruction each, on the same accumulator: the chain of the sixteen-column form, the same bits.
-template <int P, int W, int D, bool WIN = false, bool SMALL = false>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_waves(P, W, D, SMALL), fold16_waves(P, W, D, SMALL)))) void fold_mfma16_kernel(
+// CG (round 6: launches of 17 .. 32 blocks): column groups of sixteen blocks per pass over the taps.  The fold launch sits on the board's
+// POWER budget, not on a pipe: its time is the matrix time PLUS the memory time at the clock the two leave each other (4-column form:
+// 0.5 + 2.2 ms, 16 columns: 1.9 + 2.2 ms, profiles/r06_experiments.md) -- so what shortens a block's share is more blocks per byte of
+// taps.  With CG = 2 a loaded (and rotated) tap operand multiplies TWO spectrum operands, blocks 0 .. 15 and 16 .. 31: twice the matrix
+// instructions per KiB of taps and per vector instruction, the same chain of FMAs per (block, channel, bin).
+template <int P, int W, int D, bool WIN = false, bool SMALL = false, int CG = 1>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_waves(P, W, D, SMALL, CG), fold16_waves(P, W, D, SMALL, CG)))) void fold_mfma16_kernel(
 		const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
 		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int octet_base, int nch, int nb,
 		const int2 *__restrict__ win)
 {
 	static_assert(!WIN || W == 1, "windows are per wave: no spectrum tile is shared");
 	static_assert(D == 2 || D == 4, "the LDS stage of a trip is a compile-time constant for even D");
+	static_assert(CG == 1 || (CG == 2 && !SMALL && !WIN), "two column groups: the sixteen-column instruction, every row");
 	// a quad's spectrum tile = 64 segments (block n, row k) of 128 contiguous bytes (16 bins) = 512 items of 16 bytes.  A load
 	// instruction takes 64 consecutive items -- eight whole segments: eight cache lines, like a load of taps; fetched the way the
 	// matrix operand wants them (lane n + 16 k <- its own 32 bytes) an instruction touched 64 lines and the address unit, not the matrix
 	// pipe, set the pace.  EVERY wave fetches MINE instructions' worth -- with more than eight waves the upper ones would fetch (and
 	// store) what the lower ones do -- so that all waves issue the same loads and no branch sits in the loop: behind a branch the
 	// compiler's s_waitcnt count assumes the path with the most loads, and the waves on the other path wait for all but one quad
-	constexpr int MINE = W >= 8 ? 1 : 8 / W;
-	constexpr int XPITCH = 68;                                // v4f per bin pair: 64 + 4, so that the eight parts of a segment do not share banks
-	__shared__ v4f xt[2][8][XPITCH];                          // [stage][bin pair][segment n + 16 k] = (Re, Im) of bins 2 b, 2 b + 1
+	constexpr int NLOADS = 8 * CG;                            // load instructions per quad's tile: 64 (CG = 2: 128) segments of eight 16-byte items
+	constexpr int MINE = W >= NLOADS ? 1 : NLOADS / W;
+	constexpr int XPITCH = 64 * CG + 4;                       // v4f per bin pair: the segments + 4, so that the eight parts of a segment do not share banks
+	__shared__ v4f xt[2][8][XPITCH];                          // [stage][bin pair][64 cg + segment n + 16 k] = (Re, Im) of bins 2 b, 2 b + 1 of block 16 cg + n, row k
 	const int ngrp = m >> 4;
 	// blockIdx -> (tile = bin group x slice, channel group).  The workgroups that share a spectrum tile must sit on ONE XCD (the
 	// dispatcher puts block b on XCD b mod 8) and be resident TOGETHER, so that the tile comes out of HBM once and out of that XCD's
@@ -159,17 +167,17 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 	int xseg[MINE];
 #pragma unroll
 	for (int i = 0; i < MINE; i++) {
-		const int item = (((wave * MINE) & 7) + i) * 64 + lane, seg = item >> 3, part = item & 7;
-		const int sn = seg & 15, sk = seg >> 4;
+		const int item = (((wave * MINE) % NLOADS) + i) * 64 + lane, seg = item >> 3, part = item & 7;
+		const int sn = (seg & 15) + 16 * (seg >> 6), sk = (seg >> 4) & 3;
 		const int bi = sn < nb ? sn : nb - 1;                 // columns past the last block repeat it; they are never stored
 		xp[i] = xp0[i] = (const char *)(spec + (size_t)bi * spec_stride + ((size_t)s * rows + sk) * (size_t)m + g * 16 + 2 * part);
 		xseg[i] = part * XPITCH + seg;
 	}
 	const char *const tb0 = tb;
 	constexpr int NACC = SMALL ? 4 : 16;                      // accumulators per octet: one per bin quad (4 x 4 products) / one per bin
-	v4f acc[P][NACC];
+	v4f acc[P * CG][NACC];                                    // [octet p, column group cg] at p * CG + cg
 #pragma unroll
-	for (int p = 0; p < P; p++)
+	for (int p = 0; p < P * CG; p++)
 #pragma unroll
 		for (int j = 0; j < NACC; j++) acc[p][j] = v4f{ 0.f, 0.f, 0.f, 0.f };
 	v4f h[D][P][4];
@@ -226,16 +234,26 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 		}
 #pragma unroll
 		for (int b = 0; b < 8; b++) {
-			const v4f x = xt[stage][b][lane];                 // (Re, Im) of bins 2 b and 2 b + 1 for (block n, row k)
+			v4f x[CG];                                        // (Re, Im) of bins 2 b and 2 b + 1 for (block 16 cg + n, row k)
+#pragma unroll
+			for (int cg = 0; cg < CG; cg++) x[cg] = xt[stage][b][64 * cg + lane];
+#pragma unroll
+			for (int p = 0; p < P; p++)
+#pragma unroll
+				for (int cg = 0; cg < CG; cg++) {
+					v4f *a = acc[p * CG + cg];
+					a[2 * b] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[slot][p][b >> 1][(2 * b) & 3], x[cg][0], a[2 * b], 0, 0, 0);
+					a[2 * b + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[slot][p][b >> 1][(2 * b + 1) & 3], x[cg][2], a[2 * b + 1], 0, 0, 0);
+				}
 #pragma unroll
 			for (int p = 0; p < P; p++) {
-				acc[p][2 * b] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[slot][p][b >> 1][(2 * b) & 3], x[0], acc[p][2 * b], 0, 0, 0);
-				acc[p][2 * b + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[slot][p][b >> 1][(2 * b + 1) & 3], x[2], acc[p][2 * b + 1], 0, 0, 0);
-			}
+				const float r0 = rot90(h[slot][p][b >> 1][(2 * b) & 3], sign_mask), r1 = rot90(h[slot][p][b >> 1][(2 * b + 1) & 3], sign_mask);
 #pragma unroll
-			for (int p = 0; p < P; p++) {
-				acc[p][2 * b] = __builtin_amdgcn_mfma_f32_16x16x4f32(rot90(h[slot][p][b >> 1][(2 * b) & 3], sign_mask), x[1], acc[p][2 * b], 0, 0, 0);
-				acc[p][2 * b + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(rot90(h[slot][p][b >> 1][(2 * b + 1) & 3], sign_mask), x[3], acc[p][2 * b + 1], 0, 0, 0);
+				for (int cg = 0; cg < CG; cg++) {
+					v4f *a = acc[p * CG + cg];
+					a[2 * b] = __builtin_amdgcn_mfma_f32_16x16x4f32(r0, x[cg][1], a[2 * b], 0, 0, 0);
+					a[2 * b + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(r1, x[cg][3], a[2 * b + 1], 0, 0, 0);
+				}
 			}
 		}
 	};
@@ -286,18 +304,24 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 	} else
 	// D[row i][block n] sits in register i & 3 of lane 16 (i >> 2) + n: this lane holds block n and the channels 2 k, 2 k + 1 of each
 	// octet (Re, Im, Re, Im in its four registers), one accumulator per bin: 128 contiguous bytes per channel
-	if (n < nb) {
+	{
 #pragma unroll
-		for (int p = 0; p < P; p++)
+		for (int cg = 0; cg < CG; cg++) {
+			const int blk = 16 * cg + n;
+			if (blk >= nb) continue;
 #pragma unroll
-			for (int cp = 0; cp < 2; cp++) {
-				const int c = 8 * (octet0 + p) + 2 * k + cp;
-				if (c >= nch) continue;
-				float2 *po = partial + (size_t)n * partial_stride + ((size_t)c * slices + s) * (size_t)m + g * 16;
+			for (int p = 0; p < P; p++)
 #pragma unroll
-				for (int j = 0; j < 16; j += 2)
-					*(v4f *)(po + j) = v4f{ acc[p][j][2 * cp], acc[p][j][2 * cp + 1], acc[p][j + 1][2 * cp], acc[p][j + 1][2 * cp + 1] };
-			}
+				for (int cp = 0; cp < 2; cp++) {
+					const int c = 8 * (octet0 + p) + 2 * k + cp;
+					if (c >= nch) continue;
+					const v4f *a = acc[p * CG + cg];
+					float2 *po = partial + (size_t)blk * partial_stride + ((size_t)c * slices + s) * (size_t)m + g * 16;
+#pragma unroll
+					for (int j = 0; j < 16; j += 2)
+						*(v4f *)(po + j) = v4f{ a[j][2 * cp], a[j][2 * cp + 1], a[j + 1][2 * cp], a[j + 1][2 * cp + 1] };
+				}
+		}
 	}
 }
 
@@ -347,19 +371,21 @@ struct FoldArgs {
 };
 
 // workgroups of 8 P W channels first; the octets left over get single-wave workgroups in a launch of their own
-template <int P, int W, int D, bool SMALL = false>
+template <int P, int W, int D, bool SMALL = false, int CG = 1>
 static int fold16_go(const FoldArgs &a)
 {
 	const int ntile = (a.m >> 4) * a.slices;
 	const int groups = a.ngroups / (P * W), rest = a.ngroups - groups * P * W;
 	int launches = 0;
 	if (groups > 0) {
-		hipExtLaunchKernelGGL((fold_mfma16_kernel<P, W, D, false, SMALL>), dim3((unsigned)(groups * ntile)), dim3(64 * W), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
+		hipExtLaunchKernelGGL((fold_mfma16_kernel<P, W, D, false, SMALL, CG>), dim3((unsigned)(groups * ntile)), dim3(64 * W), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
 			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, 0, a.nch, a.nb, (const int2 *)nullptr);
 		launches++;
 	}
 	if (rest > 0) {
-		hipExtLaunchKernelGGL((fold_mfma16_kernel<1, 1, D, false, SMALL>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+		// (a single wave fetches the whole spectrum tile itself: two quads in flight keep that within its registers when the tile is 32 blocks wide)
+		constexpr int DR = CG > 1 ? 2 : D;
+		hipExtLaunchKernelGGL((fold_mfma16_kernel<1, 1, DR, false, SMALL, CG>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
 			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, groups * P * W, a.nch, a.nb, (const int2 *)nullptr);
 		launches++;
 	}
@@ -380,6 +406,7 @@ static int fold16_go_win(const FoldArgs &a, const int2 *win)
 struct FoldVariant { int layout, p, q, w, d; int (*go)(const FoldArgs &); };
 #define F16(P, W, D) { TAPL_OCTET, P, 4, W, D, fold16_go<P, W, D> }
 #define F4(P, W, D) { TAPL_OCTET, P, 1, W, D, fold16_go<P, W, D, true> }        // the four-column form: at most four blocks
+#define F32(P, W, D) { TAPL_OCTET, P, 8, W, D, fold16_go<P, W, D, false, 2> }   // two column groups: 17 .. 32 blocks
 // The first entry whose look-ahead D divides the slice's quads is the one used.
 // Measured on cfg3 (M = 4096, 512 rows per slice) with profiles/fold_variants.py: profiles/r05/fold_variants_cfg3_k4.md.
 static const FoldVariant fold_variants[] = {
@@ -388,11 +415,14 @@ static const FoldVariant fold_variants[] = {
 	// turns with it and the pipeline loses 10 % (profiles/r05/k4_tilings_in_pipeline.txt)
 	F16(2, 4, 4), F16(2, 4, 2),
 	F4(2, 4, 2),
+	F32(1, 4, 4), F32(1, 4, 2),
 #ifdef HFDL_LAB
+	F32(1, 8, 2), F32(1, 8, 4), F32(1, 2, 2), F32(2, 4, 2),
 	F4(2, 4, 4), F4(4, 4, 2), F4(1, 8, 4), F4(2, 8, 2), F4(2, 8, 4), F4(4, 2, 2), F4(1, 4, 4),
 	F16(1, 4, 2), F16(1, 4, 4), F16(1, 8, 2), F16(1, 8, 4), F16(2, 2, 2), F16(2, 8, 2), F16(1, 2, 2), F16(1, 2, 4), F16(3, 4, 2),
 #endif
 };
+#undef F32
 #undef F4
 #undef F16
 constexpr int N_FOLD_VARIANTS = (int)(sizeof(fold_variants) / sizeof(fold_variants[0]));
@@ -418,8 +448,8 @@ static const FoldVariant *pick_variant(const Geometry &g, int nb)
 	if (g.fold_tile >= 0 && g.fold_tile < N_FOLD_VARIANTS && 4 * fold_variants[g.fold_tile].q >= nb && variant_fits(fold_variants[g.fold_tile], g)) return &fold_variants[g.fold_tile];
 	for (const FoldVariant &f : fold_variants)             // up to four blocks: the four-column form
 		if (nb <= 4 && f.q == 1 && variant_fits(f, g)) return &f;
-	for (const FoldVariant &f : fold_variants)
-		if (4 * f.q >= nb && variant_fits(f, g)) return &f;
+	for (const FoldVariant &f : fold_variants)             // the narrowest form that holds the blocks: sixteen columns up to 16 blocks, thirty-two beyond
+		if (f.q == (nb <= 16 ? 4 : 8) && variant_fits(f, g)) return &f;
 	return nullptr;
 }
 
@@ -455,8 +485,10 @@ int launch_fold(const Geometry &g, const float2 *taps, const float2 *spectrum, s
 	int launches = 0;
 	if (nb_max > FOLD_MAX_BLOCKS) nb_max = FOLD_MAX_BLOCKS;
 	// one launch per nb_max blocks: a launch takes ANY block count up to 16 (columns past the last block are computed and dropped)
+	if (g.fold_win && g.tap_layout == TAPL_OCTET && nb_max > 16) nb_max = 16;      // the pruned fold has the sixteen-column form only
 	for (int done = 0; done < nb;) {
-		const int take = nb - done < nb_max ? nb - done : nb_max;
+		int take = nb - done < nb_max ? nb - done : nb_max;
+		if (take > 16 && !pick_variant(g, take)) take = 16;                       // no thirty-two-column tiling fits this geometry
 		const bool first = done == 0, last = done + take >= nb;
 		const float2 *sp = spectrum + (size_t)done * spec_stride;
 		float2 *pp = partial + (size_t)done * partial_stride;

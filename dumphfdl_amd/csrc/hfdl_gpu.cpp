@@ -115,8 +115,8 @@ struct hfdl_gpu_frontend {
 	hipStream_t stream_b = nullptr;     // B: demodulator launches of half k-1, beside the forward FFTs and the fold of half k
 	hipStream_t stream_d = nullptr;     // D: burst decoders + PDU snapshots, off the demodulators' critical path (== stream_b only in a laboratory A/B run)
 	bool own_decode_stream = false;
-	static constexpr int MAX_HALF = FOLD_MAX_BLOCKS;      // blocks per half at most: what one fold launch can take (16)
-	static constexpr int MAX_STAGE = MAX_HALF + 2;        // staging buffers for host input at most
+	static constexpr int MAX_HALF = FOLD_MAX_BLOCKS;      // blocks per half at most: what one fold launch can take (32)
+	static constexpr int MAX_STAGE = HFDL_GPU_PREFETCH_MAX + 1;      // staging buffers for host input at most: uploads run at most 17 blocks ahead
 	hipEvent_t ev_dm[2][MAX_HALF] = {};              // demodulator launch j of the half in buffer 0 / 1 done (the decoder may start)
 	hipEvent_t ev_dm_cur[2] = { nullptr, nullptr };  // LAST demodulator launch of that half done (chan_out free): an ev_dm, or (timing on) the stop event of a timed pair
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_dmt;      // timed demodulator launches not yet read
@@ -305,6 +305,7 @@ static int pick_demod_batch(const hfdl_gpu_frontend *fe)
 // catching up, the bench) the spectra of up to `fold_nb` consecutive blocks are folded in ONE pass over the taps on the matrix pipe
 // (fold_kernels.hip).  Every block's sums are bit-identical to a launch of its own (fixed FMA chain per bin); a caller that polls
 // or syncs after every block (live input) still gets one launch per block: a sync / poll closes the half as it is.
+static_assert(HFDL_GPU_FOLD_BATCH_MAX == FOLD_MAX_BLOCKS, "include/hfdl_gpu.h and kernels.h name the same limit");
 static int pick_fold_batch(const hfdl_gpu_frontend *fe)
 {
 	// 16 = the columns of the matrix instruction, where the fold bounds the block.  Where the demodulator does (fewer than 128
@@ -564,7 +565,7 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	fe->batch = fe->demod.batch;        // what fits the demodulator's LDS
 	fe->fold_nb = pick_fold_batch(fe);
 	fe->half_blocks = std::min((int)hfdl_gpu_frontend::MAX_HALF, ((std::max(fe->fold_nb, fe->batch) + fe->fold_nb - 1) / fe->fold_nb) * fe->fold_nb);
-	fe->n_stage = fe->half_blocks + 2;
+	fe->n_stage = std::min(fe->half_blocks + 2, (int)hfdl_gpu_frontend::MAX_STAGE);      // a 32-block half is not uploaded a whole half ahead: 17 blocks of link time cover a 6 ms fold five times over
 	for (int i = 0; i < fe->n_stage; i++) {
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_ready[i], hipEventDisableTiming));
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_free[i], hipEventDisableTiming));
@@ -1090,7 +1091,7 @@ extern "C" int hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *tot
 	return 0;
 }
 
-extern "C" int hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[17], double ms[17])
+extern "C" int hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[HFDL_GPU_FOLD_BATCH_MAX + 1], double ms[HFDL_GPU_FOLD_BATCH_MAX + 1])
 {
 	if (!fe || !counts) return fail(HFDL_GPU_EINVAL, "null argument");
 	int rc = hfdl_gpu_frontend_sync(fe);

@@ -65,7 +65,7 @@ __host__ __device__ inline size_t tap_index_f(int layout, int m, size_t rs_f, in
 }
 inline int tap_layout_group(int layout) { return layout == TAPL_OCTET ? 8 : 1; }
 
-constexpr int FOLD_MAX_BLOCKS = 16;         // blocks one fold launch can take: the sixteen columns of the matrix instruction
+constexpr int FOLD_MAX_BLOCKS = 32;         // blocks one fold launch can take: two column groups of the sixteen-column matrix instruction
 
 // The NCO phasor table of a block, made while that block's forward FFT runs.  decimating_shift_addition_cc's phasor recurrence
 // (src/libcsdr_gpl.c:48-66) is 1792 strictly serial fp32 steps per channel at cfg3 -- 47 us for a lone lane, which used to be the

@@ -75,6 +75,8 @@ EXPORTS = [
 ]
 
 
+FOLD_BATCH_MAX = 32        # HFDL_GPU_FOLD_BATCH_MAX of include/hfdl_gpu.h
+
 # what include/hfdl_gpu_lab.h adds in the laboratory build (libhfdl_gpu_lab.so)
 LAB_EXPORTS = ["hfdl_gpu_lab_fold_variant_count", "hfdl_gpu_lab_fold_variant_describe", "hfdl_gpu_lab_fold_variant_probe", "hfdl_gpu_lab_stream_read_probe",
                "hfdl_gpu_lab_read_constants"]
@@ -157,7 +159,7 @@ def _bind(L):
     L.hfdl_gpu_frontend_fold_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_demod_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.hfdl_gpu_frontend_fold_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
-    L.hfdl_gpu_frontend_fold_launch_shapes.argtypes = [C.c_void_p, C.POINTER(C.c_int64 * 17), C.POINTER(C.c_double * 17)]
+    L.hfdl_gpu_frontend_fold_launch_shapes.argtypes = [C.c_void_p, C.POINTER(C.c_int64 * (FOLD_BATCH_MAX + 1)), C.POINTER(C.c_double * (FOLD_BATCH_MAX + 1))]
     L.hfdl_gpu_frontend_input_copied.argtypes = [C.c_void_p, C.c_uint64]
     L.hfdl_gpu_frontend_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 5), C.POINTER(C.c_int64 * 5)]
     L.hfdl_gpu_frontend_reset_timers.argtypes = [C.c_void_p, C.c_int]
@@ -367,15 +369,15 @@ class Frontend:
 
     def fold_launch_shapes(self):
         """{blocks per launch: timed fold launches of that size} since reset_timers(True)."""
-        c = (C.c_int64 * 17)()
+        c = (C.c_int64 * (FOLD_BATCH_MAX + 1))()
         _check(self._L.hfdl_gpu_frontend_fold_launch_shapes(self._h, C.byref(c), None), self._L)
-        return {nb: int(c[nb]) for nb in range(1, 17) if c[nb]}
+        return {nb: int(c[nb]) for nb in range(1, FOLD_BATCH_MAX + 1) if c[nb]}
 
     def fold_launch_times(self):
         """{blocks per launch: (timed fold launches of that size, their kernel time in ms)} since reset_timers(True)."""
-        c, ms = (C.c_int64 * 17)(), (C.c_double * 17)()
+        c, ms = (C.c_int64 * (FOLD_BATCH_MAX + 1))(), (C.c_double * (FOLD_BATCH_MAX + 1))()
         _check(self._L.hfdl_gpu_frontend_fold_launch_shapes(self._h, C.byref(c), C.byref(ms)), self._L)
-        return {nb: (int(c[nb]), float(ms[nb])) for nb in range(1, 17) if c[nb]}
+        return {nb: (int(c[nb]), float(ms[nb])) for nb in range(1, FOLD_BATCH_MAX + 1) if c[nb]}
 
     def stage_times(self):
         """{stage: (total ms, launches)} of the timed kernels since reset_timers(True): fft (per block), fold, ifft, demod, decode."""

@@ -77,7 +77,7 @@ typedef struct {
 	int32_t fold_batch;              /* blocks whose spectra one fold launch multiplies against ONE pass over the per-channel filter taps when
 	                                    they are pushed faster than they are collected (src/fastddc.c:123-150 run for that many blocks; the taps are
 	                                    > 99 % of a block's bytes on the 256-channel geometries).  Every block's result is bit-identical to a launch
-	                                    of its own; a poll / sync always folds what has been pushed.  HFDL_GPU_FOLD_BATCH=1..16 overrides the default
+	                                    of its own; a poll / sync always folds what has been pushed.  HFDL_GPU_FOLD_BATCH=1..32 overrides the default
 	                                    (16 from 128 channels up, where the fold bounds the block; 8 below) at create time.  0 from hfdl_gpu_plan_geometry() */
 	int32_t prefetch_depth;          /* host blocks whose upload hfdl_gpu_frontend_prefetch_block_raw() may queue ahead of their push
 	                                    (half + 1, for a staging ring of half + 2 buffers in HBM, where a half = the blocks between two fold / inverse-FFT
@@ -87,9 +87,10 @@ typedef struct {
 	                                    term) unless HFDL_GPU_FOLD_PRUNE is set.  0 from hfdl_gpu_plan_geometry() */
 } hfdl_gpu_geometry;
 #define HFDL_GPU_PREFETCH_MAX 17
+#define HFDL_GPU_FOLD_BATCH_MAX 32   /* blocks one fold launch takes at most: two column groups of the sixteen-column matrix instruction */
 
 /* Create-time configuration read from the environment by hfdl_gpu_frontend_create() (every create reads it afresh; nothing is cached):
- *   HFDL_GPU_FOLD_BATCH   1..16  blocks per fold launch (geometry.fold_batch)
+ *   HFDL_GPU_FOLD_BATCH   1..32  blocks per fold launch (geometry.fold_batch)
  *   HFDL_GPU_DEMOD_BATCH  1..8   blocks per demodulator launch (geometry.demod_batch)
  *   HFDL_GPU_HOST_THREADS >= 1   host threads that design the filter taps (default: one per core; set to cores / processes when several
  *                                front ends are created at once on one host)
@@ -267,10 +268,11 @@ int  hfdl_gpu_frontend_read_tap_block(hfdl_gpu_frontend *fe, int what, int32_t c
  * blocks: hfdl_gpu_frontend_fold_blocks() = the blocks the timed launches covered */
 int  hfdl_gpu_frontend_fold_time_ms(hfdl_gpu_frontend *fe, double *total_ms, int64_t *launches);
 int  hfdl_gpu_frontend_fold_blocks(hfdl_gpu_frontend *fe, int64_t *blocks);
-/* timed fold launches by block count: counts[nb] = launches that folded nb blocks (nb = 1 .. 16; counts[0] unused) since the timers
- * were reset, ms[nb] (may be NULL) = their kernel time -- what a caller needs to price the launches it timed (a launch of up to 4
- * blocks runs the four-column form of the kernel and is bound by the HBM reads of the taps, one of 5 .. 16 the sixteen-column form) */
-int  hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[17], double ms[17]);
+/* timed fold launches by block count: counts[nb] = launches that folded nb blocks (nb = 1 .. HFDL_GPU_FOLD_BATCH_MAX; counts[0] unused)
+ * since the timers were reset, ms[nb] (may be NULL) = their kernel time -- what a caller needs to price the launches it timed (a launch
+ * of up to 4 blocks runs the four-column form of the kernel and is bound by the HBM reads of the taps, one of 5 .. 16 the sixteen-column
+ * form, one of 17 .. 32 the thirty-two-column form: every loaded tap operand multiplies two spectrum operands) */
+int  hfdl_gpu_frontend_fold_launch_shapes(hfdl_gpu_frontend *fe, int64_t counts[HFDL_GPU_FOLD_BATCH_MAX + 1], double ms[HFDL_GPU_FOLD_BATCH_MAX + 1]);
 int  hfdl_gpu_frontend_reset_timers(hfdl_gpu_frontend *fe, int enable);
 /* the same for the demodulator kernel (the kernel that bounds the small geometries), from its dispatch's own start / stop events;
  * *blocks = the blocks those launches covered (a launch takes up to geometry.demod_batch blocks) */

@@ -28,8 +28,10 @@ fe.enable_taps(False)
 rng = np.random.default_rng(1)
 x = (rng.standard_normal(2 * 16 * g.input_size).astype(np.float32) * 0.05)
 dev = torch.from_numpy(x).cuda()
-for b in range(16):     # sixteen spectra into the half (no sync in between: they stay queued until the half is full)
-    fe.push_block(dev.data_ptr() + 8 * b * g.input_size)
+# sixteen spectra into the half (no sync in between: they stay queued until the half is full); thirty-two when the front end was created
+# with HFDL_GPU_FOLD_BATCH=32 and the thirty-two-column tilings are asked for (the sixteen resident blocks pushed twice)
+for b in range(max(16, min(max(nbs), g.fold_batch))):
+    fe.push_block(dev.data_ptr() + 8 * (b % 16) * g.input_size)
 fe.poll_pdus()
 rows = []
 ref = {}
@@ -43,7 +45,7 @@ for v, (p, q, wv, d, nbmax, layout) in enumerate(F.fold_variants()):
     if only is not None and v not in only:
         continue
     for nb in nbs:
-        if nb > nbmax:        # the four-column form takes at most 4 blocks, the sixteen-column form any count up to 16
+        if nb > nbmax or (nbmax == 32 and nb <= 16 and nb != 16):        # the four-column form takes at most 4 blocks, the sixteen-column form any count up to 16, the thirty-two-column form is timed at 16 (for comparison) and beyond
             continue
         try:
             avg, best, chk = fe.fold_variant_probe(v, nb, reps)

@@ -916,7 +916,8 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
     the company, so the channelizer output of EVERY block -- read back per block, compared as uint32 -- and every PDU equal those of a
     pass over the taps per block (HFDL_GPU_FOLD_BATCH=1: the four-column form of the kernel, K = 1 products in the order of the K = 4
     instruction), for full batches of 16 / 8 (the sixteen-column form) / 4 / 2 and the ragged batches that draining polls / syncs
-    cut (13, 7, 5: columns past the last block computed and dropped; 3, 1: the four-column form).  5 channels: demodulator-bound
+    cut (13, 7, 5: columns past the last block computed and dropped; 3, 1: the four-column form) -- and, since round 6, for batches of
+    17 .. 32 blocks, which run the thirty-two-column form (two spectrum operands per loaded tap operand).  5 channels: demodulator-bound
     geometry (several blocks per demodulator launch, five channels padded to an octet, only the single-wave workgroups of the
     left-over octets run); 130 channels: fold-bound shape (two 64-channel workgroups + one left-over octet; demodulator launches
     held back behind the next half's forward FFTs)."""
@@ -928,7 +929,7 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
         bursts = synth.plan_traffic(freqs, dur, seed=31, dense=True, gap_s=0.12, amp=(0.02, 0.1))
     else:
         freqs = [int(cf + (i - nch // 2) * 15_000 + 4_000) for i in range(nch)]
-        dur = 3.7               # 19 blocks; a single-slot burst lasts 2.5 s
+        dur = 6.6               # 34 blocks (a 32-block launch and a ragged one); a single-slot burst lasts 2.5 s
         bursts = [dict(freq=freqs[c], mode=int(rng.integers(0, 4)), octets=b"", t0=float(rng.uniform(0.1, 0.7)), amp=0.03, cfo=float(rng.uniform(-10, 10)))
                   for c in (0, 3, 64, 77, 128, 129)]
         for b in bursts:
@@ -949,7 +950,7 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
             for j in range(k):
                 fe.push_block(x[(b + j) * n:(b + j + 1) * n])
             got += fe.poll_pdus()                 # closes the half as it is: one fold launch for its k blocks
-            half = min(16, -(-max(g.fold_batch, g.demod_batch) // g.fold_batch) * g.fold_batch)      # blocks a half holds (hfdl_gpu.cpp half_blocks)
+            half = min(32, -(-max(g.fold_batch, g.demod_batch) // g.fold_batch) * g.fold_batch)      # blocks a half holds (hfdl_gpu.cpp half_blocks)
             held = min(k, ((k - 1) % half) + 1)   # blocks of the newest half: what read_tap(back=...) still reaches
             for j in range(held):
                 outs.append((b + k - held + j, [fe.read_tap(F.TAP_CHAN_OUT, c, back=held - 1 - j).view(np.uint32).copy() for c in watch]))
@@ -961,7 +962,7 @@ def test_fold_batching_changes_nothing(gpu, monkeypatch, fs, nch):
     ref_outs, ref_pdus, ref_stats = run(1, [1])
     assert len(ref_outs) == len(x) // (28672 if fs == 250000 else 458752)
     assert len(ref_pdus) >= len(bursts) - 2
-    for fold_env, cuts in ((4, [4]), (4, [3, 1, 2, 4]), (8, [8]), (8, [7, 5, 8, 3]), (2, [2, 1]), (16, [16]), (16, [13, 5, 16, 3, 9])):
+    for fold_env, cuts in ((4, [4]), (4, [3, 1, 2, 4]), (8, [8]), (8, [7, 5, 8, 3]), (2, [2, 1]), (16, [16]), (16, [13, 5, 16, 3, 9]), (32, [32]), (32, [17, 25, 9, 32, 20])):
         outs, pdus, stats = run(fold_env, cuts)
         assert outs, (fold_env, cuts)
         for blk, chans in outs.items():
@@ -976,28 +977,30 @@ def test_fold_mfma_equals_fma_chain(gpu, monkeypatch, fs, nch):
     """The fold runs on the fp32 matrix pipe: v_mfma_f32_16x16x4_f32 (per instruction one bin x eight channels' Re / Im rows x FOUR alias
     rows x sixteen blocks; taps in the octet-interleaved layout, four rows per KiB).  One instruction adds its four products to the
     accumulator one after the other, each an exact fmaf (profiles/micro/mfma_k4.hip), so every compiled tiling (the sweep set of the
-    laboratory build included) must leave the partial sums of EVERY block count 1 .. 16 bit-identical to the plain-VALU reference
+    laboratory build included) must leave the partial sums of EVERY block count 1 .. 32 (17 .. 32: the thirty-two-column tilings, which
+    are also run at 16 and fewer) bit-identical to the plain-VALU reference
     kernel, which spells each bin's sum out as the same chain of fused multiply-adds one thread at a time: the checksum over the bit
     patterns of all partial sums is compared, the buffer poisoned before every kernel.  5 channels: one octet (three channels of zero
     taps), the single-wave workgroups only; 130: two 64-channel workgroups + a left-over octet; 32: single-wave workgroups again."""
     cf = 10_000_000
     lab = F.load_lab()
     freqs = [int(cf + (i - nch // 2) * (15_000 if nch > 5 else 40_000) + 4_000) for i in range(nch)]
-    monkeypatch.setenv("HFDL_GPU_FOLD_BATCH", "16")
+    monkeypatch.setenv("HFDL_GPU_FOLD_BATCH", "32")
     fe = gpu.Frontend(fs, cf, freqs, lib=lab)
     g = fe.geometry
-    assert g.fold_batch == 16
+    assert g.fold_batch == 32
     rng = np.random.default_rng(nch)
     n = fe.input_size
     for b in range(16):
         fe.channelize_block((rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.1))
-    # channelize_block closes a half per block; fill one half with 16 spectra for the probe
-    for b in range(16):
+    # channelize_block closes a half per block; fill one half with 32 spectra for the probe
+    for b in range(32):
         fe.push_block((rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.1))
     fe.sync()
     variants = F.fold_variants()
+    assert {nbmax for (_, _, _, _, nbmax, _) in variants} == {4, 16, 32}
     ran = 0
-    for nb in (1, 2, 3, 4, 5, 8, 11, 13, 16):
+    for nb in (1, 2, 3, 4, 5, 8, 11, 13, 16, 17, 21, 31, 32):
         ref = fe.fold_variant_probe(-1, nb, 1)[2]
         for v, (p, q, w, d, nbmax, layout) in enumerate(variants):
             if nb > nbmax or layout != 2:
@@ -1008,7 +1011,7 @@ def test_fold_mfma_equals_fma_chain(gpu, monkeypatch, fs, nch):
                 continue                              # rows per slice not a multiple of the tiling's look-ahead
             assert chk == ref, (nb, (p, q, w, d, layout))
             ran += 1
-    assert ran >= 9
+    assert ran >= 13
     fe.close()
 
 

@@ -83,7 +83,7 @@ def test_product_library_exports_exactly_the_public_header():
     prod = dyn(hf.lib_path())
     assert prod == pub, (sorted(prod - pub), sorted(pub - prod))
     assert not [s for s in prod if "probe" in s or "variant" in s or "_lab_" in s]
-    assert os.path.getsize(hf.lib_path()) < 700 * 1024
+    assert os.path.getsize(hf.lib_path()) < 800 * 1024        # (round 6: + the two thirty-two-column tilings and their left-over forms)
     strings = subprocess.run(["strings", hf.lib_path()], capture_output=True, text=True).stdout
     for knob in ("HFDL_GPU_FFT_STREAM", "HFDL_GPU_DECODE_STREAM", "HFDL_GPU_FOLD_TILE", "HFDL_GPU_FOLD_BOUND", "HFDL_GPU_PROBE_VERBOSE"):
         assert knob not in strings, knob
