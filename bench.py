@@ -885,7 +885,14 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom else None
         fold_flops = 8.0 * geom["channels"] * geom["fft_size"] * fold_nb
         tflops = (fold_flops / (dom_ms * 1e-3) / 1e12) if dom else None
-        wide = dom >= 5                                       # the sixteen-column form: bound by the multiplies; up to 4 blocks: by the HBM reads of the taps
+        # both sides of the launch; `bound` / `frac` = the side that is nearer its peak (round 5 always priced the wide forms on the
+        # matrix pipe, which understated a launch whose operational intensity lies left of the ridge)
+        mfma_frac = (tflops / FP32_MFMA_PEAK_TFLOPS) if tflops else None
+        hbm_frac = (achieved / HBM_PEAK_GBS) if achieved else None
+        wide = bool(dom) and mfma_frac >= hbm_frac
+        intensity = (fold_flops / alg_bytes) if dom else None
+        ridge = FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        fold_form = lambda nb: "4 columns (4x4x1_16B)" if nb <= 4 else "16 columns (16x16x4)" if nb <= 16 else "32 columns (16x16x4, two spectrum operands per tap operand)"
         traffic, traffic_src = traffic_record(args.workload, [dom] * dom_n, dom_n) if dom else (None, None)
         fold_total_ms = sum(ms for _, ms in shape_times.values())
         par = ("%d independent %d-channel streams, one per GPU, no collectives" % (world, geom["channels"])) if args.shard == "streams" else \
@@ -935,19 +942,25 @@ def main():
             # of HBM reads (PMC: profiles/r05_experiments.md) -- so the roofline is the matrix pipe's; the HBM side of the same launch is
             # `hbm`.  Launches of at most four blocks run the four-column form, bound by the HBM reads: priced as such when they dominate.
             "roofline": {"bound": "mfma" if wide else "hbm",
-                         "kernel": "fold_mfma16_kernel (v_mfma_f32_16x16x4_f32: four alias rows per instruction)" if wide else "fold_mfma16_kernel, four-column form (v_mfma_f32_4x4x1_16B_f32)",
+                         "kernel": "fold_mfma16_kernel, %s" % fold_form(dom) if dom else None,
                          "achieved": tflops if wide else achieved, "peak": FP32_MFMA_PEAK_TFLOPS if wide else HBM_PEAK_GBS, "unit": "TFLOP/s" if wide else "GB/s",
-                         "frac": ((tflops / FP32_MFMA_PEAK_TFLOPS) if wide else (achieved / HBM_PEAK_GBS)) if dom else None,
+                         "frac": (mfma_frac if wide else hbm_frac) if dom else None,
+                         "frac_is": "max(mfma.frac, hbm.frac): the side of the launch nearer its peak names the bound",
+                         "operational_intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
+                         # The launch sits on the board's POWER budget: its time is the matrix time plus the memory time at the clock the two
+                         # leave each other (four / sixteen / thirty-two columns: 0.5 / 1.9 / 3.8 ms of multiplies + 2.2 ms of taps;
+                         # profiles/r06_experiments.md), so the two utilisations ADD towards ~1 instead of either reaching it.
+                         "utilisation_sum": (mfma_frac + hbm_frac) if dom else None,
                          "priced_on": ("the %d-block launches: %d of the timed region's %d fold launches, %.0f %% of its fold kernel time"
                                        % (dom, dom_n, fold_n, 100.0 * dom_ms * dom_n / max(fold_total_ms, 1e-9))) if dom else None,
                          "algorithmic_flops_per_launch": fold_flops,
                          "flops_model": "8 flops per complex multiply-accumulate x channels x fft_size x blocks_per_launch (src/fastddc.c:114-150 run for that many blocks)",
                          "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": dom_ms, "launches": dom_n, "blocks_per_launch": dom, "fold_batch": fold_batch,
-                         "launch_shapes": {str(nb): {"launches": c, "avg_ms": ms / c, "form": "16 columns (16x16x4)" if nb >= 5 else "4 columns (4x4x1_16B)"}
+                         "launch_shapes": {str(nb): {"launches": c, "avg_ms": ms / c, "form": fold_form(nb)}
                                            for nb, (c, ms) in sorted(shape_times.items())},
-                         "mfma": {"achieved": tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (tflops / FP32_MFMA_PEAK_TFLOPS) if tflops else None},
-                         "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "mfma": {"achieved": tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_frac},
+                         "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
                                  "algorithmic_bytes_per_launch": alg_bytes,
                                  "model": "8*NB*input_size + C*8*N + C*8*NB*outputs_per_block per launch: NB queued blocks share ONE pass over the C*N filter "
                                           "taps (NB = blocks_per_launch; NB = 1 is SURVEY.md 8(d)'s per-block figure, algorithmic_bytes_per_block_unbatched)",

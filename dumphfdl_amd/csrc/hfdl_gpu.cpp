@@ -162,6 +162,11 @@ struct hfdl_gpu_frontend {
 	int batch = 1;                      // blocks per demodulator launch (see pick_demod_batch)
 	int fold_nb = 1;                    // blocks per fold launch (see pick_fold_batch)
 	int half_blocks = 1;                // slots per half: a multiple of fold_nb, at least `batch`
+	// How many blocks close the half being filled.  A pipeline that starts empty closes its first half at `half_first` blocks (16 where a
+	// half holds 32): the first fold launch is the sixteen-column form and the demodulators start 3 ms earlier; once a half has been
+	// closed BY FILLING -- the caller pushes faster than it collects -- the next ones take all `half_blocks`.  Any sync / poll that closes
+	// a half early (a drain) starts over.  Results do not depend on where the halves are cut (test_fold_batching_changes_nothing).
+	int half_first = 1, half_target = 1;
 	int cur_half = 0, batch_fill = 0;   // the half being filled and the blocks already in it (forward FFT queued, fold not yet)
 	int last_slot = 0;                  // slot (half * half_blocks + index) of the newest channelized block: what HFDL_GPU_TAP_CHAN_OUT reads
 	int last_index = 0;                 // its index inside the half: spectrum / phasor-table slot of the newest block
@@ -308,10 +313,13 @@ static int pick_demod_batch(const hfdl_gpu_frontend *fe)
 static_assert(HFDL_GPU_FOLD_BATCH_MAX == FOLD_MAX_BLOCKS, "include/hfdl_gpu.h and kernels.h name the same limit");
 static int pick_fold_batch(const hfdl_gpu_frontend *fe)
 {
-	// 16 = the columns of the matrix instruction, where the fold bounds the block.  Where the demodulator does (fewer than 128
-	// channels: the taps are a few hundred MiB and a fold launch takes 0.2 ms whatever it folds) a half of 16 only adds fill,
-	// drain and latency: 8, as in round 4 (cfg2: 0.1545 against 0.1595 ms per block over 256 blocks)
-	return (int)env_long("HFDL_GPU_FOLD_BATCH", 1, hfdl_gpu_frontend::MAX_HALF, fe->fold_bound ? 16 : 8);       // 1 = a pass over the taps per block
+	// 32 where the fold bounds the block (128 channels and more): two column groups of the sixteen-column matrix instruction per loaded tap
+	// operand.  The launch sits on the board's power budget -- its time is the matrix time plus the memory time (profiles/r06_experiments.md)
+	// -- so a block's share shrinks with the blocks per byte of taps: 0.212 ms per block at 32 against 0.245 at 16 in the pipeline.  The
+	// first half after a drain closes at 16 (half_first).  Where the demodulator bounds the block (fewer than 128 channels: the taps are a
+	// few hundred MiB and a fold launch takes 0.2 ms whatever it folds) a long half only adds fill, drain and latency: 8, as in round 4
+	// (cfg2: 0.1545 against 0.1595 ms per block over 256 blocks)
+	return (int)env_long("HFDL_GPU_FOLD_BATCH", 1, hfdl_gpu_frontend::MAX_HALF, fe->fold_bound ? 32 : 8);       // 1 = a pass over the taps per block
 }
 
 static double env_double(const char *name, double lo, double hi, double otherwise)
@@ -565,6 +573,11 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	fe->batch = fe->demod.batch;        // what fits the demodulator's LDS
 	fe->fold_nb = pick_fold_batch(fe);
 	fe->half_blocks = std::min((int)hfdl_gpu_frontend::MAX_HALF, ((std::max(fe->fold_nb, fe->batch) + fe->fold_nb - 1) / fe->fold_nb) * fe->fold_nb);
+	fe->half_first = (fe->fold_bound && fe->half_blocks > 16) ? 16 : fe->half_blocks;
+#ifdef HFDL_LAB
+	if (env_long("HFDL_GPU_FOLD_RAMP", 0, 1, 1) == 0) fe->half_first = fe->half_blocks;      // A/B: every half the full size from the start
+#endif
+	fe->half_target = fe->half_first;
 	fe->n_stage = std::min(fe->half_blocks + 2, (int)hfdl_gpu_frontend::MAX_STAGE);      // a 32-block half is not uploaded a whole half ahead: 17 blocks of link time cover a 6 ms fold five times over
 	for (int i = 0; i < fe->n_stage; i++) {
 		FE_TRY(hipEventCreateWithFlags(&fe->ev_stage_ready[i], hipEventDisableTiming));
@@ -779,7 +792,7 @@ static int enqueue_fft(hfdl_gpu_frontend *fe, const void *fresh, int fmt, int st
 	// (hipExtLaunchKernelGGL start / stop events): a separate hipEventRecord is one more barrier packet in the queue, ~5 us
 	// of idle machine each (profiles/r01_experiments.md).
 	// FFT on stream A: the held-back demodulators of the half before follow the LAST forward FFT of this half (launch_demod)
-	const bool pend = !fe->fft_own_stream && fe->pending_demod_buf >= 0 && i + 1 == fe->half_blocks;
+	const bool pend = !fe->fft_own_stream && fe->pending_demod_buf >= 0 && i + 1 == fe->half_target;
 	if (pend && !fe->ev_fft) HIP_TRY(hipEventCreateWithFlags(&fe->ev_fft, hipEventDisableTiming));
 	// FFT on its own stream: this set of spectra / phasor tables / snapshots was last read by the fold and inverse FFT two halves ago
 	if (fe->fft_own_stream && i == 0) HIP_TRY(hipStreamWaitEvent(fe->stream_f, fe->ev_chan_cur[set] ? fe->ev_chan_cur[set] : fe->ev_chan[set], 0));
@@ -822,8 +835,11 @@ static int close_half(hfdl_gpu_frontend *fe, bool launch_now, bool with_demod = 
 	if (fe->fft_own_stream) HIP_TRY(hipStreamWaitEvent(fe->stream, fe->ev_spec[half], 0));      // the newest forward FFT of this half (stream F)
 	// one launch per `fold_nb` blocks (a half holds a whole number of them only when it is full), each timed and counted AS LAUNCHED: the
 	// shape the bench prices is a launch that happened
-	for (int done = 0; done < nblk; done += fe->fold_nb) {
-		const int take = std::min(fe->fold_nb, nblk - done);
+	for (int done = 0, take = 0; done < nblk; done += take) {
+		take = std::min(fe->fold_nb, nblk - done);
+		// a ragged rest of 17 .. 20 blocks: sixteen columns, then the four-column form (3.9 + 2.7 ms) -- thirty-two columns cost their 6.8 ms
+		// whatever the block count
+		if (take > 16 && take <= 20) take = 16;
 		float2 *pp = fe->d_partial + (size_t)done * fe->partial_stride();
 		if (fe->timing) {
 			std::pair<hipEvent_t, hipEvent_t> e;
@@ -914,11 +930,13 @@ static int push_any(hfdl_gpu_frontend *fe, const void *raw, size_t nsamples, int
 	int rc = stage_input(fe, raw, nsamples, fmt, on_device, &fresh, &sidx);
 	if (rc) return rc;
 	if ((rc = enqueue_fft(fe, fresh, fmt, sidx))) return rc;
-	if (fe->batch_fill < fe->half_blocks) return 0;         // the half is still filling
+	if (fe->batch_fill < fe->half_target) return 0;         // the half is still filling
 	// demodulator-bound geometry (few channels): the fold is short, there is nothing to place the demodulator under, and
 	// holding it back until the NEXT half's forward FFTs would put those blocks' host -> device copies on the demodulator's
 	// critical path (cfg2 fed from host memory: 0.56 -> 0.33 ms per block): launched at once.  Otherwise held back (launch_demod).
-	return close_half(fe, !fe->fold_bound);
+	rc = close_half(fe, !fe->fold_bound);
+	fe->half_target = fe->half_blocks;                      // closed by filling: the caller runs ahead of the collection, the next halves take every slot
+	return rc;
 }
 
 extern "C" int hfdl_gpu_frontend_push_block(hfdl_gpu_frontend *fe, const float *iq, size_t nsamples, int on_device)
@@ -986,6 +1004,7 @@ extern "C" int hfdl_gpu_frontend_sync(hfdl_gpu_frontend *fe)
 	HIP_TRY(hipSetDevice(fe->device));
 	{ int rc = flush_pending_demod(fe, false); if (rc) return rc; }
 	{ int rc = close_half(fe, true); if (rc) return rc; }           // blocks waiting for their half to fill: folded and demodulated now
+	fe->half_target = fe->half_first;                               // a drain: the pipeline starts over with a short first half
 	HIP_TRY(hipStreamSynchronize(fe->stream_c));
 	if (fe->fft_own_stream) HIP_TRY(hipStreamSynchronize(fe->stream_f));
 	HIP_TRY(hipStreamSynchronize(fe->stream));
