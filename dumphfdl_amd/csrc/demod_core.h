@@ -30,6 +30,11 @@ namespace hfdl {
 #define HFDL_DM_CHUNK 32
 #endif
 constexpr int DM_WAVES = 3, DM_THREADS = 64 * DM_WAVES, DM_CHUNK = HFDL_DM_CHUNK;      // chunk: measured, profiles/r02_experiments.md
+// The timing-recovery outputs travel from wave 1 to wave 2 through a RING of this many entries (round 6; until then a buffer of twice the
+// launch's samples: 16 of the 46 bytes of LDS a sample cost).  Wave 1 never runs more than two chunks ahead of what wave 2 has finished
+// (demod_block), a sample yields at most four outputs and wave 2 looks at 64 entries at a time: at most 2 x 32 x 4 + 64 entries are live.
+constexpr int OUTQ_RING = 512;
+static_assert((OUTQ_RING & (OUTQ_RING - 1)) == 0 && OUTQ_RING >= 2 * DM_CHUNK * 4 + 64 + 64, "ring: a power of two that holds what can be live");
 
 // ---- DPP helpers (GFX9 encodings): all row-local, a row = 16 lanes ----
 __device__ __forceinline__ float dpp_row_shr1(float old, float src)      // lane i <- src[i-1]; lane 0 of every row <- old
@@ -86,8 +91,8 @@ __device__ __forceinline__ float lane_value(float v, int lane)           // wave
 
 // what the three waves share through LDS besides the sample buffers
 struct DemodShared {
-	cf *outq;                      // symsync outputs of the block, in order
-	int outq_cap;
+	cf *outq;                      // symsync outputs of the launch, in order: output j at outq[j & (OUTQ_RING - 1)]
+	int outq_cap;                  // outputs a launch may produce at most (the 16-bit counts of cum[]); beyond it they are dropped
 	uint16_t *cum;                 // cum[k] = outputs produced up to and including input sample k
 	const float2 *sstab;           // [16 banks][64 lanes] {tap t, tap t+16} of the lane's row: rows 0,1 matched filter, rows 2,3 derivative
 	ChanScalars *S;                // the channel's scalars; every wave owns a disjoint set of fields
@@ -223,7 +228,7 @@ __device__ __forceinline__ void symsync_chunk(SymsyncRegs &r, const DemodConst &
 			do {
 				// four 18-tap dot products at once: row 0/1 = matched filter re/im, row 2/3 = derivative filter re/im
 				const float p = row_scan_sum(h.x * wl + h.y * wh);
-				if (__builtin_expect(r.j < sh.outq_cap, 1)) out_base[out_stride * r.j] = div3(p);
+				if (__builtin_expect(r.j < sh.outq_cap, 1)) out_base[out_stride * (r.j & (OUTQ_RING - 1))] = div3(p);
 				r.j++;
 				if (r.decim == 2) {
 					r.decim = 0;
@@ -347,7 +352,7 @@ __device__ __forceinline__ int carrier_chunk(CarrierRegs &c, ChanScalars &s, Cha
 	const float lv_l = (lane < n) ? io.lvl[k0 + lane] : 0.f;
 	const int cum_l = (lane < n) ? (int)sh.cum[k0 + lane] : 0x7fffffff;
 	const int jbase = k0 > 0 ? (int)sh.cum[k0 - 1] : 0;
-	const cf oq_l = (jbase + lane < sh.outq_cap) ? sh.outq[jbase + lane] : cf{0.f, 0.f};
+	const cf oq_l = (jbase + lane < sh.outq_cap) ? sh.outq[(jbase + lane) & (OUTQ_RING - 1)] : cf{0.f, 0.f};
 	{   // the chunk's outputs are taken from the 64 lanes of oq_l: a chunk that produced more (a timing loop far off its rate: up to four
 		// outputs per input sample) is cut where they end, and k1 tells the caller
 #ifndef HFDL_DM_OUT_LANES            // (a smaller value makes every chunk take the cut: how that path was tested, profiles/r03_experiments.md)
@@ -691,6 +696,9 @@ __device__ inline int demod_block(ChanArrays &a, const DemodConst &T, const Bloc
 			const unsigned long long tb = TAPS ? __builtin_amdgcn_s_memtime() : 0ull;
 			if (pp.restart) symsync_restart(ss, sh, pp.ss_ready);
 			int to = pp.ss_ready + DM_CHUNK < pp.mf_ready ? pp.ss_ready + DM_CHUNK : pp.mf_ready;
+			// never more than two chunks ahead of what wave 2 has finished: the output ring holds that much (in step, wave 2 is exactly one
+			// chunk behind and this never binds; it does when a timing loop far off its rate makes wave 2 cut its chunks short)
+			if (to > pp.s3_done + 2 * DM_CHUNK) to = pp.s3_done + 2 * DM_CHUNK;
 			if (to > pp.ss_ready) {
 				if (__builtin_expect(pp.ss_ready - (D_SS_TAPS - 1) < ss.valid_from, 0)) symsync_chunk<true>(ss, T, io, sh, pp.ss_ready, to, lane);
 				else symsync_chunk<false>(ss, T, io, sh, pp.ss_ready, to, lane);

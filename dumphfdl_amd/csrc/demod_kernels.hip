@@ -81,7 +81,7 @@ struct DemodLds {
 		agc = take(sizeof(cf) * (size_t)cap);          // agc and mfo are adjacent: together they stage the block's input
 		mfo = take(sizeof(cf) * ((size_t)cap + SS_HIST)) + sizeof(cf) * SS_HIST;     // SS_HIST history entries sit right before mf[0]
 		lvl = take(sizeof(float) * (size_t)cap);
-		outq = take(sizeof(cf) * 2 * (size_t)cap);
+		outq = take(sizeof(cf) * (size_t)OUTQ_RING);
 		cum = take(sizeof(uint16_t) * (size_t)cap);
 		rs_h = take(sizeof(float) * D_RS_NPFB * D_RS_TAPS);
 		total = o;
@@ -595,7 +595,7 @@ int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hi
 {
 	nch = nch_; outs = outs_;
 	if (resamp_rate <= 0.5f || resamp_rate > 1.0f) return HFDL_GPU_ERANGE;   // one arbitrary stage, no half-band stages
-	// blocks per launch: the per-launch sample buffers live in LDS (~46 bytes per 5400-sps sample next to ~25 KiB of tables and state)
+	// blocks per launch: the per-launch sample buffers live in LDS (30 bytes per 5400-sps sample next to ~29 KiB of tables, state and the output ring)
 	batch = batch_want < 1 ? 1 : batch_want;
 	for (;; batch--) {
 		cap = (int)((double)outs * (double)batch * (double)resamp_rate + 8);

@@ -290,18 +290,18 @@ static long env_long(const char *name, long lo, long hi, long otherwise)
 // to ONE launch, which treats them as one longer stretch of samples -- the per-channel state is carried sample by sample, so the
 // result is that of block-by-block processing.  A caller that waits for its PDUs after every block (live input: poll / sync) still
 // gets a launch per block: a partial batch is launched by any call that needs the results.  Bounds: the LDS (Demod::init keeps what
-// fits: 46 B per sample, two cfg3 blocks), and one second of signal -- less than half the shortest frame (2.34 s), so that a channel
+// fits: 30 B per sample, three cfg3 blocks), and one second of signal -- less than half the shortest frame (2.34 s), so that a channel
 // finishes at most one frame per launch (frame queue: one entry per channel; two data slots).
 static int pick_demod_batch(const hfdl_gpu_frontend *fe)
 {
 	const double block_s = (double)fe->plan.input_size / (double)fe->sample_rate;
 	int want = (int)std::floor(1.0 / block_s);
 	want = std::max(1, std::min(8, want));
-	// Where the fold bounds the block the demodulator workgroups (one per channel, ~one per CU) must stay CO-RESIDENT with the fold's:
-	// three cfg3 blocks per launch take 159 KiB of a CU's 160 KiB of LDS, no fold workgroup fits beside that, and the two kernels
-	// take turns (measured: the demodulator launch beside a 4.8 ms fold took 5.5 ms, profiles/r05_experiments.md).  Two blocks
-	// (118 KiB) leave room for the fold's 4 KiB workgroups and a forward-FFT tile.
-	if (fe->fold_bound) want = std::min(want, 2);
+	// Where the fold bounds the block the demodulator workgroups (one per channel, ~one per CU) must stay CO-RESIDENT with the fold's
+	// (34 KiB of LDS per workgroup in the thirty-two-column form) and a forward-FFT tile: three cfg3 blocks per launch take 117 KiB of a
+	// CU's 160 KiB since the timing-recovery outputs go through a ring (round 6; round 5: two blocks, 118 KiB).  One block more and the
+	// kernels take turns (measured in round 5 at 159 KiB: a demodulator launch beside a 4.8 ms fold took 5.5 ms, profiles/r05_experiments.md).
+	if (fe->fold_bound) want = std::min(want, 3);
 	return (int)env_long("HFDL_GPU_DEMOD_BATCH", 1, 8, want);       // 1 = a launch per block
 }
 
