@@ -43,6 +43,7 @@ struct Demod {
 	size_t lds_bytes = 0;
 	void *priv = nullptr;                   // DemodPriv (host image of the tables + resolved device pointers)
 
+	static int fit_batch(int outs, float resamp_rate, int want);     // blocks a launch can take at most, `want` or fewer (LDS, 16-bit output counts, < 1 s of signal)
 	int init(int nch, int outs, float resamp_rate, const int32_t *freqs, hipStream_t st, int batch_want = 1);
 	// K4 of a block.  `done` (optional) is signalled by the kernel's own dispatch packet.  frames_free: the caller has already
 	// ordered this launch after the decoder of launch i-2 (frames_free_event()), so no wait is queued in front of the kernel.
@@ -60,6 +61,9 @@ struct Demod {
 	void release();
 };
 
+#ifdef HFDL_LAB
+int demod_clock_probe_read(unsigned long long *out, int max, int *n);      // laboratory: {tag, shader cycles, 100 MHz ticks, start tick} per probed launch
+#endif
 // kernel_ms (optional): time of the kernel launch alone, HIP events on the null stream
 int demod_viterbi_batch(const uint8_t *soft, int32_t nbits, int32_t nframes, uint8_t *out, double *kernel_ms = nullptr);
 int demod_crc16(const uint8_t *data, uint32_t len, uint16_t crc_init, uint16_t *crc);

@@ -88,6 +88,22 @@ struct DemodLds {
 	}
 };
 
+#ifdef HFDL_LAB
+// Laboratory build: the shader clock a launch ran at, measured from inside it.  Workgroup 0 notes s_memtime (shader cycles) and
+// s_memrealtime (the constant 100 MHz reference) when it starts and when it ends: cycles / reference ticks x 100 MHz = the average clock
+// of THIS launch -- what rocm-smi's quarter-second samples cannot resolve (a fold launch lasts 4 - 7 ms, a demodulator launch 1 ms).
+// Ring of 4096 records {launch tag, cycles, reference ticks, 0}; hfdl_gpu_lab_clock_probe_read().
+__device__ unsigned long long hfdl_clk_probe[4096 * 4];
+__device__ unsigned hfdl_clk_probe_n;
+#define HFDL_CLK_PROBE_BEGIN(tag) unsigned long long clk_c0 = 0, clk_r0 = 0; unsigned clk_slot = 0; \
+	if (blockIdx.x == 0 && threadIdx.x == 0) { clk_slot = atomicAdd(&hfdl_clk_probe_n, 1u) & 4095u; clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#define HFDL_CLK_PROBE_END(tag) if (blockIdx.x == 0 && threadIdx.x == 0) { hfdl_clk_probe[4 * clk_slot] = (tag); hfdl_clk_probe[4 * clk_slot + 1] = __builtin_amdgcn_s_memtime() - clk_c0; \
+	hfdl_clk_probe[4 * clk_slot + 2] = __builtin_amdgcn_s_memrealtime() - clk_r0; hfdl_clk_probe[4 * clk_slot + 3] = clk_r0; }
+#else
+#define HFDL_CLK_PROBE_BEGIN(tag)
+#define HFDL_CLK_PROBE_END(tag)
+#endif
+
 // __launch_bounds__(192, 5): at most 96 VGPRs per wave.  The demodulator workgroups (three waves each, on three SIMDs of a CU) are
 // co-resident with the fold kernel's workgroups (stream A), and the two are budgeted against each other: the fold's tiling leaves a
 // SIMD at least these 96 of its 512 registers (one 384-register wave per SIMD since round 5; four waves of 104 in round 1) -- a fold
@@ -101,6 +117,7 @@ __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, Demod
 	// These workgroups are a handful of wavefronts that run serial recurrences beside thousands of throughput-bound ones (fold, forward
 	// FFT): whenever one of them has an instruction ready it goes first (the instruction arbiter otherwise treats all waves of a SIMD alike)
 	__builtin_amdgcn_s_setprio(3);
+	HFDL_CLK_PROBE_BEGIN(1)
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const int c = blockIdx.x, tid = threadIdx.x;
 	const DemodLds L(B.cap);
@@ -180,6 +197,7 @@ __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, Demod
 		src = (const uint32_t *)S;
 		for (unsigned i = tid; i < sizeof(ChanScalars) / 4; i += DM_THREADS) dst[i] = src[i];
 	}
+	HFDL_CLK_PROBE_END(1000ull + (unsigned long long)nblk)           // tag: 1000 + blocks of the launch = a demodulator launch
 }
 
 // ---------------------------------------------------------------- K5
@@ -591,19 +609,27 @@ static int set_big_lds(const void *fn, size_t bytes)
 	return 0;
 }
 
-int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hipStream_t st, int batch_want)
+// blocks a launch can take at most, `want` or fewer: what fits the LDS ...
+int Demod::fit_batch(int outs, float resamp_rate, int want)
 {
-	nch = nch_; outs = outs_;
-	if (resamp_rate <= 0.5f || resamp_rate > 1.0f) return HFDL_GPU_ERANGE;   // one arbitrary stage, no half-band stages
-	// blocks per launch: the per-launch sample buffers live in LDS (30 bytes per 5400-sps sample next to ~29 KiB of tables, state and the output ring)
-	batch = batch_want < 1 ? 1 : batch_want;
+	int batch = want < 1 ? 1 : want;
 	for (;; batch--) {
-		cap = (int)((double)outs * (double)batch * (double)resamp_rate + 8);
+		const int cap = (int)((double)outs * (double)batch * (double)resamp_rate + 8);
 		// ... and less than one second of signal per launch WHATEVER asked for the batch (cap samples at 5400 sps): a channel then finishes
 		// at most one frame per launch -- the frame queue has one entry per channel and the frame buffers two slots (hfdl_gpu.cpp
 		// pick_demod_batch states the same bound; an override or a larger LDS must not get past it)
 		if (batch == 1 || (demod_lds_bytes(cap) <= 160 * 1024 && 2 * cap <= 65535 && (double)cap / 5400.0 < 1.0)) break;      // cum[] counts outputs in 16 bits
 	}
+	return batch;
+}
+
+int Demod::init(int nch_, int outs_, float resamp_rate, const int32_t *freqs, hipStream_t st, int batch_want)
+{
+	nch = nch_; outs = outs_;
+	if (resamp_rate <= 0.5f || resamp_rate > 1.0f) return HFDL_GPU_ERANGE;   // one arbitrary stage, no half-band stages
+	// blocks per launch: the per-launch sample buffers live in LDS (30 bytes per 5400-sps sample next to ~29 KiB of tables, state and the output ring)
+	batch = fit_batch(outs, resamp_rate, batch_want);
+	cap = (int)((double)outs * (double)batch * (double)resamp_rate + 8);
 	auto *pv = new DemodPriv();
 	build_demod_tables(pv->h, resamp_rate);
 	priv = pv;
@@ -806,6 +832,29 @@ void Demod::release()
 	delete (DemodPriv *)priv;
 	priv = nullptr;
 }
+
+#ifdef HFDL_LAB
+// the clock-probe ring of this translation unit's kernels: records made since the last read, oldest first (at most `max`)
+int demod_clock_probe_read(unsigned long long *out, int max, int *n)
+{
+	unsigned cnt = 0;
+	D_TRY(hipDeviceSynchronize());
+	D_TRY(hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(hfdl_clk_probe_n), sizeof(cnt)));
+	std::vector<unsigned long long> all(4096 * 4);
+	D_TRY(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(hfdl_clk_probe), sizeof(unsigned long long) * all.size()));
+	const unsigned have = cnt < 4096u ? cnt : 4096u;
+	int k = 0;
+	for (unsigned i = 0; i < have && k < max; i++) {
+		const unsigned slot = (cnt - have + i) & 4095u;
+		for (int j = 0; j < 4; j++) out[4 * k + j] = all[4 * slot + j];
+		k++;
+	}
+	*n = k;
+	cnt = 0;
+	D_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hfdl_clk_probe_n), &cnt, sizeof(cnt)));
+	return 0;
+}
+#endif
 
 // the DemodTables image resident on the device and the device's own evaluation of hfdl_constants()
 int Demod::read_constants(void *tables, size_t tables_bytes, void *constants, size_t constants_bytes)

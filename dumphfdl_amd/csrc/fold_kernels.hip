@@ -76,6 +76,13 @@ __device__ __forceinline__ float rot90(float a, int sign_mask)
 	return __int_as_float(v ^ sign_mask);
 }
 
+#ifdef HFDL_LAB
+// Laboratory build: the shader clock a fold launch ran at, from inside it (demod_kernels.hip has the demodulator's twin).  The workgroup
+// in the middle of the grid notes s_memtime and s_memrealtime (100 MHz) around its whole life (1/16 of the launch): cycles / ticks x 100 MHz.
+__device__ unsigned long long hfdl_fold_clk_probe[1024 * 4];
+__device__ unsigned hfdl_fold_clk_probe_n;
+#endif
+
 // registers the tile asks for -> waves per SIMD told to the compiler (512 per lane and SIMD): left to itself it aims at 8 waves,
 // squeezes the loop into 64 registers and gets there by loading, waiting, multiplying, loading again
 constexpr int fold16_waves(int p, int w, int d, bool small = false, int cg = 1)
@@ -130,6 +137,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 	// pipe, set the pace.  EVERY wave fetches MINE instructions' worth -- with more than eight waves the upper ones would fetch (and
 	// store) what the lower ones do -- so that all waves issue the same loads and no branch sits in the loop: behind a branch the
 	// compiler's s_waitcnt count assumes the path with the most loads, and the waves on the other path wait for all but one quad
+#ifdef HFDL_LAB
+	unsigned long long clk_c0 = 0, clk_r0 = 0;
+	const bool clk_me = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+	if (clk_me) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
 	constexpr int NLOADS = 8 * CG;                            // load instructions per quad's tile: 64 (CG = 2: 128) segments of eight 16-byte items
 	constexpr int MINE = W >= NLOADS ? 1 : NLOADS / W;
 	constexpr int XPITCH = 64 * CG + 4;                       // v4f per bin pair: the segments + 4, so that the eight parts of a segment do not share banks
@@ -323,6 +335,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 				}
 		}
 	}
+#ifdef HFDL_LAB
+	if (clk_me) {
+		const unsigned slot = atomicAdd(&hfdl_fold_clk_probe_n, 1u) & 1023u;
+		hfdl_fold_clk_probe[4 * slot] = (SMALL ? 4ull : 16ull * CG) * 100ull + (unsigned long long)nb;      // tag: columns x 100 + blocks
+		hfdl_fold_clk_probe[4 * slot + 1] = __builtin_amdgcn_s_memtime() - clk_c0;
+		hfdl_fold_clk_probe[4 * slot + 2] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+		hfdl_fold_clk_probe[4 * slot + 3] = clk_r0;
+	}
+#endif
 }
 
 #ifdef HFDL_LAB
@@ -343,6 +364,25 @@ __global__ __launch_bounds__(FOLD_THREADS) void stream_read_kernel(const float4 
 		for (int i = 0; i < L; i++) acc += v[i].x + v[i].w;
 	}
 	if (acc == 1.2345e33f) *sink = acc;
+}
+
+int fold_clock_probe_read(unsigned long long *out, int max, int *n)
+{
+	unsigned cnt = 0;
+	if (hipDeviceSynchronize() != hipSuccess) return -1;
+	if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(hfdl_fold_clk_probe_n), sizeof(cnt)) != hipSuccess) return -1;
+	unsigned long long all[1024 * 4];
+	if (hipMemcpyFromSymbol(all, HIP_SYMBOL(hfdl_fold_clk_probe), sizeof(all)) != hipSuccess) return -1;
+	const unsigned have = cnt < 1024u ? cnt : 1024u;
+	int k = 0;
+	for (unsigned i = 0; i < have && k < max; i++) {
+		const unsigned slot = (cnt - have + i) & 1023u;
+		for (int j = 0; j < 4; j++) out[4 * k + j] = all[4 * slot + j];
+		k++;
+	}
+	*n = k;
+	cnt = 0;
+	return hipMemcpyToSymbol(HIP_SYMBOL(hfdl_fold_clk_probe_n), &cnt, sizeof(cnt)) == hipSuccess ? 0 : -1;
 }
 
 int stream_read_variants() { return 4; }

@@ -569,9 +569,16 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	if (fe->prune_tol > 0 && g.tap_layout == TAPL_OCTET && (rc = build_fold_windows(fe))) { frontend_free(fe); return rc; }
 	FE_TRY(hipMemcpy(fe->d_cc, fe->cc.data(), sizeof(ChanConst) * (size_t)nch, hipMemcpyHostToDevice));
 	float resamp_rate = (float)(1800 * 3) / ((float)sample_rate / (float)fe->decimation);
-	if ((rc = fe->demod.init(nch, g.outs, resamp_rate, fe->freqs.data(), fe->stream, pick_demod_batch(fe)))) { frontend_free(fe); return rc; }
-	fe->batch = fe->demod.batch;        // what fits the demodulator's LDS
 	fe->fold_nb = pick_fold_batch(fe);
+	int want_batch = Demod::fit_batch(g.outs, resamp_rate, pick_demod_batch(fe));       // what fits the demodulator's LDS
+	if (!getenv("HFDL_GPU_DEMOD_BATCH") && want_batch < fe->fold_nb) {
+		// even launches: a half of 8 blocks at up to 7 per launch is two launches of 4, not 7 + 1 (cfg2: 5.5 against 5.8 Gsamples/s); an
+		// explicit HFDL_GPU_DEMOD_BATCH is taken as it is
+		const int launches = (fe->fold_nb + want_batch - 1) / want_batch;
+		want_batch = (fe->fold_nb + launches - 1) / launches;
+	}
+	if ((rc = fe->demod.init(nch, g.outs, resamp_rate, fe->freqs.data(), fe->stream, want_batch))) { frontend_free(fe); return rc; }
+	fe->batch = fe->demod.batch;
 	fe->half_blocks = std::min((int)hfdl_gpu_frontend::MAX_HALF, ((std::max(fe->fold_nb, fe->batch) + fe->fold_nb - 1) / fe->fold_nb) * fe->fold_nb);
 	fe->half_first = (fe->fold_bound && fe->half_blocks > 16) ? 16 : fe->half_blocks;
 #ifdef HFDL_LAB
@@ -1474,6 +1481,16 @@ extern "C" int hfdl_gpu_lab_read_constants(hfdl_gpu_frontend *fe, void *tables, 
 	if (rc) return rc;
 	rc = fe->demod.read_constants(tables, tables_bytes, constants, constants_bytes);
 	if (rc) return fail(rc, "constants read-back failed (sizes %zu / %zu): %s", tables_bytes, constants_bytes, hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
+extern "C" int hfdl_gpu_lab_clock_probe_read(int which, uint64_t *records, int32_t max, int32_t *n)
+{
+	if (!records || !n || max < 1) return fail(HFDL_GPU_EINVAL, "bad arguments");
+	int k = 0;
+	const int rc = which == 0 ? fold_clock_probe_read((unsigned long long *)records, max, &k) : demod_clock_probe_read((unsigned long long *)records, max, &k);
+	if (rc) return fail(HFDL_GPU_EHIP, "clock probe read failed: %s", hipGetErrorString(hipGetLastError()));
+	*n = k;
 	return 0;
 }
 

@@ -130,6 +130,7 @@ void launch_ifft_nco(const Geometry &g, const float2 *partial, size_t partial_st
 void launch_nco_decimate(const float2 *in, int input_size, float cosdelta, float sindelta, float rate, int decimation,
 		NcoState *state, float2 *phasor_scratch, float2 *out, hipStream_t st);
 #ifdef HFDL_LAB
+int fold_clock_probe_read(unsigned long long *out, int max, int *n);      // {columns x 100 + blocks, shader cycles, 100 MHz ticks, start tick} per fold launch
 int stream_read_variants();
 void launch_stream_read(int variant, const float2 *src, size_t bytes, float *sink, hipStream_t st);
 #endif

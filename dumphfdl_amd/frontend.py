@@ -79,7 +79,7 @@ FOLD_BATCH_MAX = 32        # HFDL_GPU_FOLD_BATCH_MAX of include/hfdl_gpu.h
 
 # what include/hfdl_gpu_lab.h adds in the laboratory build (libhfdl_gpu_lab.so)
 LAB_EXPORTS = ["hfdl_gpu_lab_fold_variant_count", "hfdl_gpu_lab_fold_variant_describe", "hfdl_gpu_lab_fold_variant_probe", "hfdl_gpu_lab_stream_read_probe",
-               "hfdl_gpu_lab_read_constants"]
+               "hfdl_gpu_lab_read_constants", "hfdl_gpu_lab_clock_probe_read"]
 
 
 def fold_variants():
@@ -125,6 +125,7 @@ def load_lab():
     L.hfdl_gpu_lab_fold_variant_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.hfdl_gpu_lab_stream_read_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.hfdl_gpu_lab_read_constants.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.hfdl_gpu_lab_clock_probe_read.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     _lab = L
     return L
 

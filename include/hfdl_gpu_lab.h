@@ -30,6 +30,11 @@ int  hfdl_gpu_lab_fold_variant_probe(hfdl_gpu_frontend *fe, int variant, int nb,
  * compared with the reference's own text, tests/golden/hfdl_constants.json.  The byte counts must equal the structs' sizes
  * (tests/hostsim reports them). */
 int  hfdl_gpu_lab_read_constants(hfdl_gpu_frontend *fe, void *tables, size_t tables_bytes, void *constants, size_t constants_bytes);
+/* The shader clock the probed launches ran at, measured from inside them (s_memtime against the constant 100 MHz s_memrealtime): records of
+ * four 64-bit words {tag, shader cycles, reference ticks, reference tick at the start}, oldest first, made since the last read.
+ * which = 0: fold launches (tag = columns x 100 + blocks; the workgroup in the middle of the grid), 1: demodulator launches (tag = 1000 +
+ * blocks of the launch; workgroup 0, the whole launch).  At most 1024 / 4096 records are kept. */
+int  hfdl_gpu_lab_clock_probe_read(int which, uint64_t *records, int32_t max, int32_t *n);
 /* what the board's HBM delivers to a read-only streaming kernel with the fold's access pattern (reads the resident taps) */
 int  hfdl_gpu_lab_stream_read_probe(hfdl_gpu_frontend *fe, double *gb_per_s);
 
