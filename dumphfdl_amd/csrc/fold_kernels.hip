@@ -123,7 +123,7 @@ constexpr int fold16_waves(int p, int w, int d, bool small = false, int cg = 1)
 // taps.  With CG = 2 a loaded (and rotated) tap operand multiplies TWO spectrum operands, blocks 0 .. 15 and 16 .. 31: twice the matrix
 // instructions per KiB of taps and per vector instruction, the same chain of FMAs per (block, channel, bin).
 template <int P, int W, int D, bool WIN = false, bool SMALL = false, int CG = 1>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_waves(P, W, D, SMALL, CG), fold16_waves(P, W, D, SMALL, CG)))) void fold_mfma16_kernel(
+__device__ __forceinline__ void fold_mfma16_body(
 		const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
 		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int octet_base, int nch, int nb,
 		const int2 *__restrict__ win)
@@ -144,7 +144,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 #endif
 	constexpr int NLOADS = 8 * CG;                            // load instructions per quad's tile: 64 (CG = 2: 128) segments of eight 16-byte items
 	constexpr int MINE = W >= NLOADS ? 1 : NLOADS / W;
-	constexpr int XPITCH = 64 * CG + 4;                       // v4f per bin pair: the segments + 4, so that the eight parts of a segment do not share banks
+	// v4f per bin pair: the segments + 1.  A stash instruction writes, per group of eight lanes, the eight 16-byte parts of ONE segment,
+	// a pitch apart; LDS WRITES bank on a 32-dword modulus (MI355X_MICROARCH.md, LDS table), so the pitch in dwords must be 4 mod 32 for
+	// the eight parts to fall on eight different bank quads.  (Rounds 5 - 6a had + 4 -- 16 mod 32: parts p and p + 2 on one bank, the
+	// four-way conflict behind round 5's unexplained 1.0e8 SQ_LDS_BANK_CONFLICT cycles per launch; + 1: fold -1 .. 2 % alone, -2 % in
+	// the pipeline, same bits, profiles/r06_experiments.md.)  The reads take 64 consecutive entries of a row: any pitch serves them.
+	constexpr int XPITCH = 64 * CG + 1;
 	__shared__ v4f xt[2][8][XPITCH];                          // [stage][bin pair][64 cg + segment n + 16 k] = (Re, Im) of bins 2 b, 2 b + 1 of block 16 cg + n, row k
 	const int ngrp = m >> 4;
 	// blockIdx -> (tile = bin group x slice, channel group).  The workgroups that share a spectrum tile must sit on ONE XCD (the
@@ -346,6 +351,28 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_w
 #endif
 }
 
+template <int P, int W, int D, bool WIN = false, bool SMALL = false, int CG = 1>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(fold16_waves(P, W, D, SMALL, CG), fold16_waves(P, W, D, SMALL, CG)))) void fold_mfma16_kernel(
+		const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
+		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int octet_base, int nch, int nb,
+		const int2 *__restrict__ win)
+{
+	fold_mfma16_body<P, W, D, WIN, SMALL, CG>(taps, spec, partial, row_stride_f, spec_stride, partial_stride, m, slices, rows, octet_base, nch, nb, win);
+}
+
+#ifdef HFDL_LAB
+// Laboratory: the thirty-two-column (1, 8, 2) tiling held to 208 registers, so that TWO of its waves and a demodulator wave (80) share a
+// SIMD's 512.  The attribute wants a literal, hence a kernel of its own around the same body; it counts each half of the unified file
+// (104 + 104); the compiler keeps the loop free of scratch at that (one 8-byte spill before the loop, reloaded after it).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) __attribute__((amdgpu_num_vgpr(104))) void fold32_two_waves_kernel(
+		const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
+		size_t row_stride_f, size_t spec_stride, size_t partial_stride, int m, int slices, int rows, int octet_base, int nch, int nb,
+		const int2 *__restrict__ win)
+{
+	fold_mfma16_body<1, 8, 2, false, false, 2>(taps, spec, partial, row_stride_f, spec_stride, partial_stride, m, slices, rows, octet_base, nch, nb, win);
+}
+#endif
+
 #ifdef HFDL_LAB
 // ---- what the memory system gives a kernel that only reads (bench.py's stream-read probe, profiles/fold_traffic.py's calibration) ----
 template <int L, bool SPAN>
@@ -432,6 +459,26 @@ static int fold16_go(const FoldArgs &a)
 	return launches;
 }
 
+#ifdef HFDL_LAB
+static int fold32_two_waves_go(const FoldArgs &a)
+{
+	const int ntile = (a.m >> 4) * a.slices;
+	const int groups = a.ngroups / 8, rest = a.ngroups - groups * 8;
+	int launches = 0;
+	if (groups > 0) {
+		hipExtLaunchKernelGGL(fold32_two_waves_kernel, dim3((unsigned)(groups * ntile)), dim3(512), 0, a.st, a.start, rest ? nullptr : a.stop, 0,
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, 0, a.nch, a.nb, (const int2 *)nullptr);
+		launches++;
+	}
+	if (rest > 0) {
+		hipExtLaunchKernelGGL((fold_mfma16_kernel<1, 1, 2, false, false, 2>), dim3((unsigned)(rest * ntile)), dim3(64), 0, a.st, groups > 0 ? nullptr : a.start, a.stop, 0,
+			a.taps, a.spec, a.partial, a.rs_f, a.ss, a.ps, a.m, a.slices, a.rows, groups * 8, a.nch, a.nb, (const int2 *)nullptr);
+		launches++;
+	}
+	return launches;
+}
+#endif
+
 // the pruned fold: a single-wave workgroup per octet and group of 16 bins, each octet with its own window of quads; one slice
 template <int D>
 static int fold16_go_win(const FoldArgs &a, const int2 *win)
@@ -460,6 +507,7 @@ static const FoldVariant fold_variants[] = {
 	F32(1, 8, 2), F32(1, 8, 4), F32(1, 2, 2), F32(2, 4, 2),
 	F4(2, 4, 4), F4(4, 4, 2), F4(1, 8, 4), F4(2, 8, 2), F4(2, 8, 4), F4(4, 2, 2), F4(1, 4, 4),
 	F16(1, 4, 2), F16(1, 4, 4), F16(1, 8, 2), F16(1, 8, 4), F16(2, 2, 2), F16(2, 8, 2), F16(1, 2, 2), F16(1, 2, 4), F16(3, 4, 2),
+	{ TAPL_OCTET, 1, 8, 8, 2, fold32_two_waves_go },          // index 25: F32(1, 8, 2) held to 208 registers -- two waves per SIMD beside a demodulator wave
 #endif
 };
 #undef F32

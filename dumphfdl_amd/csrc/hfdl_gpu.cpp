@@ -264,11 +264,15 @@ extern "C" void hfdl_gpu_frontend_destroy(hfdl_gpu_frontend *fe) { frontend_free
 
 static int pick_slices(int nch, int rows)
 {
-	// nch * slices workgroups (a channel pair x a slice x half the columns each): 1024 = the 4 that fit a CU x 256 CUs, all
-	// resident at once (measured best: profiles/r01_experiments.md); keep >= 8 alias rows per slice so the partial-sum
-	// traffic stays small against the taps
+	// Slices of alias rows per (channel group, bin group): each slice is a workgroup of its own and leaves a partial sum that the inverse
+	// FFT adds up.  A CU holds ONE matrix-pipe fold workgroup at a time (one 384 / 420-register wave per SIMD), so every workgroup
+	// generation pays its dispatch, its first loads and its stores with an idle matrix pipe: as few and as long-lived workgroups as fill
+	// the chip.  256 channels need no slicing (cfg3: 2048 workgroups of 512 quads at one slice; against round 1's rule of
+	// channels x slices >= 1024 -- four slices -- the 32-block fold takes 5.7 instead of 6.8 ms alone, 0.203 instead of 0.22 ms per block
+	// in the pipeline, and a quarter of the partial sums are written and read back: profiles/r06_experiments.md); fewer channels are
+	// sliced until channels x slices >= 256, a slice keeping at least 8 alias rows.
 	int s = 1;
-	while (s * 2 <= rows / 8 && nch * s < 1024) s *= 2;
+	while (s * 2 <= rows / 8 && nch * s < 256) s *= 2;
 	return s;
 }
 
@@ -493,6 +497,10 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 	// rows around each channel's pass band (build_fold_windows) -- one slice, the windows are the parallelism
 #ifdef HFDL_LAB
 	g.fold_tile = (int32_t)env_long("HFDL_GPU_FOLD_TILE", 0, 63, -1);
+	{	// laboratory A/B: slices of alias rows per channel and bin (1, 2, 4 ...; a slice keeps at least 16 rows)
+		const int sl = (int)env_long("HFDL_GPU_FOLD_SLICES", 1, 64, 0);
+		if (sl > 0 && (sl & (sl - 1)) == 0 && pl.pre % sl == 0 && pl.pre / sl >= 16) g.slices = sl;
+	}
 #endif
 	fe->prune_tol = g.tap_layout == TAPL_OCTET ? env_double("HFDL_GPU_FOLD_PRUNE", 1e-12, 1e-3, 0.0) : 0.0;
 	if (fe->prune_tol > 0) g.slices = 1;
@@ -502,10 +510,27 @@ extern "C" int hfdl_gpu_frontend_create(hfdl_gpu_frontend **out, int device, int
 #define FE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
 	int rc_ = fail(e_ == hipErrorOutOfMemory ? HFDL_GPU_ENOMEM : HFDL_GPU_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
 	frontend_free(fe); return rc_; } } while (0)
+#ifdef HFDL_LAB
+	// Laboratory A/B (HFDL_GPU_CU_SPLIT=k, k = 2 / 4 / 8): the demodulator's stream on every k-th CU, the channelizer's stream on the others --
+	// does a demodulator launch still execute twice the cycles while a fold runs, when no fold wave shares its SIMD?  CU i belongs to the
+	// demodulator iff ((i >> 3) + i) % k == 0: an equal share of every XCD whether the mask counts XCD-major or XCD-interleaved.
+	const int cu_split = (int)env_long("HFDL_GPU_CU_SPLIT", 2, 8, 0);
+	uint32_t mask_a[8] = {}, mask_b[8] = {};
+	for (int i = 0; i < 256; i++) {
+		const bool demod_cu = cu_split && (((i >> 3) + i) % cu_split) == 0;
+		(demod_cu ? mask_b : mask_a)[i >> 5] |= 1u << (i & 31);
+	}
+	if (cu_split) FE_TRY(hipExtStreamCreateWithCUMask(&fe->stream, 8, mask_a));
+	else
+#endif
 	FE_TRY(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
 	{
 		// measured on MI355X: stream priority (hi/lo) and CU-masking of this stream change nothing beyond run-to-run
 		// noise (profiles/r01_experiments.md), so a plain non-blocking stream is used
+#ifdef HFDL_LAB
+		if (cu_split) FE_TRY(hipExtStreamCreateWithCUMask(&fe->stream_b, 8, mask_b));
+		else
+#endif
 		FE_TRY(hipStreamCreateWithFlags(&fe->stream_b, hipStreamNonBlocking));
 	}
 	FE_TRY(hipStreamCreateWithFlags(&fe->stream_c, hipStreamNonBlocking));

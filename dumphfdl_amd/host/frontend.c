@@ -274,7 +274,7 @@ static int release_copied(hfdl_gpu_frontend *fe, struct circ_buffer *ring, size_
  *
  * Live source or replay?  The pipeline is drained (everything pushed so far folded, demodulated and delivered at once) only when
  * the ring has run EMPTY and the source has stayed silent for a grace period of a quarter of a block's own duration (at most
- * 20 ms): a live radio delivers a block every block duration and gets its PDUs within that grace; a file reader that hiccups for
+ * 20 ms), counted from the arrival of the newest block: a live radio delivers a block every block duration and gets its PDUs within that grace; a file reader that hiccups for
  * a millisecond beside a GPU about as fast as itself never drains a filled pipeline (round 4's fixed 0.5 ms grace did, five times
  * in a run, for 19 % of the rate). */
 static void *frontend_thread(void *ctx)
@@ -330,6 +330,8 @@ static void *frontend_thread(void *ctx)
 	const void *queued[HFDL_GPU_PREFETCH_MAX + 1];      /* uploads not pushed yet, oldest at q_head */
 	size_t q_head = 0, q_len = 0;
 	uint64_t undelivered = 0;                /* blocks pushed since the pipeline was last drained */
+	struct timespec last_push;               /* when the newest block was taken from the ring and pushed (CLOCK_REALTIME: pthread_cond_timedwait's clock) */
+	clock_gettime(CLOCK_REALTIME, &last_push);
 	for (;;) {
 		const double tw0 = now_s();
 		const void *blk = NULL;
@@ -357,8 +359,9 @@ static void *frontend_thread(void *ctx)
 				}
 				if (ok && undelivered > 0 && !waited_grace) {
 					/* the ring is empty: a live source, or a reader catching its breath?  Wait the grace period, then deliver */
-					struct timespec until;
-					clock_gettime(CLOCK_REALTIME, &until);
+					/* the grace period counts from the moment the newest block was PUSHED, not from here (the wait for its upload
+					 * lies in between): a live block's PDUs leave grace after its arrival, whatever the copy took */
+					struct timespec until = last_push;
 					until.tv_nsec += (long)(grace * 1e9);
 					while (until.tv_nsec >= 1000000000) { until.tv_sec++; until.tv_nsec -= 1000000000; }
 					const double tg = now_s();
@@ -408,6 +411,7 @@ static void *frontend_thread(void *ctx)
 			if (!ok) { pthread_cond_signal(ring->cond); continue; }
 		}
 		const double tw1 = now_s();
+		clock_gettime(CLOCK_REALTIME, &last_push);
 		if (k == 0) t_first = tw1; else s_wait += tw1 - tw0;
 		if (hfdl_gpu_frontend_push_block_raw(fe, blk, need, from_bounce ? HFDL_GPU_SFMT_CF32 : gfmt, 0) != 0) {
 			fprintf(stderr, "GPU front end: %s\n", hfdl_gpu_last_error());

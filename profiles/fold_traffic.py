@@ -50,6 +50,18 @@ for ctr, rows in per_dispatch.items():
     if len(rows) != len(launch_nbs):
         sys.exit("fold_traffic.py: %s pass saw %d fold dispatches, the command makes %d launches (%s): one dispatch per launch expected "
                  "(channel counts that leave no partial workgroup)" % (ctr, len(rows), len(launch_nbs), shapes_arg))
+# the kernel's template arguments name the FORM of a launch (<P, W, D, WIN, SMALL, CG>: SMALL = the four-column form, CG = 2 the
+# thirty-two-column one): the forms of the dispatches must be those the assumed launch order implies
+for ctr, rows in per_dispatch.items():
+    for (start, kname, val), nb in zip(rows, launch_nbs):
+        m = re.search(r"fold_mfma16_kernel<\d+, \d+, \d+, (?:false|true|0|1), (false|true|0|1), (\d+)>", kname)
+        if not m:
+            continue
+        small, cg = m.group(1) in ("true", "1"), int(m.group(2))
+        want = ("4" if nb <= 4 else "32" if nb > 16 else "16")
+        have = ("4" if small else "32" if cg == 2 else "16")
+        if want != have:
+            sys.exit("fold_traffic.py: %s pass: a launch assumed to hold %d blocks ran the %s-column form (%s): the launch order %s is not the command's" % (ctr, nb, have, kname, shapes_arg))
 probe_bytes = min(w["nch"] * 8 * g.fft_size // (4 << 20) * (4 << 20), 16 << 30)
 corr = probe_bytes / (1024.0 * (sum(probe) / len(probe))) if probe else 2.0
 
@@ -83,7 +95,7 @@ out.update({
     "workload": "%s: %s" % (wl, w["name"]),
     "measured_at_commit": commit,
     "csrc_sha16": csrc_now,
-    "command": "profiles/pmc_passes.sh %s (rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --workload %s --steps 36 --warmup 8 "
+    "command": "profiles/pmc_passes.sh %s (rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --workload %s --steps 68 --warmup 8 "
                "--no-cpu-baseline --no-extra-legs: fold launches of %s blocks in that order; second pass --pmc WRITE_SIZE; third --pmc TCC_HIT_sum TCC_MISS_sum)" % (wl, wl, shapes_arg),
     "gfx950_fetch_correction": round(corr, 4),
     "correction_calibration": "same run: stream_read_kernel reads exactly %d bytes and reports FETCH_SIZE = %.1f KB (x %.3f); "

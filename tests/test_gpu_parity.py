@@ -1205,16 +1205,34 @@ def test_host_c_program_live_pipe(gpu, oracle):
                             + ["%.3f" % (f / 1e3) for f in freqs], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     raw = x.view(np.float32).tobytes()
     step = 8 * 28672                                    # one block of this geometry
+    import threading
+    arrivals, lines = [], []
+
+    def reader():                                       # every PDU line with the wall time it came out at (the sink flushes per PDU)
+        for ln in proc.stdout:
+            arrivals.append(time.monotonic())
+            lines.append(ln.decode())
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
     time.sleep(3.0)                                     # let the front end come up (filter design, 3 channels) before pacing matters
+    written = []
     for off in range(0, len(raw), step):
         proc.stdin.write(raw[off:off + step])
         proc.stdin.flush()
+        written.append(time.monotonic())
         time.sleep(0.03)
     time.sleep(2.2)                                     # source idle, program still running: the 1 s gauge thread reports the settled values
+    t_closed = time.monotonic()
     proc.stdin.close()
-    out = proc.stdout.read().decode()
     err = proc.stderr.read().decode()
     assert proc.wait(timeout=120) == 0, err
+    th.join(timeout=30)
+    out = "".join(lines)
+    # latency of a paced source: PDUs leave while the source is still feeding -- a block's PDUs are delivered a grace period
+    # (a quarter of a block, 29 ms here, counted from the block's arrival) after it, not when the program shuts down
+    pdu_t = [t for t, ln in zip(arrivals, lines) if ln.startswith("PDU ")]
+    assert pdu_t and max(pdu_t) < written[-1] + 0.5 < t_closed, (max(pdu_t) - written[-1], t_closed - written[-1])
+    assert min(pdu_t) < written[len(written) // 2], "no PDU before half of the samples were fed"
     got = []
     for line in out.splitlines():
         if line.startswith("PDU "):
