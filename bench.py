@@ -859,6 +859,17 @@ def main():
     # ---- extra legs (untimed with respect to `value`; rank 0 at N = 1)
     extra = {}
     solo = world == 1 and rank == 0
+    if solo:
+        # a live receiver's latency: ONE block pushed into an idle pipeline until its PDUs are on the host (forward FFT, a one-block
+        # fold in the four-column form, inverse FFT, demodulator, burst decoder, collection): the median of five
+        lat = []
+        for i in range(5):
+            t0 = time.perf_counter()
+            push((step + i) % nblocks)
+            fe.poll_pdus_raw(16384)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        extra["block_to_pdus_latency_ms"] = sorted(lat)[2]
+        fe.reset_timers(False)
     if solo and not args.no_extra_legs and not args.host_input:
         hbuf, extra["host_ram_input"] = host_ram_leg(torch, hf, F, fe, x, g, nblocks, args.steps)
     if solo and not args.no_extra_legs:

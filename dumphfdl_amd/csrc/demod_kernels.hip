@@ -104,12 +104,12 @@ __device__ unsigned hfdl_clk_probe_n;
 #define HFDL_CLK_PROBE_END(tag)
 #endif
 
-// __launch_bounds__(192, 5): at most 96 VGPRs per wave.  The demodulator workgroups (three waves each, on three SIMDs of a CU) are
-// co-resident with the fold kernel's workgroups (stream A), and the two are budgeted against each other: the fold's tiling leaves a
-// SIMD at least these 96 of its 512 registers (one 384-register wave per SIMD since round 5; four waves of 104 in round 1) -- a fold
-// tiling that does not (two waves of 252) makes the two kernels take turns and costs the pipeline 10 % (fold_kernels.hip,
-// profiles/r05/k4_tilings_in_pipeline.txt).  Staying inside the budget also keeps the loops free of scratch spills: scratch is
-// memory, and beside a kernel that reads HBM at 4.6 TB/s every spill reload is a multi-microsecond stall.
+// __launch_bounds__(192, 5): at most 96 VGPRs per wave (the code object says 73 used, 80 allocated).  The demodulator workgroups (three
+// waves each, on three SIMDs of a CU) are co-resident with the fold kernel's workgroups (stream A), and the two are budgeted against each
+// other: the fold's tiling leaves a SIMD at least these registers of its 512 (one 372 / 420-register wave per SIMD since round 5; four waves
+// of 104 in round 1) -- a fold tiling that does not (two waves of 256) makes the two kernels take turns and costs the pipeline 10 %
+// (fold_kernels.hip, profiles/r05/k4_tilings_in_pipeline.txt).  Staying inside the budget also keeps the loops free of scratch spills:
+// scratch is memory, and beside a kernel that reads HBM at 4.6 TB/s every spill reload is a multi-microsecond stall.
 template <bool TAPS>
 __global__ __launch_bounds__(DM_THREADS, 5) void demod_kernel(DevTables T, DemodBuffers B, const cf *__restrict__ chan_out,
 		const int *__restrict__ n_in, int outs_stride, int nblk, int nch)

@@ -97,9 +97,12 @@ constexpr int fold16_waves(int p, int w, int d, bool small = false, int cg = 1)
 }
 
 // THE fold: v_mfma_f32_16x16x4_f32 on TAPL_OCTET taps.  One instruction = one bin x (8 channels' Re / Im rows) x FOUR alias rows x 16
-// blocks: 1024 multiply-accumulates with a quarter of the accumulator traffic of the one-row form (16x16x1_4B) of the first builds --
-// the board runs the fold at the clock its power budget leaves, and the register file was most of that power
+// blocks: 1024 multiply-accumulates with a quarter of the accumulator traffic of the one-row form (16x16x1_4B) of the first builds
 // (profiles/r05_experiments.md: the same loop with this instruction in the place of the other ran 22 % faster before it was right).
+// The fp32 matrix instruction runs at the vector ALUs' own rate (64 FLOP per clock and SIMD) and holds the SIMD's vector issue while it
+// executes: a neighbour wave on the SIMD -- the demodulator's -- gets one instruction in per matrix instruction (measured with a
+// synthetic neighbour, profiles/r06/neighbour_probe_cfg3.md: the demodulator takes 3.4 - 4.3 x its cycles beside back-to-back matrix
+// instructions, 1.0 x beside LDS or HBM traffic alone).
 // P channel OCTETS per wave, W waves per workgroup, D groups of four alias rows ("quads") of loads in flight.  A workgroup = one group
 // of 16 bins x one slice of alias rows x 8 P W channels; its W waves cover the SAME bins and different channels, so each quad's spectrum
 // tile (16 blocks x 4 rows x 16 bins = 8 KiB) is fetched ONCE per workgroup -- every wave a share of it, in whole 128-byte segments --
@@ -117,11 +120,13 @@ constexpr int fold16_waves(int p, int w, int d, bool small = false, int cg = 1)
 // 16-lane groups and the four bins in the four registers: two v_permlane32_swap + two v_permlane16_swap per KiB transpose groups
 // against registers, after which register k = alias row k and the lane group = the bin.  Then k = 0 .. 3 with Re(X), k = 0 .. 3 with
 // Im(X), one instruction each, on the same accumulator: the chain of the sixteen-column form, the same bits.
-// CG (round 6: launches of 17 .. 32 blocks): column groups of sixteen blocks per pass over the taps.  The fold launch sits on the board's
-// POWER budget, not on a pipe: its time is the matrix time PLUS the memory time at the clock the two leave each other (4-column form:
-// 0.5 + 2.2 ms, 16 columns: 1.9 + 2.2 ms, profiles/r06_experiments.md) -- so what shortens a block's share is more blocks per byte of
-// taps.  With CG = 2 a loaded (and rotated) tap operand multiplies TWO spectrum operands, blocks 0 .. 15 and 16 .. 31: twice the matrix
-// instructions per KiB of taps and per vector instruction, the same chain of FMAs per (block, channel, bin).
+// CG (round 6: launches of 17 .. 32 blocks): column groups of sixteen blocks per pass over the taps.  A launch costs about its matrix
+// time PLUS its memory time, not the larger of the two (alone: four columns 2.8 ms, sixteen 3.9, thirty-two 5.7 .. 6.3 for the same
+// 16 GiB of taps): one wave per SIMD issues a matrix instruction every 40 cycles at best (32 of execution + 8 of issue,
+// profiles/micro/neighbour.hip) and every wait at a quad's barrier for the slowest wave's taps is idle pipe -- so what shortens a
+// block's share is more blocks per byte of taps.  With CG = 2 a loaded (and rotated) tap operand multiplies TWO spectrum operands,
+// blocks 0 .. 15 and 16 .. 31: twice the matrix instructions per KiB of taps and per vector instruction, the same chain of FMAs per
+// (block, channel, bin).
 template <int P, int W, int D, bool WIN = false, bool SMALL = false, int CG = 1>
 __device__ __forceinline__ void fold_mfma16_body(
 		const float *__restrict__ taps, const float2 *__restrict__ spec, float2 *__restrict__ partial,
@@ -495,11 +500,14 @@ struct FoldVariant { int layout, p, q, w, d; int (*go)(const FoldArgs &); };
 #define F4(P, W, D) { TAPL_OCTET, P, 1, W, D, fold16_go<P, W, D, true> }        // the four-column form: at most four blocks
 #define F32(P, W, D) { TAPL_OCTET, P, 8, W, D, fold16_go<P, W, D, false, 2> }   // two column groups: 17 .. 32 blocks
 // The first entry whose look-ahead D divides the slice's quads is the one used.
-// Measured on cfg3 (M = 4096, 512 rows per slice) with profiles/fold_variants.py: profiles/r05/fold_variants_cfg3_k4.md.
+// Measured on cfg3 (M = 4096) with profiles/fold_variants.py: profiles/r05/fold_variants_cfg3_k4.md (512 rows per slice),
+// profiles/r06/run10_fold_variants_slices1.md (one slice of 2048 rows, the default since round 6).
 static const FoldVariant fold_variants[] = {
-	// (2, 4, 4): 384 registers -- ONE wave per SIMD, four quads of taps in flight -- and 128 left on the SIMD: the demodulator's waves
-	// (96) fit beside it.  (2, 4, 2) at 252 registers runs two waves per SIMD, is faster alone and leaves no room: the demodulator takes
-	// turns with it and the pipeline loses 10 % (profiles/r05/k4_tilings_in_pipeline.txt)
+	// (2, 4, 4): 372 registers -- ONE wave per SIMD, four quads of taps in flight -- and 128 left on the SIMD: the demodulator's waves
+	// (73 used, 80 allocated) fit beside it.  (2, 4, 2) at 256 registers runs two waves per SIMD, is faster alone and leaves no room: the
+	// demodulator takes turns with it and the pipeline loses 10 % (profiles/r05/k4_tilings_in_pipeline.txt).  The thirty-two-column
+	// (1, 4, 4) takes 420 registers; two waves of it held to 208 beside a demodulator wave (laboratory tiling 25) gain nothing in the
+	// pipeline: the denser the matrix instructions, the less the demodulator's waves get to issue (profiles/r06_experiments.md)
 	F16(2, 4, 4), F16(2, 4, 2),
 	F4(2, 4, 2),
 	F32(1, 4, 4), F32(1, 4, 2),

@@ -318,8 +318,8 @@ static_assert(HFDL_GPU_FOLD_BATCH_MAX == FOLD_MAX_BLOCKS, "include/hfdl_gpu.h an
 static int pick_fold_batch(const hfdl_gpu_frontend *fe)
 {
 	// 32 where the fold bounds the block (128 channels and more): two column groups of the sixteen-column matrix instruction per loaded tap
-	// operand.  The launch sits on the board's power budget -- its time is the matrix time plus the memory time (profiles/r06_experiments.md)
-	// -- so a block's share shrinks with the blocks per byte of taps: 0.212 ms per block at 32 against 0.245 at 16 in the pipeline.  The
+	// operand.  A launch costs about its matrix time plus its memory time (fold_kernels.hip, profiles/r06_experiments.md), so a block's share
+	// shrinks with the blocks per byte of taps: 0.20 ms per block at 32 against 0.245 at 16 in the pipeline.  The
 	// first half after a drain closes at 16 (half_first).  Where the demodulator bounds the block (fewer than 128 channels: the taps are a
 	// few hundred MiB and a fold launch takes 0.2 ms whatever it folds) a long half only adds fill, drain and latency: 8, as in round 4
 	// (cfg2: 0.1545 against 0.1595 ms per block over 256 blocks)

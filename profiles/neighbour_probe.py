@@ -39,6 +39,7 @@ MODES = [
     (0, "nothing beside it"),
     (1, "matrix pipe only (64 MFMA per quad, back to back)"),
     (1000, "matrix pipe only, inline-asm instructions, back to back"),
+    (2000, "matrix pipe only, the short form: v_mfma_f32_4x4x1_16B_f32 (2 passes) back to back, the same multiply-accumulates per quad"),
     (1008, "matrix pipe only, 8 idle cycles of the issuing wave behind every instruction"),
     (1016, "matrix pipe only, 16 idle cycles behind every instruction"),
     (1020, "matrix pipe only, 20 idle cycles behind every instruction"),
