@@ -602,7 +602,7 @@ def host_ram_leg(torch, hf, F, fe, x, g, nblocks, steps):
     el2, raw2, _ = timed_blocks(torch, fe, hpush, k2, warm, nblocks, prefetch_fn=hprefetch)
     return hbuf, dict(value=k2 * g.input_size / el2 / 1e6, unit="Msamples/s", steps=k2, ms_per_step=el2 / k2 * 1e3,
                       path="cf32 blocks in page-locked host RAM -> hfdl_gpu_frontend_prefetch_block_raw / push_block_raw (copy stream, a ring of "
-                           "fold_batch + 2 staging buffers in HBM: uploads run a whole half ahead of the kernels) -> same kernels; PCIe-inclusive",
+                           "up to 18 staging buffers in HBM: uploads run up to 17 blocks ahead of the kernels) -> same kernels; PCIe-inclusive",
                       pcie_GBs=k2 * g.input_size * 8 / el2 / 1e9, pdus=sum(n for _, n in raw2))
 
 

@@ -9,8 +9,9 @@ WL=${1:-cfg3}
 OUT=${2:-/root/repo/gpurun_out/pmc_$WL}
 COMMIT=${3:-unknown}
 # fold launches of the profiled command in launch order: the warm-up's 8 blocks (closed by a poll), then the 68 timed ones: 16 + 32 +
-# (16 + 4) (cfg3 / cfg4: the fold bounds the block) or halves of 8 (cfg2: the demodulator does)
-if [ "$WL" = "cfg2" ]; then SHAPES=8,8,8,8,8,8,8,8,8,4; else SHAPES=8,16,32,16,4; fi
+# (16 + 4) (cfg3 / cfg4: the fold bounds the block) or halves of 8 (cfg2: the demodulator does), then the five one-block launches of the
+# bench's latency leg (block_to_pdus_latency_ms)
+if [ "$WL" = "cfg2" ]; then SHAPES=8,8,8,8,8,8,8,8,8,4,1,1,1,1,1; else SHAPES=8,16,32,16,4,1,1,1,1,1; fi
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_${WL}_*
