@@ -51,7 +51,9 @@ WORKLOADS = {
     # BASELINE.json configs[3]: same geometry, every channel carries back-to-back bursts cycling all 8 modes (Viterbi batch stress)
     "cfg4": dict(fs=40_000_000, centerfreq=15_000_000, nch=256, grid=150_000, blocks=32, seed=4, noise=0.05, dense=True,
                  name="40 Msps cf32, 256 HFDL channels, burst-dense: back-to-back 300/600/1200/1800 bps single+double-slot bursts (BASELINE.json configs[3])"),
-    # BASELINE.json configs[1]: 8 Msps, 32 channels on a 200 kHz grid
+    # BASELINE.json configs[1]: 8 Msps, 32 channels on a 200 kHz grid.  SURVEY.md 8(d) words it with 30 s of signal: the bench keeps 26 blocks
+    # (3 s) resident in HBM and replays them (it measures a rate); the thirty seconds themselves -- burst-dense, all eight modes, a cs16 file
+    # through hfdl_replay against the oracle on every channel -- are tests/test_gpu_parity.py::test_cfg2_thirty_seconds_through_the_c_host_program
     "cfg2": dict(fs=8_000_000, centerfreq=10_000_000, nch=32, grid=200_000, blocks=26, seed=2, noise=0.02,
                  name="8 Msps cf32, 32 HFDL channels (BASELINE.json configs[1])"),
 }

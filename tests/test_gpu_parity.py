@@ -318,6 +318,37 @@ def test_end_to_end_cfg2_shape(gpu, oracle):
         assert p["octets"][:len(by_freq[p["freq"]])] == by_freq[p["freq"]]
 
 
+def test_cfg2_thirty_seconds_through_the_c_host_program(gpu, oracle, tmp_path):
+    """BASELINE.json configs[1] at the duration SURVEY.md 8(d) words it with: 8 Msps, 32 channels on a 200 kHz grid, THIRTY seconds of
+    burst-dense traffic in all eight modes, as a cs16 file through hfdl_replay (the C host path: file input -> page-locked ring -> GPU
+    front end -> pdu_decoder_queue_push), against the oracle on the same converted samples, every channel.  (bench.WORKLOADS["cfg2"]
+    keeps 26 blocks = 3 s resident in HBM and replays them: the bench measures rate, this test the thirty seconds.)"""
+    import os
+    fs, cf = 8_000_000, 10_000_000
+    freqs = [int(cf + (i - 16) * 200_000 + 37_000) for i in range(32)]
+    dur = 30.0
+    bursts = synth.plan_traffic(freqs, dur - 0.4, seed=21, dense=True, amp=(0.008, 0.03))
+    x = synth.synth_wideband(fs, cf, int(dur * fs), bursts, noise_sigma=0.02, seed=21)
+    raw = np.clip(np.round(x.view(np.float32) * 20000), -32768, 32767).astype(np.int16)
+    del x
+    got = _replay(tmp_path, raw, "CS16", fs, cf, freqs)
+    x_in = (raw.astype(np.float32) / np.float32(32767.5)).view(np.complex64)       # what convert_cs16 produces
+    del raw
+    threads = max(1, min(64, os.cpu_count() or 1))
+    ora = oracle.Frontend(fs, cf, freqs, nthreads=threads)
+    n = ora.ddc.input_size
+    for b in range(len(x_in) // n):
+        ora.push_block(x_in[b * n:(b + 1) * n], nthreads=threads)
+    want = [(p["freq"], p["bit_rate"], p["slot"], p["octets"]) for p in ora.pdus]
+    assert sorted(got) == sorted(want)
+    # the preamble search loses 1 - 3 % of bursts on both sides alike (oracle/PINNING.md); everything else is there, intact
+    assert len(got) >= 0.95 * len(bursts) and len(bursts) >= 200
+    sent = {}
+    for b in bursts:
+        sent.setdefault(b["freq"], []).append(b["octets"])
+    assert all(any(o[:len(s)] == s for s in sent[f]) for f, _, _, o in got)
+
+
 def test_no_device_pointer_confusion(gpu):
     with pytest.raises(F.GpuError):
         gpu.Frontend(250000, 10_000_000, [20_000_000])      # outside +-fs/2
