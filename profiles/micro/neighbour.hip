@@ -11,6 +11,7 @@
 //   bit 3  barrier       one s_barrier per quad
 //   bit 4  HBM reads     5 KiB per quad and wave of non-temporal 16-byte loads (4 KiB of taps + the spectrum share)
 //   bit 5  vector ALU    16 DPP moves per quad (the rotated operand)
+//   3000           v_mfma_f32_16x16x32_bf16 back to back (the bf16 matrix pipe: what an exact multi-term split of the fp32 product would run on)
 //   2000           the matrix pipe alone on v_mfma_f32_4x4x1_16B_f32: the same multiply-accumulates in instructions of 2 passes instead of 8
 //   1000 + n       the matrix pipe alone with n idle cycles (s_nop) of the issuing wave behind every instruction
 //   bit 6  no pacing     without bit 0 a quad is otherwise padded to ~2048 cycles by s_sleep; with bit 6 it runs flat out
@@ -102,7 +103,13 @@ __global__ __launch_bounds__(256) void neighbour_kernel(const v4f *__restrict__ 
 			for (int r = 0; r < 4; r++)
 #pragma unroll
 				for (int j = 0; j < 16; j++) {
-					if constexpr (NOPS == -2) {        // the same multiply-accumulates in the short form: four v_mfma_f32_4x4x1_16B_f32 (2 passes each) per 16x16x4 (8 passes)
+					if constexpr (NOPS == -3) {        // the bf16 matrix instruction (16 x the multiply-accumulates per instruction): does IT leave the vector issue alone?
+						typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+						v8bf a8, b8;
+#pragma unroll
+						for (int e = 0; e < 8; e++) { a8[e] = (__bf16)h[e & 3]; b8[e] = (__bf16)x[j & 1][e & 3]; }
+						acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[j], 0, 0, 0);
+					} else if constexpr (NOPS == -2) {        // the same multiply-accumulates in the short form: four v_mfma_f32_4x4x1_16B_f32 (2 passes each) per 16x16x4 (8 passes)
 #pragma unroll
 						for (int u = 0; u < 4; u++) acc[(j + 4 * u) & 15] = __builtin_amdgcn_mfma_f32_4x4x1f32(h[(j + u) & 3], x[j & 1][r], acc[(j + 4 * u) & 15], 0, 0, 0);
 					} else if constexpr (NOPS >= 0) mfma_paced<NOPS>(acc[j], h[j & 3], x[j & 1][r]);
@@ -159,7 +166,8 @@ extern "C" int neighbour_start(int mode, const void *src, size_t bytes, double m
 	case 1020: return go<1, 20>(src, bytes, ms, groups);
 	case 1024: return go<1, 24>(src, bytes, ms, groups);
 	case 1028: return go<1, 28>(src, bytes, ms, groups);
-	case 2000: return go<1, -2>(src, bytes, ms, groups);        // the matrix pipe alone on the 4x4x1_16B form: 256 instructions of 2 passes per quad
+	case 2000: return go<1, -2>(src, bytes, ms, groups);
+	case 3000: return go<1, -3>(src, bytes, ms, groups);        // v_mfma_f32_16x16x32_bf16 back to back        // the matrix pipe alone on the 4x4x1_16B form: 256 instructions of 2 passes per quad
 	M(1) M(2) M(4) M(6) M(14) M(16) M(32) M(33) M(15) M(31) M(63) M(66) M(68) M(80) M(78) M(96)
 #undef M
 	}

@@ -40,6 +40,7 @@ MODES = [
     (1, "matrix pipe only (64 MFMA per quad, back to back)"),
     (1000, "matrix pipe only, inline-asm instructions, back to back"),
     (2000, "matrix pipe only, the short form: v_mfma_f32_4x4x1_16B_f32 (2 passes) back to back, the same multiply-accumulates per quad"),
+    (3000, "the bf16 matrix instruction (v_mfma_f32_16x16x32_bf16) back to back"),
     (1008, "matrix pipe only, 8 idle cycles of the issuing wave behind every instruction"),
     (1016, "matrix pipe only, 16 idle cycles behind every instruction"),
     (1020, "matrix pipe only, 20 idle cycles behind every instruction"),
