@@ -949,11 +949,11 @@ def main():
             # who bounds a half: kernel time per stream and half of `fold_batch` blocks, summed from the dispatches'
             # own events over the timed region (streams overlap: the largest is the bound, the sum is not the step)
             "streams": stream_budget(stages, args.steps, fold_batch),
-            # The dominant kernel: the fold.  Since round 5 it multiplies ONE pass over the filter taps into the spectra of up to 16 queued
-            # blocks on the fp32 matrix pipe, all sixteen columns of the instruction always computed: its time does not move with the blocks
-            # in a launch (3.9 - 4.2 ms at 5 .. 16) -- the multiplies bound it, at the clock the board's power budget leaves beside 4.6 TB/s
-            # of HBM reads (PMC: profiles/r05_experiments.md) -- so the roofline is the matrix pipe's; the HBM side of the same launch is
-            # `hbm`.  Launches of at most four blocks run the four-column form, bound by the HBM reads: priced as such when they dominate.
+            # The dominant kernel: the fold.  It multiplies ONE pass over the filter taps into the spectra of up to 32 queued blocks on the
+            # fp32 matrix pipe (sixteen columns of the instruction per group of up to 16 blocks, all of them always computed).  Both sides of
+            # the launch are priced -- `mfma` (dense fp32 matrix peak) and `hbm` -- and `bound` / `frac` name the side nearer its peak: the
+            # 32-block launches of a long run lie right of the ridge (28.7 flop/B), the 16-block launch of a short run left of it, launches
+            # of at most four blocks (the four-column form) are bound by the HBM reads of the taps.
             "roofline": {"bound": "mfma" if wide else "hbm",
                          "kernel": "fold_mfma16_kernel, %s" % fold_form(dom) if dom else None,
                          "achieved": tflops if wide else achieved, "peak": FP32_MFMA_PEAK_TFLOPS if wide else HBM_PEAK_GBS, "unit": "TFLOP/s" if wide else "GB/s",

@@ -71,17 +71,18 @@ typedef struct {
 	                                    decimation remainder is non-zero (post_input_size not a multiple of post_decimation);
 	                                    size HFDL_GPU_TAP_CHAN_OUT buffers from this */
 	int32_t demod_batch;             /* blocks one demodulator launch takes when they are pushed faster than they are collected (up to one second
-	                                    of signal, cut down to what fits the LDS: 2 at 40 Msps, up to 8 on the small geometries).  Results do not
+	                                    of signal, cut down to what fits the LDS: 3 at 40 Msps, up to 8 on the small geometries).  Results do not
 	                                    depend on it; a poll / sync always demodulates what has been pushed.  HFDL_GPU_DEMOD_BATCH=1..8 overrides
 	                                    the default at create time.  0 from hfdl_gpu_plan_geometry() */
 	int32_t fold_batch;              /* blocks whose spectra one fold launch multiplies against ONE pass over the per-channel filter taps when
 	                                    they are pushed faster than they are collected (src/fastddc.c:123-150 run for that many blocks; the taps are
 	                                    > 99 % of a block's bytes on the 256-channel geometries).  Every block's result is bit-identical to a launch
 	                                    of its own; a poll / sync always folds what has been pushed.  HFDL_GPU_FOLD_BATCH=1..32 overrides the default
-	                                    (16 from 128 channels up, where the fold bounds the block; 8 below) at create time.  0 from hfdl_gpu_plan_geometry() */
+	                                    (32 from 128 channels up, where the fold bounds the block -- the first half after a drain closes at 16 --; 8 below) at create time.  0 from hfdl_gpu_plan_geometry() */
 	int32_t prefetch_depth;          /* host blocks whose upload hfdl_gpu_frontend_prefetch_block_raw() may queue ahead of their push
 	                                    (half + 1, for a staging ring of half + 2 buffers in HBM, where a half = the blocks between two fold / inverse-FFT
-	                                    phases = fold_batch rounded up to hold at least demod_batch blocks); at most HFDL_GPU_PREFETCH_MAX.
+	                                    phases = fold_batch rounded up to hold at least demod_batch blocks); at most HFDL_GPU_PREFETCH_MAX (a 32-block
+	                                    half is not uploaded a whole half ahead: 17 blocks of link time cover its fold several times over).
 	                                    0 from hfdl_gpu_plan_geometry() */
 	int32_t fold_rows;               /* alias rows a fold workgroup adds up at most: pre_decimation (all of them, the reference's sum term for
 	                                    term) unless HFDL_GPU_FOLD_PRUNE is set.  0 from hfdl_gpu_plan_geometry() */
