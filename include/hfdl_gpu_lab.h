@@ -7,6 +7,12 @@
  *
  *   HFDL_GPU_FFT_STREAM=1     forward FFTs of the half being filled on a stream of their own (measured slower in round 4)
  *   HFDL_GPU_DECODE_STREAM=0  burst decoders back on the demodulators' stream
+ *   HFDL_GPU_FOLD_TILE=i      the i-th entry of fold_kernels.hip fold_variants[] instead of the first that fits (25: the thirty-two-column
+ *                             tiling with two waves of 208 registers per SIMD)
+ *   HFDL_GPU_FOLD_SLICES=s    slices of alias rows per fold workgroup column (a power of two; default: channels x slices >= 256)
+ *   HFDL_GPU_FOLD_RAMP=0      the first half after a drain as long as the others (default: 16 blocks where halves are 32)
+ *   HFDL_GPU_FOLD_BOUND=0|1   override "the fold bounds the block" (128 channels and more): halves of 8 / 32, demodulator batch
+ *   HFDL_GPU_CU_SPLIT=k       k = 2 .. 8: the demodulators' stream on every k-th CU, the channelizer's on the others (hipExtStreamCreateWithCUMask)
  *   HFDL_GPU_PROBE_VERBOSE=1  the stream-read probe prints every variant
  */
 #ifndef HFDL_GPU_LAB_H
