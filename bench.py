@@ -234,6 +234,13 @@ def parity_gate(w, x, input_size, hf, dev_index, cores, max_seconds=25.0):
     pyoracle.select_build("strict")
     freqs = channel_plan(w)
     cs = min(len(freqs), cores)
+    try:
+        ram_gib = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2.0 ** 30
+    except (ValueError, OSError):
+        ram_gib = 0.0
+    if (os.cpu_count() or 1) >= 32 and ram_gib >= 128:
+        # a host with the cores and the memory for the oracle's filters (8 N bytes per channel: 16 GiB at cfg3) checks EVERY channel
+        cs, cores = len(freqs), max(cores, min(os.cpu_count(), 256))
     sel = freqs[:: max(1, len(freqs) // cs)][:cs]
     ora = pyoracle.Frontend(w["fs"], w["centerfreq"], sel, nthreads=cores)
     fe = hf.Frontend(w["fs"], w["centerfreq"], sel, device=dev_index)
@@ -286,6 +293,9 @@ def cpu_baseline(w, x, input_size, target_seconds=20.0):
     from oracle import pyoracle
     libs = probe_cpu_libs()
     pyoracle.select_build("fast")
+    # 64 threads at most, the channel part scaled to the full channel count.  (Measured once on a 256-thread box with all 256 channels
+    # on 256 threads: 14.8 Msamples/s against 44.7 by this estimate -- the oracle's filters, 16 GiB initialised by one thread, then sit
+    # on one memory node; the scaled 64-thread figure is the one that does not flatter the GPU.  profiles/r06_experiments.md)
     cores = max(1, min(os.cpu_count() or 1, 64))
     freqs = channel_plan(w)
     cs = min(len(freqs), cores)
